@@ -1,0 +1,156 @@
+/*
+ * neurosis_hip.h -- C-ABI of libneurosis_hip.so: the MI355X (gfx950) kernels behind the SDXL
+ * training-step hot path of neggles/neurosis.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, non-zero on error; nk_last_error() gives the message.
+ *     Nothing falls back to a CPU path: a bad argument or a failed launch is an error.
+ *   - all pointers are DEVICE pointers unless the name says host; `stream` is a hipStream_t passed as void*.
+ *   - activations are bf16 (raw uint16 bits), physically channels-last: an image batch is [N][H][W][C],
+ *     a token matrix is [rows][C].  Parameters are fp32 masters with bf16 shadows; conv weights are
+ *     [Cout][KH][KW][Cin] (= an OIHW tensor in torch.channels_last memory format), Linear weights [out][in].
+ *   - gradients of parameters are fp32 and are written ("accumulate=0") or added ("accumulate=1") in place.
+ *   - kernels are asynchronous on `stream`; no entry point synchronises, allocates or frees device memory
+ *     (so every one of them can be captured into a hipGraph).
+ *
+ * Each declaration cites the reference call site it replaces (paths relative to
+ * /root/reference/src/neurosis/).
+ */
+#ifndef NEUROSIS_HIP_H
+#define NEUROSIS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* nk_last_error(void);
+int nk_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * nn.Linear  (modules/attention.py:53,65,70,204-209,283-290,618,639; modules/diffusion/openaimodel.py:273-279,
+ * 586-590,612-618).  1x1 Conv2d on channels-last data is the same contraction (openaimodel.py:301 skip_connection,
+ * modules/diffusion/model.py:150-153 q/k/v/proj_out, :108 nin_shortcut).
+ * ---------------------------------------------------------------------------------------------- */
+/* y[M,N] = alpha * x[M,K] @ w[N,K]^T + bias[N] + residual[M,N]      (bias, residual optional = NULL) */
+int nk_linear_fwd(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                  int M, int N, int K, long ldx, long ldw, long ldr, long ldy, float alpha, void* stream);
+/* dx[M,K] = dy[M,N] @ w[N,K] + dx_add[M,K]                          (dx_add optional) */
+int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add, void* dx, int M, int N, int K,
+                    long lddy, long ldw, long ldadd, long lddx, void* stream);
+/* dw[N,K] (+)= dy[M,N]^T @ x[M,K]   fp32 */
+int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy, long ldx,
+                    long lddw, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * nn.Conv2d as implicit GEMM  (openaimodel.py:124 Upsample.conv, :183-190 Downsample.op, :247-301 ResBlock convs,
+ * :622-624 input conv, :797-801 out conv; model.py:71-79 asymmetric-pad stride-2 conv, :98-102, :519, :540 VAE convs).
+ * upsample=1 fuses F.interpolate(scale_factor=2, mode="nearest") (openaimodel.py:140) into the gather.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct NkConvDesc {
+  int N, H, W, Cin;   /* input  x [N][H][W][Cin] (before the optional virtual 2x upsample) */
+  int Cout, KH, KW;   /* weight w [Cout][KH][KW][Cin] */
+  int stride;         /* 1 or 2 */
+  int pad_t, pad_l;   /* zero padding on top / left; bottom / right are implied by Ho, Wo */
+  int Ho, Wo;         /* output y [N][Ho][Wo][Cout] */
+  int upsample;       /* 1: x is read as its 2x nearest-neighbour upsampling */
+} NkConvDesc;
+/* y = conv(x, w) + bias[Cout] + rowvec[n][Cout] + residual[N][Ho][Wo][Cout]   (all three optional) */
+int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
+                  const void* residual, void* y, void* stream);
+/* dx over the conv input grid ([N][2H][2W][Cin] when upsample=1: follow with nk_upsample2x_bwd) */
+int nk_conv2d_dgrad(const NkConvDesc* d, const void* dy, const void* w, void* dx, void* stream);
+/* dw[Cout][KH][KW][Cin] (+)= ...  fp32 */
+int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention  softmax(q k^T * scale) v, no mask, no dropout
+ * (modules/attention.py:410-412 TorchSDPCrossAttention, :337-352 MemoryEfficientCrossAttention).
+ * q/k/v/o are token-major [B][L][H*D] views with explicit row and batch strides (elements), so they can be
+ * column slices of a fused projection buffer.  lse is [B][H][Lq] fp32 (saved for the backward).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct NkAttnDesc {
+  int B, H, Lq, Lk, D;          /* D % 8 == 0, D <= 160 */
+  long sq, sk, sv, so;          /* row strides of q, k, v, o */
+  long bq, bk, bv, bo;          /* batch strides */
+  long sdq, sdk, sdv, sdo;      /* backward only: row strides of dq, dk, dv, do */
+  long bdq, bdk, bdv, bdo;      /* backward only: batch strides */
+  float scale;                  /* D^-0.5 */
+} NkAttnDesc;
+int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, void* o, float* lse,
+                     void* stream);
+/* delta_ws: fp32 workspace [B][H][Lq] */
+int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, const void* o,
+                     const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* delta_ws, void* stream);
+/* in-place row softmax on bf16 [M][L]: the unfused single-head d=512 attention of the VAE mid block
+ * (modules/diffusion/model.py:224-243) = nk_linear_fwd (q k^T) -> nk_softmax_rows -> nk_linear_dgrad (p v) */
+int nk_softmax_rows(void* s, long M, int L, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm(32, C) (+ fused SiLU) on channels-last x [N][HW][C]
+ * (openaimodel.py:247-250,281-283,797-799; attention.py:612 with eps 1e-6, no SiLU; layers.py:5-7 Normalize).
+ * mean/rstd: [N][G] fp32 (saved for backward).  stats_ws / gsum_ws: fp32 workspace [N][G][2].
+ * Backward adds into dgamma/dbeta (fp32) and optionally adds dx_add into dx.
+ * ---------------------------------------------------------------------------------------------- */
+int nk_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     float* stats_ws, int N, int HW, int C, int G, float eps, int silu, void* stream);
+int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                     const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* gsum_ws,
+                     int N, int HW, int C, int G, int silu, void* stream);
+
+/* nn.LayerNorm(C) over rows of [M][C] (attention.py:468-470).  mean/rstd: [M] fp32. */
+int nk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     int M, int C, float eps, void* stream);
+int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                     const void* dx_add, void* dx, float* dgamma, float* dbeta, int M, int C, void* stream);
+
+/* GEGLU (attention.py:55-57): y[M][I] = u[:, :I] * gelu_erf(u[:, I:]) */
+int nk_geglu_fwd(const void* u, void* y, long M, int I, void* stream);
+int nk_geglu_bwd(const void* dy, const void* u, void* du, long M, int I, void* stream);
+
+/* nn.SiLU on a flat bf16 array (openaimodel.py:274,588,615) */
+int nk_silu_fwd(const void* x, void* y, long n, void* stream);
+int nk_silu_bwd(const void* dy, const void* x, void* dx, long n, void* stream);
+
+/* out = a + b on flat bf16 arrays: gradient join where one tensor feeds two consumers (skip connections,
+ * openaimodel.py:832-836) */
+int nk_add(const void* a, const void* b, void* out, long n, void* stream);
+
+/* torch.cat([h, skip], dim=1) on channels-last rows and its backward (openaimodel.py:836) */
+int nk_cat_channels(const void* a, const void* b, void* out, long rows, int Ca, int Cb, void* stream);
+int nk_split_channels(const void* src, void* a, void* b, long rows, int Ca, int Cb, void* stream);
+
+/* backward of F.interpolate(scale_factor=2, mode="nearest") (openaimodel.py:140): 2x2 sum-pool */
+int nk_upsample2x_bwd(const void* dup, void* dx, int N, int H, int W, int C, void* stream);
+
+/* boundary layout/dtype conversion: NCHW (fp32 or bf16) <-> channels-last bf16 with channels padded to Cpad */
+int nk_nchw_to_nhwc(const void* src, int src_is_f32, void* dst, int N, int C, int HW, int Cpad, float scale,
+                    void* stream);
+int nk_nhwc_to_nchw(const void* src, void* dst, int dst_is_f32, int N, int C, int HW, int Cpad, void* stream);
+int nk_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+int nk_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream);
+
+/* bias gradient: out[N] (+)= sum over rows of dy[M][N] (row stride ld) */
+int nk_colsum(const void* dy, float* out, long M, int N, long ld, int accumulate, void* stream);
+
+/* timestep_embedding (modules/diffusion/util.py:152-177): out[B][dim] bf16 = [cos | sin](t * freq) */
+int nk_timestep_embedding(const float* t, void* out, int B, int dim, float max_period, void* stream);
+
+/* StandardDiffusionLoss "edm" branch + Denoiser scaling (modules/diffusion/loss.py:117-157,
+ * modules/diffusion/denoiser.py:41-53, modules/losses/functions.py:91-94).
+ * prepare: z_t = x + sigma*eps (fp32 NCHW); net_in = bf16 channels-last z_t*c_in, channels padded to Cpad.
+ * loss:    D = net_out*c_out + z_t*c_skip; loss[b] = w[b]*mean((D-target)^2);
+ *          dnet (optional) = upstream * dloss[b]/dnet_out, bf16 channels-last padded. */
+int nk_edm_prepare(const float* x, const float* eps, const float* sigma, const float* c_in, float* zt, void* net_in,
+                   int B, int C, int HW, int Cpad, void* stream);
+int nk_edm_loss(const void* net_out, const float* zt, const float* target, const float* c_out, const float* c_skip,
+                const float* w, float* loss, void* dnet, int B, int C, int HW, int Cpad, float upstream, void* stream);
+
+/* Fused AdamW over the flat fp32 parameter buffer; also rewrites the bf16 shadow the kernels read.
+ * (The optimizer itself is outside SURVEY section 8(a); bench.py needs a real parameter update in the timed step.) */
+int nk_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,580 @@
+// Flash-style multi-head attention for the SpatialTransformer blocks (gfx950 / CDNA4), forward and
+// backward, softmax(Q K^T * scale) V with no mask and no dropout.
+// Reference: TorchSDPCrossAttention.forward (modules/attention.py:369-417) /
+// MemoryEfficientCrossAttention.forward (modules/attention.py:293-366).
+//
+// Layout: tokens-major "[B][L][H*D]" views with arbitrary row stride, so q/k/v can be column slices of
+// one fused projection buffer and the output feeds to_out directly -- no head transposes in HBM.
+//
+// MFMA orientation (v_mfma_f32_32x32x16_bf16): the score tile is computed TRANSPOSED, S^T[key][q] =
+// K Q^T, so a query row lives on one lane (col = lane&31): the online-softmax state (m, l) is a per-lane
+// scalar, the P^T accumulator is directly the B operand of the next product (O^T += V^T P^T) with no
+// LDS round trip, and V^T / K^T / Q^T / dO^T operands come from row-major LDS tiles through the
+// transposing ds_read_b64_tr_b16.
+//
+// forward : 1 kernel, 128 queries per workgroup (4 waves x 32), KV tiles of 64 keys double-buffered in LDS
+// backward: delta = rowsum(dO*O); dK/dV kernel (keys on lanes, loops over query tiles, no atomics);
+//           dQ kernel (queries on lanes, loops over key tiles, no atomics).  P is recomputed from LSE.
+#include "../../include/neurosis_hip.h"
+#include "nk_common.h"
+
+struct AttnParams {
+  const bf16_t *Q, *K, *V, *dO;
+  const bf16_t* Oc;     // forward output (backward: for delta)
+  bf16_t *O, *dQ, *dK, *dV;
+  float* LSE;           // [B][H][Lq] natural-log sum-exp of scaled scores
+  float* delta;         // [B][H][Lq]
+  int B, H, Lq, Lk, D;
+  long sq, sk, sv, so;      // row (token) strides in elements
+  long bq, bk, bv, bo;      // batch strides in elements
+  long sdq, sdk, sdv, sdo;  // strides of gradients
+  long bdq, bdk, bdv, bdo;
+  float scale;
+};
+
+#define LOG2E 1.4426950408889634f
+#define NEG_BIG (-1.0e30f)
+
+typedef __attribute__((address_space(3))) short4_t* lds_s4p;
+
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int rs_bytes, int row0, int col0, int lane) {
+  // A-operand fragment of a 32x32x16 MFMA whose rows run along the tile's COLUMNS:
+  //   lane (r = lane&31, h = lane>>5), element j <- tile[row0 + 4h + (j&3) + 8*(j>>2)][col0 + r]
+  const int g = lane >> 4, i = lane & 15, q4 = i >> 2, p = i & 3, h = g >> 1;
+  const int byte = (row0 + 4 * h + q4) * rs_bytes + (col0 + 16 * (g & 1) + 4 * p) * 2;
+  short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + byte));
+  short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + byte + 8 * rs_bytes));
+  short8_t r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int rs_bytes, int row0, int ks, int lane) {
+  // A-operand fragment whose rows are the tile's rows: elem j <- tile[row0 + (lane&31)][16ks + 8(lane>>5) + j]
+  const int byte = (row0 + (lane & 31)) * rs_bytes + (16 * ks + 8 * (lane >> 5)) * 2;
+  return *(const bf16x8_t*)(tile + byte);
+}
+__device__ __forceinline__ bf16x8_t pack_frag(const float16_t& x, int s) {
+  // registers 8s..8s+7 of an accumulator tile as the bf16 B operand of k-step s
+  uint4_t v;
+  v.x = pack2bf(x[8 * s + 0], x[8 * s + 1]); v.y = pack2bf(x[8 * s + 2], x[8 * s + 3]);
+  v.z = pack2bf(x[8 * s + 4], x[8 * s + 5]); v.w = pack2bf(x[8 * s + 6], x[8 * s + 7]);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// cooperative load of a [ROWS][DP] tile (rows >= nrows or cols >= D read as zero) into registers / LDS
+template <int ROWS, int DP>
+struct TileLoader {
+  static constexpr int CPR = DP / 8;
+  static constexpr int PER = (ROWS * CPR + 255) / 256;
+  static constexpr int RS = DP * 2 + 16;
+  uint4_t v[PER];
+  __device__ __forceinline__ void load(const bf16_t* base, long stride, int row0, int nrows, int D, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int c = tid + 256 * i;
+      int row = c / CPR, ch = c - row * CPR;
+      uint4_t z = {0u, 0u, 0u, 0u};
+      if (c < ROWS * CPR && row0 + row < nrows && ch * 8 < D)
+        z = *(const uint4_t*)(base + (long)(row0 + row) * stride + ch * 8);
+      v[i] = z;
+    }
+  }
+  __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int c = tid + 256 * i;
+      int row = c / CPR, ch = c - row * CPR;
+      if (c < ROWS * CPR) *(uint4_t*)(tile + row * RS + ch * 16) = v[i];
+    }
+  }
+};
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <int DP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 64 * RS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K,V][64][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, ql = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float c = p.scale * LOG2E;
+
+  const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * p.D;
+  const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * p.D;
+  const bf16_t* Vb = p.V + (long)b * p.bv + (long)hd * p.D;
+
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4_t z = {0u, 0u, 0u, 0u};
+    int d0 = 16 * ks + 8 * h5;
+    if (q0 + ql < p.Lq && d0 < p.D) z = *(const uint4_t*)(Qb + (long)(q0 + ql) * p.sq + d0);
+    qf[ks] = __builtin_bit_cast(bf16x8_t, z);
+  }
+  float16_t oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  float m = NEG_BIG, l = 0.f;
+
+  const int nt = (p.Lk + 63) / 64;
+  TileLoader<64, DP> lk, lv;
+  lk.load(Kb, p.sk, 0, p.Lk, p.D, tid);
+  lv.load(Vb, p.sv, 0, p.Lk, p.D, tid);
+  lk.store(smem, tid);
+  lv.store(smem + TILE, tid);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* kt = smem + (t & 1) * 2 * TILE;
+    const char* vt = kt + TILE;
+    const bool more = t + 1 < nt;
+    if (more) {
+      lk.load(Kb, p.sk, (t + 1) * 64, p.Lk, p.D, tid);
+      lv.load(Vb, p.sv, (t + 1) * 64, p.Lk, p.D, tid);
+    }
+    float16_t s[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[hf][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, RS, hf * 32, ks, lane), qf[ks], s[hf], 0, 0, 0);
+    }
+    // mask keys beyond Lk, running max
+    float mloc = NEG_BIG;
+    const int kbase = t * 64;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int key = kbase + hf * 32 + acc_row(r, h5);
+        float v = key < p.Lk ? s[hf][r] : NEG_BIG;
+        s[hf][r] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(m, mloc);
+    const float alpha = exp2f((m - mnew) * c);
+    m = mnew;
+    const float mc = mnew * c;
+    float lsum = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = exp2f(s[hf][r] * c - mc);
+        s[hf][r] = pv;
+        lsum += pv;
+      }
+    l = l * alpha + lsum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t pf = pack_frag(s[hf], s2);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vt, RS, hf * 32 + 16 * s2, dt * 32, lane), pf,
+                                                             oacc[dt], 0, 0, 0);
+      }
+    if (more) {
+      char* nk_ = smem + ((t + 1) & 1) * 2 * TILE;
+      lk.store(nk_, tid);
+      lv.store(nk_ + TILE, tid);
+    }
+    __syncthreads();
+  }
+
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  const int q = q0 + ql;
+  if (q < p.Lq) {
+    bf16_t* Ob = p.O + (long)b * p.bo + (long)q * p.so + (long)hd * p.D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        int d = dt * 32 + 8 * r4 + 4 * h5;
+        if (d < p.D) {
+          uint2_t o;
+          o.x = pack2bf(oacc[dt][4 * r4 + 0] * inv, oacc[dt][4 * r4 + 1] * inv);
+          o.y = pack2bf(oacc[dt][4 * r4 + 2] * inv, oacc[dt][4 * r4 + 3] * inv);
+          *(uint2_t*)(Ob + d) = o;
+        }
+      }
+    if (h5 == 0) p.LSE[((long)b * p.H + hd) * p.Lq + q] = m * p.scale + logf(l);
+  }
+}
+
+// ================================================================================================
+// backward: delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+// ================================================================================================
+__global__ void attn_delta_kernel(const AttnParams p) {
+  // one 8-lane group per (b, q, h) row of D elements
+  const long total = (long)p.B * p.Lq * p.H;
+  const int sub = threadIdx.x & 7;
+  for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 3; i < total; i += ((long)gridDim.x * blockDim.x) >> 3) {
+    int hd = (int)(i % p.H);
+    long t = i / p.H;
+    int q = (int)(t % p.Lq);
+    int b = (int)(t / p.Lq);
+    const bf16_t* o = p.Oc + (long)b * p.bo + (long)q * p.so + (long)hd * p.D;
+    const bf16_t* d = p.dO + (long)b * p.bdo + (long)q * p.sdo + (long)hd * p.D;
+    float acc = 0.f;
+    for (int c8 = sub * 8; c8 < p.D; c8 += 64) {
+      float fo[8], fd[8];
+      unpack8(*(const uint4_t*)(o + c8), fo);
+      unpack8(*(const uint4_t*)(d + c8), fd);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += fo[e] * fd[e];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0) p.delta[((long)b * p.H + hd) * p.Lq + q] = acc;
+  }
+}
+
+// ================================================================================================
+// backward: dK, dV.  Workgroup = 128 keys (4 waves x 32 keys on lanes), loops over 32-query tiles.
+// ================================================================================================
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) {
+  constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 32 * RS;
+  constexpr int STAGE = 2 * TILE + 256;  // Q tile, dO tile, lse2[32], delta[32]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, kl = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const float c = p.scale * LOG2E;
+
+  const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * p.D;
+  const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * p.D;
+  const bf16_t* Vb = p.V + (long)b * p.bv + (long)hd * p.D;
+  const bf16_t* dOb = p.dO + (long)b * p.bdo + (long)hd * p.D;
+  const float* lse = p.LSE + ((long)b * p.H + hd) * p.Lq;
+  const float* dl = p.delta + ((long)b * p.H + hd) * p.Lq;
+
+  bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4_t zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+    int d0 = 16 * ks + 8 * h5;
+    if (k0 + kl < p.Lk && d0 < p.D) {
+      zk = *(const uint4_t*)(Kb + (long)(k0 + kl) * p.sk + d0);
+      zv = *(const uint4_t*)(Vb + (long)(k0 + kl) * p.sv + d0);
+    }
+    kf[ks] = __builtin_bit_cast(bf16x8_t, zk);
+    vf[ks] = __builtin_bit_cast(bf16x8_t, zv);
+  }
+  float16_t dk[DT], dv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+  const int nt = (p.Lq + 31) / 32;
+  TileLoader<32, DP> lq, ld_;
+  float st_lse = 0.f, st_dl = 0.f;
+  auto load_stats = [&](int q0) {
+    if (tid < 32) {
+      int q = q0 + tid;
+      st_lse = q < p.Lq ? lse[q] * LOG2E : 1.0e30f;  // invalid query rows -> P = 0
+      st_dl = q < p.Lq ? dl[q] : 0.f;
+    }
+  };
+  auto store_stats = [&](char* stage) {
+    if (tid < 32) {
+      ((float*)(stage + 2 * TILE))[tid] = st_lse;
+      ((float*)(stage + 2 * TILE))[32 + tid] = st_dl;
+    }
+  };
+  lq.load(Qb, p.sq, 0, p.Lq, p.D, tid);
+  ld_.load(dOb, p.sdo, 0, p.Lq, p.D, tid);
+  load_stats(0);
+  lq.store(smem, tid);
+  ld_.store(smem + TILE, tid);
+  store_stats(smem);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* st = smem + (t & 1) * STAGE;
+    const char* qt = st;
+    const char* dot = st + TILE;
+    const float* s_lse = (const float*)(st + 2 * TILE);
+    const float* s_dl = s_lse + 32;
+    const bool more = t + 1 < nt;
+    if (more) {
+      lq.load(Qb, p.sq, (t + 1) * 32, p.Lq, p.D, tid);
+      ld_.load(dOb, p.sdo, (t + 1) * 32, p.Lq, p.D, tid);
+      load_stats((t + 1) * 32);
+    }
+    float16_t s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qt, RS, 0, ks, lane), kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dot, RS, 0, ks, lane), vf[ks], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int qr = acc_row(r, h5);
+      float pv = exp2f(s[r] * c - s_lse[qr]);
+      s[r] = pv;
+      dp[r] = pv * (dp[r] - s_dl[qr]) * p.scale;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8_t pf = pack_frag(s, s2);
+      const bf16x8_t dsf = pack_frag(dp, s2);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dot, RS, 16 * s2, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qt, RS, 16 * s2, dt * 32, lane), dsf, dk[dt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      char* nx = smem + ((t + 1) & 1) * STAGE;
+      lq.store(nx, tid);
+      ld_.store(nx + TILE, tid);
+      store_stats(nx);
+    }
+    __syncthreads();
+  }
+
+  const int key = k0 + kl;
+  if (key < p.Lk) {
+    bf16_t* dKb = p.dK + (long)b * p.bdk + (long)key * p.sdk + (long)hd * p.D;
+    bf16_t* dVb = p.dV + (long)b * p.bdv + (long)key * p.sdv + (long)hd * p.D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        int d = dt * 32 + 8 * r4 + 4 * h5;
+        if (d < p.D) {
+          uint2_t a, v;
+          a.x = pack2bf(dk[dt][4 * r4 + 0], dk[dt][4 * r4 + 1]);
+          a.y = pack2bf(dk[dt][4 * r4 + 2], dk[dt][4 * r4 + 3]);
+          v.x = pack2bf(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
+          v.y = pack2bf(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
+          *(uint2_t*)(dKb + d) = a;
+          *(uint2_t*)(dVb + d) = v;
+        }
+      }
+  }
+}
+
+// ================================================================================================
+// backward: dQ.  Workgroup = 128 queries (on lanes), loops over 64-key tiles.
+// ================================================================================================
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+  constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 64 * RS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, ql = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q = q0 + ql;
+  const float c = p.scale * LOG2E;
+
+  const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * p.D;
+  const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * p.D;
+  const bf16_t* Vb = p.V + (long)b * p.bv + (long)hd * p.D;
+  const bf16_t* dOb = p.dO + (long)b * p.bdo + (long)hd * p.D;
+
+  bf16x8_t qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4_t zq = {0u, 0u, 0u, 0u}, zd = {0u, 0u, 0u, 0u};
+    int d0 = 16 * ks + 8 * h5;
+    if (q < p.Lq && d0 < p.D) {
+      zq = *(const uint4_t*)(Qb + (long)q * p.sq + d0);
+      zd = *(const uint4_t*)(dOb + (long)q * p.sdo + d0);
+    }
+    qf[ks] = __builtin_bit_cast(bf16x8_t, zq);
+    dof[ks] = __builtin_bit_cast(bf16x8_t, zd);
+  }
+  const float lse2 = q < p.Lq ? p.LSE[((long)b * p.H + hd) * p.Lq + q] * LOG2E : 1.0e30f;
+  const float dlt = q < p.Lq ? p.delta[((long)b * p.H + hd) * p.Lq + q] : 0.f;
+
+  float16_t dq[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+  const int nt = (p.Lk + 63) / 64;
+  TileLoader<64, DP> lk, lv;
+  lk.load(Kb, p.sk, 0, p.Lk, p.D, tid);
+  lv.load(Vb, p.sv, 0, p.Lk, p.D, tid);
+  lk.store(smem, tid);
+  lv.store(smem + TILE, tid);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* kt = smem + (t & 1) * 2 * TILE;
+    const char* vt = kt + TILE;
+    const bool more = t + 1 < nt;
+    if (more) {
+      lk.load(Kb, p.sk, (t + 1) * 64, p.Lk, p.D, tid);
+      lv.load(Vb, p.sv, (t + 1) * 64, p.Lk, p.D, tid);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, RS, hf * 32, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vt, RS, hf * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int key = t * 64 + hf * 32 + acc_row(r, h5);
+        float pv = key < p.Lk ? exp2f(s[r] * c - lse2) : 0.f;
+        dp[r] = pv * (dp[r] - dlt) * p.scale;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t dsf = pack_frag(dp, s2);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(kt, RS, hf * 32 + 16 * s2, dt * 32, lane), dsf,
+                                                           dq[dt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      char* nx = smem + ((t + 1) & 1) * 2 * TILE;
+      lk.store(nx, tid);
+      lv.store(nx + TILE, tid);
+    }
+    __syncthreads();
+  }
+
+  if (q < p.Lq) {
+    bf16_t* dQb = p.dQ + (long)b * p.bdq + (long)q * p.sdq + (long)hd * p.D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        int d = dt * 32 + 8 * r4 + 4 * h5;
+        if (d < p.D) {
+          uint2_t a;
+          a.x = pack2bf(dq[dt][4 * r4 + 0], dq[dt][4 * r4 + 1]);
+          a.y = pack2bf(dq[dt][4 * r4 + 2], dq[dt][4 * r4 + 3]);
+          *(uint2_t*)(dQb + d) = a;
+        }
+      }
+  }
+}
+
+// ================================================================================================
+// host
+// ================================================================================================
+static int attn_check(const NkAttnDesc* d) {
+  NK_CHECK_ARG(d != nullptr);
+  NK_CHECK_ARG(d->B > 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0 && d->D > 0);
+  NK_CHECK_ARG((d->D & 7) == 0 && d->D <= 160);
+  NK_CHECK_ARG((d->sq & 7) == 0 && (d->sk & 7) == 0 && (d->sv & 7) == 0 && (d->so & 7) == 0);
+  NK_CHECK_ARG((d->bq & 7) == 0 && (d->bk & 7) == 0 && (d->bv & 7) == 0 && (d->bo & 7) == 0);
+  NK_CHECK_ARG(d->B <= 65535 && d->H <= 65535);
+  return NK_OK;
+}
+static int attn_dp(int D) { return D <= 64 ? 64 : (D <= 96 ? 96 : 160); }
+
+template <typename K>
+static void set_smem(K kern, int bytes) {
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, void* o, float* lse,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = attn_check(d)) return e;
+  NK_CHECK_ARG(q && k && v && o && lse);
+  AttnParams p = {};
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)o; p.LSE = lse;
+  p.B = d->B; p.H = d->H; p.Lq = d->Lq; p.Lk = d->Lk; p.D = d->D;
+  p.sq = d->sq; p.sk = d->sk; p.sv = d->sv; p.so = d->so;
+  p.bq = d->bq; p.bk = d->bk; p.bv = d->bv; p.bo = d->bo;
+  p.scale = d->scale;
+  dim3 grid((d->Lq + 127) / 128, d->H, d->B);
+  const int dp = attn_dp(d->D);
+  const int smem = 2 * 2 * 64 * (dp * 2 + 16);
+#define FWD_CASE(DP_)                                                                          \
+  if (dp == DP_) {                                                                             \
+    set_smem(attn_fwd_kernel<DP_>, smem);                                                      \
+    hipLaunchKernelGGL(attn_fwd_kernel<DP_>, grid, dim3(256), smem, stream, p);                \
+  }
+  FWD_CASE(64) FWD_CASE(96) FWD_CASE(160)
+#undef FWD_CASE
+  return nk_check_launch("attn_fwd_kernel");
+}
+
+extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, const void* o,
+                                const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* delta_ws,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = attn_check(d)) return e;
+  NK_CHECK_ARG(q && k && v && o && lse && d_o && dq && dk && dv && delta_ws);
+  NK_CHECK_ARG((d->sdq & 7) == 0 && (d->sdk & 7) == 0 && (d->sdv & 7) == 0 && (d->sdo & 7) == 0);
+  NK_CHECK_ARG((d->bdq & 7) == 0 && (d->bdk & 7) == 0 && (d->bdv & 7) == 0 && (d->bdo & 7) == 0);
+  AttnParams p = {};
+  p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.Oc = (const bf16_t*)o;
+  p.dO = (const bf16_t*)d_o; p.dQ = (bf16_t*)dq; p.dK = (bf16_t*)dk; p.dV = (bf16_t*)dv;
+  p.LSE = (float*)lse; p.delta = delta_ws;
+  p.B = d->B; p.H = d->H; p.Lq = d->Lq; p.Lk = d->Lk; p.D = d->D;
+  p.sq = d->sq; p.sk = d->sk; p.sv = d->sv; p.so = d->so;
+  p.bq = d->bq; p.bk = d->bk; p.bv = d->bv; p.bo = d->bo;
+  p.sdq = d->sdq; p.sdk = d->sdk; p.sdv = d->sdv; p.sdo = d->sdo;
+  p.bdq = d->bdq; p.bdk = d->bdk; p.bdv = d->bdv; p.bdo = d->bdo;
+  p.scale = d->scale;
+  {
+    long rows = (long)d->B * d->Lq * d->H;
+    long blocks = (rows * 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((int)blocks), dim3(256), 0, stream, p);
+    if (int e = nk_check_launch("attn_delta_kernel")) return e;
+  }
+  const int dp = attn_dp(d->D);
+  {
+    dim3 grid((d->Lk + 127) / 128, d->H, d->B);
+    const int smem = 2 * (2 * 32 * (dp * 2 + 16) + 256);
+#define KV_CASE(DP_)                                                                           \
+  if (dp == DP_) {                                                                             \
+    set_smem(attn_bwd_dkdv_kernel<DP_>, smem);                                                 \
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DP_>, grid, dim3(256), smem, stream, p);           \
+  }
+    KV_CASE(64) KV_CASE(96) KV_CASE(160)
+#undef KV_CASE
+    if (int e = nk_check_launch("attn_bwd_dkdv_kernel")) return e;
+  }
+  {
+    dim3 grid((d->Lq + 127) / 128, d->H, d->B);
+    const int smem = 2 * 2 * 64 * (dp * 2 + 16);
+#define Q_CASE(DP_)                                                                            \
+  if (dp == DP_) {                                                                             \
+    set_smem(attn_bwd_dq_kernel<DP_>, smem);                                                   \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<DP_>, grid, dim3(256), smem, stream, p);             \
+  }
+    Q_CASE(64) Q_CASE(96) Q_CASE(160)
+#undef Q_CASE
+  }
+  return nk_check_launch("attn_bwd_dq_kernel");
+}

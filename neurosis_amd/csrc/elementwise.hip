@@ -1,0 +1,497 @@
+// HBM-bound elementwise / data-movement kernels of the SDXL training step (gfx950).
+// All bf16 traffic is 16 B per lane; fp32 traffic 16 B per lane where the layout allows.
+#include "../../include/neurosis_hip.h"
+#include "nk_common.h"
+
+#define EW_THREADS 256
+static inline int ew_blocks(long work_items) {
+  long b = (work_items + EW_THREADS - 1) / EW_THREADS;
+  if (b > 8192) b = 8192;  // grid-stride the rest
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- GEGLU (modules/attention.py:55-57): y = u[:, :I] * gelu(u[:, I:]) ------------------------
+__global__ void geglu_fwd_kernel(const bf16_t* __restrict__ u, bf16_t* __restrict__ y, long M, int I) {
+  const int cpr = I >> 3;
+  const long total = M * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i / cpr;
+    int ch = (int)(i - row * cpr);
+    float a[8], g[8];
+    unpack8(*(const uint4_t*)(u + row * 2 * I + ch * 8), a);
+    unpack8(*(const uint4_t*)(u + row * 2 * I + I + ch * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] *= gelu_erf(g[e]);
+    *(uint4_t*)(y + row * I + ch * 8) = pack8(a);
+  }
+}
+__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ du,
+                                 long M, int I) {
+  const int cpr = I >> 3;
+  const long total = M * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i / cpr;
+    int ch = (int)(i - row * cpr);
+    float a[8], g[8], d[8], da[8], dg[8];
+    unpack8(*(const uint4_t*)(u + row * 2 * I + ch * 8), a);
+    unpack8(*(const uint4_t*)(u + row * 2 * I + I + ch * 8), g);
+    unpack8(*(const uint4_t*)(dy + row * I + ch * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      da[e] = d[e] * gelu_erf(g[e]);
+      dg[e] = d[e] * a[e] * dgelu_erf(g[e]);
+    }
+    *(uint4_t*)(du + row * 2 * I + ch * 8) = pack8(da);
+    *(uint4_t*)(du + row * 2 * I + I + ch * 8) = pack8(dg);
+  }
+}
+extern "C" int nk_geglu_fwd(const void* u, void* y, long M, int I, void* stream) {
+  NK_CHECK_ARG(u && y && M > 0 && I > 0 && (I & 7) == 0);
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_blocks(M * (I >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)u, (bf16_t*)y, M, I);
+  return nk_check_launch("geglu_fwd");
+}
+extern "C" int nk_geglu_bwd(const void* dy, const void* u, void* du, long M, int I, void* stream) {
+  NK_CHECK_ARG(dy && u && du && M > 0 && I > 0 && (I & 7) == 0);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks(M * (I >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)du, M, I);
+  return nk_check_launch("geglu_bwd");
+}
+
+// ---- SiLU on a flat bf16 array (openaimodel.py:274, 588, 615) ----------------------------------
+__global__ void silu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(*(const uint4_t*)(x + i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+    *(uint4_t*)(y + i * 8) = pack8(f);
+  }
+}
+__global__ void silu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, bf16_t* __restrict__ dx,
+                                long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8], d[8];
+    unpack8(*(const uint4_t*)(x + i * 8), f);
+    unpack8(*(const uint4_t*)(dy + i * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] *= dsilu_f(f[e]);
+    *(uint4_t*)(dx + i * 8) = pack8(d);
+  }
+}
+extern "C" int nk_silu_fwd(const void* x, void* y, long n, void* stream) {
+  NK_CHECK_ARG(x && y && n > 0 && (n & 7) == 0);
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(ew_blocks(n >> 3)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, n >> 3);
+  return nk_check_launch("silu_fwd");
+}
+extern "C" int nk_silu_bwd(const void* dy, const void* x, void* dx, long n, void* stream) {
+  NK_CHECK_ARG(dy && x && dx && n > 0 && (n & 7) == 0);
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_blocks(n >> 3)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, n >> 3);
+  return nk_check_launch("silu_bwd");
+}
+
+// ---- out = a + b (gradient join where a tensor feeds two consumers) ----------------------------
+__global__ void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8], g[8];
+    unpack8(*(const uint4_t*)(a + i * 8), f);
+    unpack8(*(const uint4_t*)(b + i * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += g[e];
+    *(uint4_t*)(o + i * 8) = pack8(f);
+  }
+}
+extern "C" int nk_add(const void* a, const void* b, void* out, long n, void* stream) {
+  NK_CHECK_ARG(a && b && out && n > 0 && (n & 7) == 0);
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n >> 3)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)a,
+                     (const bf16_t*)b, (bf16_t*)out, n >> 3);
+  return nk_check_launch("add");
+}
+
+// ---- channel concat / split on channels-last rows (torch.cat(dim=1), openaimodel.py:836) -------
+// dir 0: out[row] = [a[row] | b[row]] ; dir 1: a[row], b[row] = split(out[row]) (either may be NULL)
+__global__ void cat_kernel(bf16_t* __restrict__ a, bf16_t* __restrict__ b, bf16_t* __restrict__ o, long rows, int Ca,
+                           int Cb, int dir) {
+  const int cpr = (Ca + Cb) >> 3, ca8 = Ca >> 3;
+  const long total = rows * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i / cpr;
+    int ch = (int)(i - row * cpr);
+    bf16_t* side = ch < ca8 ? (a ? a + row * Ca + ch * 8 : nullptr) : (b ? b + row * Cb + (ch - ca8) * 8 : nullptr);
+    if (!side) continue;
+    uint4_t* op = (uint4_t*)(o + i * 8);
+    if (dir == 0) *op = *(const uint4_t*)side;
+    else *(uint4_t*)side = *op;
+  }
+}
+extern "C" int nk_cat_channels(const void* a, const void* b, void* out, long rows, int Ca, int Cb, void* stream) {
+  NK_CHECK_ARG(a && b && out && rows > 0 && Ca > 0 && Cb > 0 && (Ca & 7) == 0 && (Cb & 7) == 0);
+  hipLaunchKernelGGL(cat_kernel, dim3(ew_blocks(rows * ((Ca + Cb) >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (bf16_t*)a, (bf16_t*)b, (bf16_t*)out, rows, Ca, Cb, 0);
+  return nk_check_launch("cat_channels");
+}
+extern "C" int nk_split_channels(const void* src, void* a, void* b, long rows, int Ca, int Cb, void* stream) {
+  NK_CHECK_ARG(src && (a || b) && rows > 0 && Ca > 0 && Cb > 0 && (Ca & 7) == 0 && (Cb & 7) == 0);
+  hipLaunchKernelGGL(cat_kernel, dim3(ew_blocks(rows * ((Ca + Cb) >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (bf16_t*)a, (bf16_t*)b, (bf16_t*)src, rows, Ca, Cb, 1);
+  return nk_check_launch("split_channels");
+}
+
+// ---- backward of nearest 2x upsampling: dx[n,h,w,:] = sum of the 2x2 block of dup --------------
+__global__ void up2_bwd_kernel(const bf16_t* __restrict__ dup, bf16_t* __restrict__ dx, int N, int H, int W, int C) {
+  const int cpr = C >> 3;
+  const long total = (long)N * H * W * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int ch = (int)(i % cpr);
+    long pix = i / cpr;
+    int w = (int)(pix % W);
+    long t = pix / W;
+    int h = (int)(t % H);
+    int n = (int)(t / H);
+    const bf16_t* s = dup + (((long)n * 2 * H + 2 * h) * 2 * W + 2 * w) * C + ch * 8;
+    float acc[8], f[8];
+    unpack8(*(const uint4_t*)s, acc);
+    unpack8(*(const uint4_t*)(s + C), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    unpack8(*(const uint4_t*)(s + (long)2 * W * C), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    unpack8(*(const uint4_t*)(s + (long)2 * W * C + C), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    *(uint4_t*)(dx + i * 8) = pack8(acc);
+  }
+}
+extern "C" int nk_upsample2x_bwd(const void* dup, void* dx, int N, int H, int W, int C, void* stream) {
+  NK_CHECK_ARG(dup && dx && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0);
+  hipLaunchKernelGGL(up2_bwd_kernel, dim3(ew_blocks((long)N * H * W * (C >> 3))), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, (const bf16_t*)dup, (bf16_t*)dx, N, H, W, C);
+  return nk_check_launch("upsample2x_bwd");
+}
+
+// ---- layout / dtype boundary: NCHW (fp32 or bf16) <-> channels-last bf16 with channel padding ---
+// tile of 32 pixels x 32 channels through LDS
+template <typename SrcT>
+__global__ void nchw_to_nhwc_kernel(const SrcT* __restrict__ src, bf16_t* __restrict__ dst, int C, int HW, int Cpad,
+                                    float scale) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, p = p0 + tx;
+    float v = 0.f;
+    if (c < C && p < HW) {
+      if constexpr (sizeof(SrcT) == 4) v = src[((long)n * C + c) * HW + p];
+      else v = bf2f(src[((long)n * C + c) * HW + p]);
+    }
+    tile[j][tx] = v * scale;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int p = p0 + j, c = c0 + tx;
+    if (p < HW && c < Cpad) dst[((long)n * HW + p) * Cpad + c] = f2bf(tile[tx][j]);
+  }
+}
+template <typename DstT>
+__global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, DstT* __restrict__ dst, int C, int HW, int Cpad) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int p = p0 + j, c = c0 + tx;
+    tile[j][tx] = (p < HW && c < C) ? bf2f(src[((long)n * HW + p) * Cpad + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, p = p0 + tx;
+    if (c < C && p < HW) {
+      float v = tile[tx][j];
+      if constexpr (sizeof(DstT) == 4) dst[((long)n * C + c) * HW + p] = v;
+      else dst[((long)n * C + c) * HW + p] = f2bf(v);
+    }
+  }
+}
+extern "C" int nk_nchw_to_nhwc(const void* src, int src_is_f32, void* dst, int N, int C, int HW, int Cpad, float scale,
+                               void* stream) {
+  NK_CHECK_ARG(src && dst && N > 0 && C > 0 && HW > 0 && Cpad >= C);
+  dim3 grid((HW + 31) / 32, (Cpad + 31) / 32, N);
+  if (src_is_f32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src,
+                       (bf16_t*)dst, C, HW, Cpad, scale);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       (bf16_t*)dst, C, HW, Cpad, scale);
+  return nk_check_launch("nchw_to_nhwc");
+}
+extern "C" int nk_nhwc_to_nchw(const void* src, void* dst, int dst_is_f32, int N, int C, int HW, int Cpad,
+                               void* stream) {
+  NK_CHECK_ARG(src && dst && N > 0 && C > 0 && HW > 0 && Cpad >= C);
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
+  if (dst_is_f32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       (float*)dst, C, HW, Cpad);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       (bf16_t*)dst, C, HW, Cpad);
+  return nk_check_launch("nhwc_to_nchw");
+}
+
+// ---- casts ----------------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n) {
+  const long n8 = n >> 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const float4_t a = *(const float4_t*)(s + i * 8), b = *(const float4_t*)(s + i * 8 + 4);
+    float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    *(uint4_t*)(d + i * 8) = pack8(f);
+  }
+  if (blockIdx.x == 0) for (long i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) d[i] = f2bf(s[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = bf2f(s[i]);
+}
+extern "C" int nk_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream) {
+  NK_CHECK_ARG(src && dst && n > 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_blocks((n >> 3) + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst, n);
+  return nk_check_launch("cast_f32_to_bf16");
+}
+extern "C" int nk_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream) {
+  NK_CHECK_ARG(src && dst && n > 0);
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, dst, n);
+  return nk_check_launch("cast_bf16_to_f32");
+}
+
+// ---- bias gradient: out[n] (+)= sum_m dy[m][n] ---------------------------------------------------
+__global__ void colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ out, long M, int N, long ld,
+                              int rows_per) {
+  extern __shared__ float ls[];  // [N] slab sums
+  const int cpr = (N >> 3) / gridDim.y;
+  const int ch0 = blockIdx.y * cpr;
+  const int rows_par = EW_THREADS / cpr;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < cpr * 8; c += EW_THREADS) ls[c] = 0.f;
+  __syncthreads();
+  const int chunk = tid % cpr, rsub = tid / cpr;
+  const long row_lo = (long)blockIdx.x * rows_per;
+  const long row_hi = row_lo + rows_per < M ? row_lo + rows_per : M;
+  if (rsub < rows_par) {
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    for (long r = row_lo + rsub; r < row_hi; r += rows_par) {
+      float f[8];
+      unpack8(*(const uint4_t*)(dy + r * ld + (ch0 + chunk) * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&ls[chunk * 8 + e], s[e]);
+  }
+  __syncthreads();
+  for (int c = tid; c < cpr * 8; c += EW_THREADS) unsafeAtomicAdd(&out[ch0 * 8 + c], ls[c]);
+}
+extern "C" int nk_colsum(const void* dy, float* out, long M, int N, long ld, int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(dy && out && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0);
+  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, stream) != hipSuccess) return NK_ERR_LAUNCH;
+  int cpr = N >> 3, nz = (cpr + EW_THREADS - 1) / EW_THREADS;
+  while (cpr % nz) ++nz;
+  int rows_per = (int)((M + 511) / 512);
+  if (rows_per < 16) rows_per = 16;
+  int nsplit = (int)((M + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nsplit, nz), dim3(EW_THREADS), (cpr / nz) * 8 * sizeof(float), stream,
+                     (const bf16_t*)dy, out, M, N, ld, rows_per);
+  return nk_check_launch("colsum");
+}
+
+// ---- sinusoidal timestep embedding (modules/diffusion/util.py:152-177): [cos | sin] -------------
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int B, int dim,
+                                          float max_period) {
+  const int half = dim >> 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * dim; i += gridDim.x * blockDim.x) {
+    int b = i / dim, j = i - b * dim;
+    float v = 0.f;
+    if (j < 2 * half) {
+      int k = j < half ? j : j - half;
+      float freq = expf(-logf(max_period) * (float)k / (float)half);
+      float arg = t[b] * freq;
+      v = j < half ? cosf(arg) : sinf(arg);
+    }
+    out[i] = f2bf(v);
+  }
+}
+extern "C" int nk_timestep_embedding(const float* t, void* out, int B, int dim, float max_period, void* stream) {
+  NK_CHECK_ARG(t && out && B > 0 && dim > 0);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
+                     (bf16_t*)out, B, dim, max_period);
+  return nk_check_launch("timestep_embedding");
+}
+
+// ---- row softmax in place on bf16 [M][L] (unfused d=512 VAE mid attention, model.py:224-243) ----
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ s, long M, int L) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (long row = blockIdx.x; row < M; row += gridDim.x) {
+    bf16_t* p = s + row * L;
+    float mx = -INFINITY;
+    for (int i = tid * 8; i < L; i += 256 * 8) {
+      float f[8];
+      unpack8(*(const uint4_t*)(p + i), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f[e]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = tid * 8; i < L; i += 256 * 8) {
+      float f[8];
+      unpack8(*(const uint4_t*)(p + i), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += __expf(f[e] - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int i = tid * 8; i < L; i += 256 * 8) {
+      float f[8];
+      unpack8(*(const uint4_t*)(p + i), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = __expf(f[e] - mx) * inv;
+      *(uint4_t*)(p + i) = pack8(f);
+    }
+    __syncthreads();
+  }
+}
+extern "C" int nk_softmax_rows(void* s, long M, int L, void* stream) {
+  NK_CHECK_ARG(s && M > 0 && L > 0 && (L & 7) == 0);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((int)(M < 4096 ? M : 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)s, M, L);
+  return nk_check_launch("softmax_rows");
+}
+
+// ---- EDM noising + preconditioning (loss.py:117-140, denoiser.py:41-49) -------------------------
+// z_t = x + sigma*eps (fp32, NCHW) ; net_in = bf16 channels-last (z_t * c_in), channels padded to Cpad
+__global__ void edm_prepare_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                   const float* __restrict__ sigma, const float* __restrict__ c_in,
+                                   float* __restrict__ zt, bf16_t* __restrict__ net_in, int B, int C, int HW, int Cpad) {
+  const long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int b = (int)(i / HW);
+    int p = (int)(i - (long)b * HW);
+    const float sg = sigma[b], ci = c_in[b];
+    for (int c = 0; c < Cpad; ++c) {
+      float v = 0.f;
+      if (c < C) {
+        long o = ((long)b * C + c) * HW + p;
+        float z = x[o] + sg * eps[o];
+        zt[o] = z;
+        v = z * ci;
+      }
+      net_in[i * Cpad + c] = f2bf(v);
+    }
+  }
+}
+extern "C" int nk_edm_prepare(const float* x, const float* eps, const float* sigma, const float* c_in, float* zt,
+                              void* net_in, int B, int C, int HW, int Cpad, void* stream) {
+  NK_CHECK_ARG(x && eps && sigma && c_in && zt && net_in && B > 0 && C > 0 && HW > 0 && Cpad >= C);
+  hipLaunchKernelGGL(edm_prepare_kernel, dim3(ew_blocks((long)B * HW)), dim3(EW_THREADS), 0, (hipStream_t)stream, x,
+                     eps, sigma, c_in, zt, (bf16_t*)net_in, B, C, HW, Cpad);
+  return nk_check_launch("edm_prepare");
+}
+
+// ---- EDM loss forward + its gradient w.r.t. the network output (loss.py:142-157, functions.py:91-94)
+// D = net_out*c_out + z_t*c_skip ; loss[b] = w[b] * mean_chw((D - target)^2)
+// dnet = upstream * w[b] * 2/(C*HW) * (D - target) * c_out       (bf16 channels-last, padded channels = 0)
+__global__ __launch_bounds__(256) void edm_loss_kernel(const bf16_t* __restrict__ net_out, const float* __restrict__ zt,
+                                                       const float* __restrict__ target, const float* __restrict__ c_out,
+                                                       const float* __restrict__ c_skip, const float* __restrict__ w,
+                                                       float* __restrict__ loss, bf16_t* __restrict__ dnet, int B, int C,
+                                                       int HW, int Cpad, float upstream) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const float co = c_out[b], cs = c_skip[b], wb = w[b];
+  const float inv_cnt = 1.0f / ((float)C * (float)HW);
+  const float gscale = upstream * wb * 2.0f * inv_cnt * co;
+  float acc = 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    for (int c = 0; c < Cpad; ++c) {
+      float g = 0.f;
+      if (c < C) {
+        long o = ((long)b * C + c) * HW + p;
+        float D = bf2f(net_out[((long)b * HW + p) * Cpad + c]) * co + zt[o] * cs;
+        float diff = D - target[o];
+        acc += diff * diff;
+        g = diff * gscale;
+      }
+      if (dnet) dnet[((long)b * HW + p) * Cpad + c] = f2bf(g);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(&loss[b], (red[0] + red[1] + red[2] + red[3]) * inv_cnt * wb);
+}
+extern "C" int nk_edm_loss(const void* net_out, const float* zt, const float* target, const float* c_out,
+                           const float* c_skip, const float* w, float* loss, void* dnet, int B, int C, int HW, int Cpad,
+                           float upstream, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(net_out && zt && target && c_out && c_skip && w && loss && B > 0 && C > 0 && HW > 0 && Cpad >= C);
+  if (hipMemsetAsync(loss, 0, sizeof(float) * B, stream) != hipSuccess) return NK_ERR_LAUNCH;
+  int bx = (HW + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(edm_loss_kernel, dim3(bx, B), dim3(256), 0, stream, (const bf16_t*)net_out, zt, target, c_out,
+                     c_skip, w, loss, (bf16_t*)dnet, B, C, HW, Cpad, upstream);
+  return nk_check_launch("edm_loss");
+}
+
+// ---- flat fused AdamW over the whole parameter buffer; also refreshes the bf16 shadow ----------
+__global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr, float b1,
+                                  float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4_t pp = *(float4_t*)(p + i * 4);
+    const float4_t gg = *(const float4_t*)(g + i * 4);
+    float4_t mm = *(float4_t*)(m + i * 4), vv = *(float4_t*)(v + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gr = gg[e] * gscale;
+      mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+      float upd = (mm[e] / bc1) / (sqrtf(vv[e] / bc2) + eps);
+      pp[e] = pp[e] * (1.f - lr * wd) - lr * upd;
+    }
+    *(float4_t*)(p + i * 4) = pp;
+    *(float4_t*)(m + i * 4) = mm;
+    *(float4_t*)(v + i * 4) = vv;
+    uint2_t s;
+    s.x = pack2bf(pp[0], pp[1]);
+    s.y = pack2bf(pp[2], pp[3]);
+    *(uint2_t*)(shadow + i * 4) = s;
+  }
+}
+extern "C" int nk_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  NK_CHECK_ARG(p && g && m && v && shadow && n > 0 && (n & 3) == 0 && step >= 1);
+  float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3(ew_blocks(n >> 2)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, g, m, v,
+                     (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  return nk_check_launch("adamw_flat");
+}

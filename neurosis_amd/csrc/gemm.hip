@@ -1,0 +1,450 @@
+// MFMA tile engine for every contraction on the SDXL training-step path (gfx950 / CDNA4).
+//
+// One templated kernel computes C[M,N] = sum_k A(m,k) * B(n,k) with bf16 operands and fp32
+// accumulation on v_mfma_f32_16x16x32_bf16.  What differs between Linear forward / dgrad / wgrad and
+// implicit-GEMM Conv2d forward / dgrad / wgrad is only HOW an operand element (r, k) is found in HBM,
+// so each operand is described by a "mode":
+//
+//   OP_KC   k-contiguous dense          elem(r,k) = P[r*ld + k]                (Linear x, W; conv W)
+//   OP_KCG  k-contiguous conv gather    r -> pixel (n,ph,pw), k -> (tap,c)      (conv fwd x, conv dgrad dy)
+//   OP_MC   r-contiguous dense          elem(r,k) = P[k*ld + r]                (dgrad W, wgrad dy / x)
+//   OP_MCT  r-contiguous, k=(tap,co)    elem(ci,k) = W[co*cs + tap*C + ci]     (conv dgrad W)
+//   OP_MCG  r-contiguous conv gather    r -> (tap,c), k -> pixel               (conv wgrad x)
+//
+// k-contiguous operands are staged into an XOR-swizzled [rows][64] LDS image and read with
+// ds_read_b128; r-contiguous operands are staged as they lie in memory ([64 k][rows]) and read with
+// gfx950's transposing ds_read_b64_tr_b16, so no operand is ever transposed in HBM.
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4 MFMA tiles),
+// register-staged double-buffered LDS (global loads for tile t+1 are issued before the MFMAs of
+// tile t and written to LDS after them), one barrier per k-step, XCD-aware block->tile mapping,
+// epilogue staged through LDS so HBM stores are 16 B per lane and row-contiguous.
+//
+// Reference call sites this engine serves: K1 conv2d, K3 nn.Linear, and the
+// unfused attention products of the VAE mid block (K10).
+#include "nk_common.h"
+#include "nk_gemm.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define NTHREADS 256
+#define KC_IMAGE_BYTES (128 * 128)          // [128 rows][64 k] bf16
+#define MC_ROW_BYTES (128 * 2 + 16)         // [64 k][128 r] bf16, rows padded by 16 B
+#define MC_IMAGE_BYTES (BK * MC_ROW_BYTES)  // 17408
+#define OPND_BYTES MC_IMAGE_BYTES           // per-operand slot (max of the two images)
+#define STAGE_BYTES (2 * OPND_BYTES)
+#define CS_LD 132                            // fp32 epilogue staging row stride (floats)
+#define SMEM_BYTES (2 * STAGE_BYTES)        // 69632 >= 128*132*4 = 67584
+
+static_assert(SMEM_BYTES >= BM * CS_LD * 4, "epilogue staging must fit");
+
+enum { OP_KC = 0, OP_KCG = 1, OP_MC = 2, OP_MCT = 3, OP_MCG = 4 };
+
+__device__ __forceinline__ bool is_kc(int mode) { return mode == OP_KC || mode == OP_KCG; }
+
+// ---------------------------------------------------------------------------------------------
+// conv gather geometry: maps (pixel, tap) -> source element offset or "padding"
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long gather_offset(const NkGather& g, int n, int bh, int bw, int kh, int kw,
+                                              int c, bool& valid) {
+  int hn = bh + kh * g.ks;
+  int wn = bw + kw * g.ks;
+  bool ok = (hn >= 0) & (wn >= 0);
+  if (g.need_even) ok &= (((hn | wn) & 1) == 0);
+  int h = hn, w = wn;
+  if (g.div == 2) { h >>= 1; w >>= 1; }
+  ok &= (h < g.H) & (w < g.W);
+  valid = valid && ok;
+  return (((long)n * g.H + h) * g.W + w) * g.C + c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Operand loader
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+struct Operand {
+  const bf16_t* P;
+  long ld;
+  int R;            // number of rows of this operand (M for A, N for B)
+  int r0;           // tile origin
+  // per-thread chunk coordinates
+  int fixed;        // KC: kc (0..7)        MC: rc (0..15)
+  int var0;         // KC: first row (tid>>3) MC: first k row (tid>>4)
+  // conv state
+  int pn[4], pbh[4], pbw[4];   // KCG: per-row pixel decode
+  int tkh, tkw, tc;            // MCG: fixed tap / channel of this thread's r-chunk
+  bool rvalid[4];              // KC*: row in range;  MC*: [0] = r-chunk in range
+
+  __device__ __forceinline__ void init(const bf16_t* p, long ld_, int R_, int r0_, int tid,
+                                       const NkGather& g) {
+    P = p; ld = ld_; R = R_; r0 = r0_;
+    if constexpr (MODE == OP_KC || MODE == OP_KCG) {
+      fixed = tid & 7;
+      var0 = tid >> 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = r0 + var0 + 32 * i;
+        rvalid[i] = r < R;
+        if constexpr (MODE == OP_KCG) {
+          unsigned p_ = rvalid[i] ? (unsigned)r : 0u;
+          unsigned n = fdiv(p_, g.fHoWo);
+          unsigned rem = p_ - n * g.fHoWo.d;
+          unsigned ph = fdiv(rem, g.fWo);
+          unsigned pw = rem - ph * g.fWo.d;
+          pn[i] = (int)n;
+          pbh[i] = (int)ph * g.rs + g.off_h;
+          pbw[i] = (int)pw * g.rs + g.off_w;
+        }
+      }
+    } else {
+      fixed = tid & 15;
+      var0 = tid >> 4;
+      int r = r0 + fixed * 8;
+      rvalid[0] = r < R;
+      if constexpr (MODE == OP_MCG) {
+        unsigned rr = rvalid[0] ? (unsigned)r : 0u;
+        unsigned tap = fdiv(rr, g.fC);
+        tc = (int)(rr - tap * g.fC.d);
+        unsigned kh = fdiv(tap, g.fKW);
+        tkh = (int)kh;
+        tkw = (int)(tap - kh * g.fKW.d);
+      }
+    }
+  }
+
+  // issue the 4 x 16-byte global loads of this thread for the k-tile [k0, k0+BK) clipped to kend
+  __device__ __forceinline__ void load(int k0, int kend, uint4_t (&v)[4], const NkGather& g,
+                                       const NkTapW& tw) const {
+    if constexpr (MODE == OP_KC) {
+      int k = k0 + fixed * 8;
+      bool kv = k < kend;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint4_t z = {0u, 0u, 0u, 0u};
+        if (kv && rvalid[i]) {
+          const bf16_t* p = P + (long)(r0 + var0 + 32 * i) * ld + k;
+          z = *(const uint4_t*)p;
+        }
+        v[i] = z;
+      }
+    } else if constexpr (MODE == OP_KCG) {
+      int k = k0 + fixed * 8;
+      bool kv = k < kend;
+      unsigned kk = kv ? (unsigned)k : 0u;
+      unsigned tap = fdiv(kk, g.fC);
+      int c = (int)(kk - tap * g.fC.d);
+      unsigned kh = fdiv(tap, g.fKW);
+      int kw = (int)(tap - kh * g.fKW.d);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint4_t z = {0u, 0u, 0u, 0u};
+        bool ok = kv && rvalid[i];
+        long off = gather_offset(g, pn[i], pbh[i], pbw[i], (int)kh, kw, c, ok);
+        if (ok) z = *(const uint4_t*)(P + off);
+        v[i] = z;
+      }
+    } else if constexpr (MODE == OP_MC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + var0 + 16 * i;
+        uint4_t z = {0u, 0u, 0u, 0u};
+        if (k < kend && rvalid[0]) z = *(const uint4_t*)(P + (long)k * ld + r0 + fixed * 8);
+        v[i] = z;
+      }
+    } else if constexpr (MODE == OP_MCT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + var0 + 16 * i;
+        uint4_t z = {0u, 0u, 0u, 0u};
+        if (k < kend && rvalid[0]) {
+          unsigned tap = fdiv((unsigned)k, tw.fCout);
+          unsigned co = (unsigned)k - tap * tw.fCout.d;
+          z = *(const uint4_t*)(P + (long)co * tw.co_stride + (long)tap * tw.tap_stride + r0 + fixed * 8);
+        }
+        v[i] = z;
+      }
+    } else {  // OP_MCG
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + var0 + 16 * i;
+        uint4_t z = {0u, 0u, 0u, 0u};
+        bool ok = (k < kend) && rvalid[0];
+        unsigned p_ = ok ? (unsigned)k : 0u;
+        unsigned n = fdiv(p_, g.fHoWo);
+        unsigned rem = p_ - n * g.fHoWo.d;
+        unsigned ph = fdiv(rem, g.fWo);
+        unsigned pw = rem - ph * g.fWo.d;
+        long off = gather_offset(g, (int)n, (int)ph * g.rs + g.off_h, (int)pw * g.rs + g.off_w, tkh, tkw,
+                                 tc, ok);
+        if (ok) z = *(const uint4_t*)(P + off);
+        v[i] = z;
+      }
+    }
+  }
+
+  // write the staged registers into this operand's LDS image
+  __device__ __forceinline__ void store(char* img, const uint4_t (&v)[4]) const {
+    if constexpr (MODE == OP_KC || MODE == OP_KCG) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = var0 + 32 * i;
+        int byte = row * 128 + ((fixed ^ (row & 7)) << 4);
+        *(uint4_t*)(img + byte) = v[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = var0 + 16 * i;
+        *(uint4_t*)(img + k * MC_ROW_BYTES + fixed * 16) = v[i];
+      }
+    }
+  }
+
+  // fragment (16 rows starting at `sub`, k sub-step ks of 32) in the 16x16x32 A/B operand layout:
+  // lane l holds elem(row = sub + (l&15), k = 32*ks + 8*(l>>4) + j), j = 0..7
+  static __device__ __forceinline__ bf16x8_t frag(const char* img, int sub, int ks, int lane) {
+    if constexpr (MODE == OP_KC || MODE == OP_KCG) {
+      int row = sub + (lane & 15);
+      int chunk = ks * 4 + (lane >> 4);
+      int byte = row * 128 + ((chunk ^ (row & 7)) << 4);
+      return *(const bf16x8_t*)(img + byte);
+    } else {
+      int g = lane >> 4, i = lane & 15;
+      int q = i >> 2, p = i & 3;
+      int k = ks * 32 + 8 * g + q;
+      int byte = k * MC_ROW_BYTES + (sub + 4 * p) * 2;
+      typedef __attribute__((address_space(3))) short4_t* lds_p;
+      short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + byte));
+      short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + byte + 4 * MC_ROW_BYTES));
+      short8_t r;
+      r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+      r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+      return __builtin_bit_cast(bf16x8_t, r);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------------
+template <int AMODE, int BMODE, int OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap: blocks that share an XCD (bid % 8) get a contiguous tile range
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int mt = wg / ntn, nt = wg - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int kbeg = blockIdx.y * p.ksplit_len;
+  const int kend = min(p.K, kbeg + p.ksplit_len);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  Operand<AMODE> opa;
+  Operand<BMODE> opb;
+  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+
+  float4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  uint4_t ra[4], rb[4];
+  if (nk > 0) {
+    opa.load(kbeg, kend, ra, p.ga, p.tw);
+    opb.load(kbeg, kend, rb, p.gb, p.tw);
+    opa.store(smem, ra);
+    opb.store(smem + OPND_BYTES, rb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      opa.load(kbeg + (kt + 1) * BK, kend, ra, p.ga, p.tw);
+      opb.load(kbeg + (kt + 1) * BK, kend, rb, p.gb, p.tw);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = Operand<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = Operand<BMODE>::frag(cur + OPND_BYTES, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      opa.store(nxt, ra);
+      opb.store(nxt + OPND_BYTES, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32, [128][CS_LD]) -> coalesced global stores ----
+  float* cs = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        int col = wn * 64 + j * 16 + (lane & 15);
+        cs[row * CS_LD + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  if constexpr (OUT_F32) {
+    float* C = (float*)p.C;
+    for (int it = 0; it < (BM * BN) / NTHREADS; ++it) {
+      int idx = tid + it * NTHREADS;
+      int row = idx >> 7, col = idx & 127;
+      int m = m0 + row, n = n0 + col;
+      if (m < p.M && n < p.N) {
+        float v = cs[row * CS_LD + col] * p.alpha;
+        float* dst = C + (long)m * p.ldc + n;
+        if (p.accumulate) unsafeAtomicAdd(dst, v);
+        else *dst = v;
+      }
+    }
+  } else {
+    bf16_t* C = (bf16_t*)p.C;
+    const bool vec = (p.N & 7) == 0;
+#pragma unroll 2
+    for (int it = 0; it < (BM * BN / 8) / NTHREADS; ++it) {
+      int idx = tid + it * NTHREADS;
+      int row = idx >> 4, cc = idx & 15;
+      int m = m0 + row, n = n0 + cc * 8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      const float4_t c0 = *(const float4_t*)(cs + row * CS_LD + cc * 8);
+      const float4_t c1 = *(const float4_t*)(cs + row * CS_LD + cc * 8 + 4);
+      v[0] = c0[0]; v[1] = c0[1]; v[2] = c0[2]; v[3] = c0[3];
+      v[4] = c1[0]; v[5] = c1[1]; v[6] = c1[2]; v[7] = c1[3];
+      if (p.alpha != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+      }
+      if (vec) {
+        if (p.bias) {
+          const float4_t b0 = *(const float4_t*)(p.bias + n);
+          const float4_t b1 = *(const float4_t*)(p.bias + n + 4);
+          v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
+          v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
+        }
+        if (p.rowvec) {
+          unsigned b = fdiv((unsigned)m, p.fRowsPerBatch);
+          float t[8];
+          unpack8(*(const uint4_t*)(p.rowvec + (long)b * p.ld_rowvec + n), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if (p.residual) {
+          float t[8];
+          unpack8(*(const uint4_t*)(p.residual + (long)m * p.ldr + n), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        *(uint4_t*)(C + (long)m * p.ldc + n) = pack8(v);
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          float x = v[e];
+          if (p.bias) x += p.bias[n + e];
+          if (p.rowvec) x += bf2f(p.rowvec[(long)fdiv((unsigned)m, p.fRowsPerBatch) * p.ld_rowvec + n + e]);
+          if (p.residual) x += bf2f(p.residual[(long)m * p.ldr + n + e]);
+          C[(long)m * p.ldc + n + e] = f2bf(x);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+template <int AMODE, int BMODE, int OUT_F32>
+static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = nk_gemm_kernel<AMODE, BMODE, OUT_F32>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_set = true;
+  }
+  int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, splitk, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SMEM_BYTES, stream, p);
+  return nk_check_launch("nk_gemm_kernel");
+}
+
+static int pick_splitk(int M, int N, int K, int max_split) {
+  int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int nk = (K + BK - 1) / BK;
+  int s = 1;
+  // fill ~2 workgroups per CU (512 slots) but keep >= 8 k-steps per split
+  while (s < max_split && tiles * s < 512 && nk / (s * 2) >= 8) s *= 2;
+  return s;
+}
+
+static void set_split(NkGemmParams& p, int splitk) {
+  int nk = (p.K + BK - 1) / BK;
+  int per = (nk + splitk - 1) / splitk;
+  p.ksplit_len = per * BK;
+}
+
+int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int allow_splitk,
+                     hipStream_t stream) {
+  NK_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0);
+  NK_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && ((uintptr_t)p.C & 15) == 0);
+  // 16-byte chunk rules: k-contiguous operands need K % 8 == 0 and ld % 8 == 0; r-contiguous ones R % 8 == 0
+  if (amode == OP_KC) NK_CHECK_ARG((p.K & 7) == 0 && (p.lda & 7) == 0);
+  if (bmode == OP_KC) NK_CHECK_ARG((p.K & 7) == 0 && (p.ldb & 7) == 0);
+  if (amode == OP_KCG) NK_CHECK_ARG((p.ga.C & 7) == 0);
+  if (amode == OP_MC) NK_CHECK_ARG((p.M & 7) == 0 && (p.lda & 7) == 0);
+  if (bmode == OP_MC) NK_CHECK_ARG((p.N & 7) == 0 && (p.ldb & 7) == 0);
+  if (bmode == OP_MCT) NK_CHECK_ARG((p.N & 7) == 0 && (p.tw.co_stride & 7) == 0 && (p.tw.tap_stride & 7) == 0);
+  if (bmode == OP_MCG) NK_CHECK_ARG((p.gb.C & 7) == 0);
+  if (p.residual) NK_CHECK_ARG(((uintptr_t)p.residual & 15) == 0 && ((p.ldr & 7) == 0 || (p.N & 7) != 0));
+  if (!out_f32) NK_CHECK_ARG((p.ldc & 7) == 0 || (p.N & 7) != 0);
+  if (p.fRowsPerBatch.d == 0) p.fRowsPerBatch = make_fastdiv(1);
+
+  int splitk = 1;
+  if (out_f32 && allow_splitk) splitk = pick_splitk(p.M, p.N, p.K, 32);
+  set_split(p, splitk);
+  if (out_f32 && splitk > 1 && !p.accumulate) {
+    // split-K partials are summed with fp32 atomics, which need a zeroed destination
+    NK_CHECK_ARG(p.ldc == p.N);
+    if (hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess) return NK_ERR_LAUNCH;
+    p.accumulate = 1;
+  }
+
+#define NK_CASE(A_, B_)                                                          \
+  if (amode == A_ && bmode == B_) {                                              \
+    return out_f32 ? launch<A_, B_, 1>(p, splitk, stream) : launch<A_, B_, 0>(p, splitk, stream); \
+  }
+  NK_CASE(OP_KC, OP_KC)
+  NK_CASE(OP_KC, OP_MC)
+  NK_CASE(OP_MC, OP_MC)
+  NK_CASE(OP_KCG, OP_KC)
+  NK_CASE(OP_KCG, OP_MCT)
+  NK_CASE(OP_MC, OP_MCG)
+#undef NK_CASE
+  nk_set_error(__FILE__, __LINE__, "unsupported operand mode combination");
+  return NK_ERR_ARG;
+}

@@ -1,0 +1,91 @@
+// Common device helpers for the neurosis_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+typedef __attribute__((ext_vector_type(16))) float float16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int uint4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int uint2_t;
+
+#define NK_OK 0
+#define NK_ERR_ARG 1
+#define NK_ERR_LAUNCH 2
+
+#define NK_CHECK_ARG(cond)                                                        \
+  do {                                                                            \
+    if (!(cond)) {                                                                \
+      nk_set_error(__FILE__, __LINE__, #cond);                                    \
+      return NK_ERR_ARG;                                                          \
+    }                                                                             \
+  } while (0)
+
+void nk_set_error(const char* file, int line, const char* what);
+int nk_check_launch(const char* what);
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4_t& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4_t pack8(const float* f) {
+  uint4_t v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+__device__ __forceinline__ void unpack4(const uint2_t& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+// 64-lane wavefront reductions (xor butterfly; every lane ends with the total).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Division by a runtime-constant divisor without the ~20-instruction udiv sequence.
+// Valid for n < 2^31.
+struct FastDiv {
+  unsigned d, m, s;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.m = 0; f.s = 0; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s = l;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  return (__umulhi(n, f.m) + n) >> f.s;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}

@@ -1,0 +1,47 @@
+// Internal parameter block of the MFMA tile engine (gemm.hip).  Not part of the C-ABI.
+#pragma once
+#include "nk_common.h"
+
+// Geometry of an implicit-GEMM gather over an NHWC tensor [NB][H][W][C].
+// A "pixel" index decomposes over the grid [NB][Ho][Wo]; a "tap" over [KH][KW].
+//   hnum = ph*rs + kh*ks + off_h ;  h = hnum / div ; valid iff 0 <= hnum, (need_even -> hnum even), h < H
+struct NkGather {
+  int H, W, C;
+  int Ho, Wo;
+  int KW;
+  int rs, ks;
+  int off_h, off_w;
+  int div;
+  int need_even;
+  FastDiv fWo, fHoWo, fC, fKW;
+};
+
+// conv-dgrad weight operand: k = tap*Cout + co  ->  W[co*co_stride + tap*tap_stride + ci]
+struct NkTapW {
+  long co_stride, tap_stride;
+  FastDiv fCout;
+};
+
+struct NkGemmParams {
+  const bf16_t* A;
+  const bf16_t* B;
+  long lda, ldb;
+  int M, N, K;
+  NkGather ga, gb;
+  NkTapW tw;
+  void* C;
+  long ldc;
+  float alpha;
+  const float* bias;        // [N] fp32, optional
+  const bf16_t* residual;   // [M][ldr] bf16, optional
+  long ldr;
+  const bf16_t* rowvec;     // [batch][ld_rowvec] bf16 broadcast over the rows of one batch item, optional
+  long ld_rowvec;
+  FastDiv fRowsPerBatch;
+  int ksplit_len;
+  int accumulate;           // fp32 output: 0 = store, 1 = atomic add
+};
+
+enum { NK_OP_KC = 0, NK_OP_KCG = 1, NK_OP_MC = 2, NK_OP_MCT = 3, NK_OP_MCG = 4 };
+
+int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int allow_splitk, hipStream_t stream);

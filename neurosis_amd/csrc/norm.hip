@@ -1,0 +1,438 @@
+// HBM-bound normalisation kernels on channels-last bf16 data: GroupNorm(+SiLU) and LayerNorm,
+// forward and backward.  Statistics are fp32; reductions are staged per thread -> LDS -> one fp32
+// atomic per (block, statistic); loads and stores are 16 B per lane and row-contiguous.
+//
+// Reference: nn.GroupNorm(32, C)+nn.SiLU (modules/diffusion/openaimodel.py:247-250,281-283,797-799),
+// SpatialTransformer.norm (modules/attention.py:612, eps 1e-6), Normalize (modules/layers.py:5-7),
+// nn.LayerNorm (modules/attention.py:468-470).
+#include "../../include/neurosis_hip.h"
+#include "nk_common.h"
+
+#define GN_THREADS 256
+#define GN_MAXC 4096
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm forward, pass 1: per-(n, group) sum and sum of squares
+// grid (nsplit, N); block handles rows [split*rows_per, ...) of image n
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats,
+                                                              int HW, int C, int G, int rows_per) {
+  __shared__ float gs[64 * 2];
+  const int n = blockIdx.y;
+  const int cpr = (C >> 3) / gridDim.z;        // 16-byte chunks per row in this block's channel slab
+  const int ch0 = blockIdx.z * cpr;            // first chunk of the slab
+  const int rows_par = GN_THREADS / cpr;       // rows processed in parallel by the block
+  const int tid = threadIdx.x;
+  const int cpg = C / G;
+  for (int i = tid; i < 2 * G; i += GN_THREADS) gs[i] = 0.f;
+  __syncthreads();
+  const int row_lo = blockIdx.x * rows_per;
+  const int row_hi = min(HW, row_lo + rows_per);
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  const int chunk = ch0 + tid % cpr, rsub = tid / cpr;
+  if (rsub < rows_par) {
+    const bf16_t* base = x + ((long)n * HW) * C + chunk * 8;
+    for (int r = row_lo + rsub; r < row_hi; r += rows_par) {
+      float f[8];
+      unpack8(*(const uint4_t*)(base + (long)r * C), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int g = (chunk * 8 + e) / cpg;
+      atomicAdd(&gs[2 * g], s[e]);
+      atomicAdd(&gs[2 * g + 1], ss[e]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * G; i += GN_THREADS) unsafeAtomicAdd(&stats[(long)n * 2 * G + i], gs[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm forward, pass 2: y = silu?((x - mean) * rstd * gamma + beta); also emits mean / rstd
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                              float* __restrict__ rstd_out, int HW, int C, int G,
+                                                              float eps, int silu, int rows_per) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sc = (float*)smem_raw;   // [C]
+  float* sh = sc + C;             // [C]
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int cpg = C / G;
+  const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+  for (int c = tid; c < C; c += GN_THREADS) {
+    int g = c / cpg;
+    float m = stats[(long)n * 2 * G + 2 * g] * inv_cnt;
+    float var = fmaxf(stats[(long)n * 2 * G + 2 * g + 1] * inv_cnt - m * m, 0.f);
+    float rs = rsqrtf(var + eps);
+    float a = rs * gamma[c];
+    sc[c] = a;
+    sh[c] = beta[c] - m * a;
+    if (blockIdx.x == 0 && (c % cpg) == 0) { mean_out[n * G + g] = m; rstd_out[n * G + g] = rs; }
+  }
+  __syncthreads();
+  const int cpr = C >> 3;
+  const int row_lo = blockIdx.x * rows_per;
+  const int row_hi = min(HW, row_lo + rows_per);
+  const long total = (long)(row_hi - row_lo) * cpr;
+  const bf16_t* xb = x + ((long)n * HW + row_lo) * C;
+  bf16_t* yb = y + ((long)n * HW + row_lo) * C;
+  for (long i = tid; i < total; i += GN_THREADS) {
+    int chunk = (int)(i % cpr);
+    float f[8];
+    unpack8(*(const uint4_t*)(xb + i * 8), f);
+    const float4_t a0 = *(const float4_t*)(sc + chunk * 8), a1 = *(const float4_t*)(sc + chunk * 8 + 4);
+    const float4_t b0 = *(const float4_t*)(sh + chunk * 8), b1 = *(const float4_t*)(sh + chunk * 8 + 4);
+    f[0] = f[0] * a0[0] + b0[0]; f[1] = f[1] * a0[1] + b0[1]; f[2] = f[2] * a0[2] + b0[2]; f[3] = f[3] * a0[3] + b0[3];
+    f[4] = f[4] * a1[0] + b1[0]; f[5] = f[5] * a1[1] + b1[1]; f[6] = f[6] * a1[2] + b1[2]; f[7] = f[7] * a1[3] + b1[3];
+    if (silu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+    }
+    *(uint4_t*)(yb + i * 8) = pack8(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm backward, pass 1.
+//   dz = dy * silu'(z) (z = xhat*gamma+beta) or dy
+//   per channel: a_c = sum dz, b_c = sum dz*xhat           -> dbeta += a, dgamma += b
+//   per (n,g):   s1 = sum_c gamma_c a_c, s2 = sum_c gamma_c b_c -> gsum[n][g][2]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_stats_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  float* __restrict__ gsum, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int HW, int C, int G, int silu,
+                                                                  int rows_per) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* ca = (float*)smem_raw;   // [C]
+  float* cb = ca + C;             // [C]
+  float* gs = cb + C;             // [2G]
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int cpg = C / G;
+  const int cpr = (C >> 3) / gridDim.z;
+  const int ch0 = blockIdx.z * cpr;
+  const int rows_par = GN_THREADS / cpr;
+  for (int c = tid; c < C; c += GN_THREADS) { ca[c] = 0.f; cb[c] = 0.f; }
+  for (int i = tid; i < 2 * G; i += GN_THREADS) gs[i] = 0.f;
+  __syncthreads();
+  const int row_lo = blockIdx.x * rows_per;
+  const int row_hi = min(HW, row_lo + rows_per);
+  const int chunk = ch0 + tid % cpr, rsub = tid / cpr;
+  if (rsub < rows_par) {
+    float a[8], b[8], mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = chunk * 8 + e;
+      int g = c / cpg;
+      a[e] = 0.f; b[e] = 0.f;
+      mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
+      ga[e] = gamma[c]; be[e] = beta[c];
+    }
+    const long base = ((long)n * HW) * C + chunk * 8;
+    for (int r = row_lo + rsub; r < row_hi; r += rows_par) {
+      float fx[8], fd[8];
+      unpack8(*(const uint4_t*)(x + base + (long)r * C), fx);
+      unpack8(*(const uint4_t*)(dy + base + (long)r * C), fd);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xh = (fx[e] - mu[e]) * rs[e];
+        float dz = fd[e];
+        if (silu) dz *= dsilu_f(xh * ga[e] + be[e]);
+        a[e] += dz;
+        b[e] += dz * xh;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&ca[chunk * 8 + e], a[e]);
+      atomicAdd(&cb[chunk * 8 + e], b[e]);
+    }
+  }
+  __syncthreads();
+  for (int c = ch0 * 8 + tid; c < (ch0 + cpr) * 8; c += GN_THREADS) {
+    int g = c / cpg;
+    float av = ca[c], bv = cb[c], gm = gamma[c];
+    atomicAdd(&gs[2 * g], gm * av);
+    atomicAdd(&gs[2 * g + 1], gm * bv);
+    unsafeAtomicAdd(&dbeta[c], av);
+    unsafeAtomicAdd(&dgamma[c], bv);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * G; i += GN_THREADS) unsafeAtomicAdd(&gsum[(long)n * 2 * G + i], gs[i]);
+}
+
+// GroupNorm backward, pass 2: dx = rstd * (dz*gamma - (s1 + xhat*s2)/cnt) (+ dx_add)
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gsum, const bf16_t* __restrict__ dx_add,
+                                                                  bf16_t* __restrict__ dx, int HW, int C, int G, int silu,
+                                                                  int rows_per) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* p_mu = (float*)smem_raw;  // per channel: mean, rstd, gamma, beta, s1/cnt, s2/cnt
+  float* p_rs = p_mu + C;
+  float* p_ga = p_rs + C;
+  float* p_be = p_ga + C;
+  float* p_s1 = p_be + C;
+  float* p_s2 = p_s1 + C;
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int cpg = C / G;
+  const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+  for (int c = tid; c < C; c += GN_THREADS) {
+    int g = c / cpg;
+    p_mu[c] = mean[n * G + g];
+    p_rs[c] = rstd[n * G + g];
+    p_ga[c] = gamma[c];
+    p_be[c] = beta[c];
+    p_s1[c] = gsum[(long)n * 2 * G + 2 * g] * inv_cnt;
+    p_s2[c] = gsum[(long)n * 2 * G + 2 * g + 1] * inv_cnt;
+  }
+  __syncthreads();
+  const int cpr = C >> 3;
+  const int row_lo = blockIdx.x * rows_per;
+  const int row_hi = min(HW, row_lo + rows_per);
+  const long total = (long)(row_hi - row_lo) * cpr;
+  const long off0 = ((long)n * HW + row_lo) * C;
+  for (long i = tid; i < total; i += GN_THREADS) {
+    int c0 = (int)(i % cpr) * 8;
+    float fx[8], fd[8], fa[8];
+    unpack8(*(const uint4_t*)(x + off0 + i * 8), fx);
+    unpack8(*(const uint4_t*)(dy + off0 + i * 8), fd);
+    if (dx_add) unpack8(*(const uint4_t*)(dx_add + off0 + i * 8), fa);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = c0 + e;
+      float xh = (fx[e] - p_mu[c]) * p_rs[c];
+      float dz = fd[e];
+      if (silu) dz *= dsilu_f(xh * p_ga[c] + p_be[c]);
+      float v = p_rs[c] * (dz * p_ga[c] - (p_s1[c] + xh * p_s2[c]));
+      if (dx_add) v += fa[e];
+      fx[e] = v;
+    }
+    *(uint4_t*)(dx + off0 + i * 8) = pack8(fx);
+  }
+}
+
+// channel slabs so that one thread owns one 16-byte chunk column: (C/8)/nz <= 256
+static int gn_nz(int C) {
+  int cpr = C >> 3, nz = (cpr + GN_THREADS - 1) / GN_THREADS;
+  while (cpr % nz) ++nz;
+  return nz;
+}
+
+static int gn_rows_per(int N, int HW, int* nsplit) {
+  // aim for ~2048 blocks in total
+  int want = (2048 + N - 1) / N;
+  int rows_per = (HW + want - 1) / want;
+  if (rows_per < 8) rows_per = 8;
+  *nsplit = (HW + rows_per - 1) / rows_per;
+  return rows_per;
+}
+
+extern "C" int nk_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                float* rstd, float* stats_ws, int N, int HW, int C, int G, float eps, int silu,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(N > 0 && HW > 0 && C > 0 && G > 0 && G <= 64);
+  NK_CHECK_ARG((C & 7) == 0 && C % G == 0 && C <= GN_MAXC);
+  NK_CHECK_ARG(x && gamma && beta && y && mean && rstd && stats_ws);
+  int nsplit;
+  int rows_per = gn_rows_per(N, HW, &nsplit);
+  if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * G * N, stream) != hipSuccess) return NK_ERR_LAUNCH;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, N, gn_nz(C)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, stats_ws, HW, C,
+                     G, rows_per);
+  if (int e = nk_check_launch("gn_stats_kernel")) return e;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, N), dim3(GN_THREADS), 2 * C * sizeof(float), stream,
+                     (const bf16_t*)x, stats_ws, gamma, beta, (bf16_t*)y, mean, rstd, HW, C, G, eps, silu, rows_per);
+  return nk_check_launch("gn_apply_kernel");
+}
+
+extern "C" int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, const void* dx_add, void* dx, float* dgamma,
+                                float* dbeta, float* gsum_ws, int N, int HW, int C, int G, int silu, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(N > 0 && HW > 0 && C > 0 && G > 0 && G <= 64);
+  NK_CHECK_ARG((C & 7) == 0 && C % G == 0 && C <= GN_MAXC);
+  NK_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && gsum_ws);
+  int nsplit;
+  int rows_per = gn_rows_per(N, HW, &nsplit);
+  if (hipMemsetAsync(gsum_ws, 0, sizeof(float) * 2 * G * N, stream) != hipSuccess) return NK_ERR_LAUNCH;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nsplit, N, gn_nz(C)), dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, gsum_ws, dgamma, dbeta, HW, C, G,
+                     silu, rows_per);
+  if (int e = nk_check_launch("gn_bwd_stats_kernel")) return e;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nsplit, N), dim3(GN_THREADS), 6 * C * sizeof(float), stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, gsum_ws, (const bf16_t*)dx_add,
+                     (bf16_t*)dx, HW, C, G, silu, rows_per);
+  return nk_check_launch("gn_bwd_apply_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim of [M][C]; one wavefront per row, rows strided over the grid.
+// ------------------------------------------------------------------------------------------------
+#define LN_MAXCH 4   // 16-byte chunks per lane: C <= 64*8*4 = 2048
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
+                                                     float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int cpr = C >> 3;
+  const float invC = 1.0f / (float)C;
+  for (int row = wave; row < M; row += nwaves) {
+    float f[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+      int ch = lane + 64 * j;
+      if (ch < cpr) {
+        unpack8(*(const uint4_t*)(x + (long)row * C + ch * 8), f[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[j][e];
+      }
+    }
+    const float mu = wave_sum(s) * invC;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+      int ch = lane + 64 * j;
+      if (ch < cpr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = f[j][e] - mu; v += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(v) * invC + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+      int ch = lane + 64 * j;
+      if (ch < cpr) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f[j][e] - mu) * rs * gamma[ch * 8 + e] + beta[ch * 8 + e];
+        *(uint4_t*)(y + (long)row * C + ch * 8) = pack8(o);
+      }
+    }
+  }
+}
+
+// dx = rstd * (dy*gamma - mean_c(dy*gamma) - xhat * mean_c(dy*gamma*xhat)) (+ dx_add);
+// dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy   (per-lane register partials -> LDS -> atomics)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
+                                                     bf16_t* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int C) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* lg = (float*)smem_raw;   // [C]
+  float* lb = lg + C;             // [C]
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int cpr = C >> 3;
+  const float invC = 1.0f / (float)C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { lg[c] = 0.f; lb[c] = 0.f; }
+  __syncthreads();
+  float ag[LN_MAXCH][8], ab[LN_MAXCH][8], gm[LN_MAXCH][8];
+#pragma unroll
+  for (int j = 0; j < LN_MAXCH; ++j) {
+    int ch = lane + 64 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ag[j][e] = 0.f; ab[j][e] = 0.f;
+      gm[j][e] = ch < cpr ? gamma[ch * 8 + e] : 0.f;
+    }
+  }
+  for (int row = wave; row < M; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAXCH][8], dg[LN_MAXCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+      int ch = lane + 64 * j;
+      if (ch < cpr) {
+        float fx[8], fd[8];
+        unpack8(*(const uint4_t*)(x + (long)row * C + ch * 8), fx);
+        unpack8(*(const uint4_t*)(dy + (long)row * C + ch * 8), fd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float h = (fx[e] - mu) * rs;
+          xh[j][e] = h;
+          ab[j][e] += fd[e];
+          ag[j][e] += fd[e] * h;
+          float d = fd[e] * gm[j][e];
+          dg[j][e] = d;
+          s1 += d;
+          s2 += d * h;
+        }
+      }
+    }
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+      int ch = lane + 64 * j;
+      if (ch < cpr) {
+        float o[8];
+        if (dx_add) unpack8(*(const uint4_t*)(dx_add + (long)row * C + ch * 8), o);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += rs * (dg[j][e] - s1 - xh[j][e] * s2);
+        *(uint4_t*)(dx + (long)row * C + ch * 8) = pack8(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXCH; ++j) {
+    int ch = lane + 64 * j;
+    if (ch < cpr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&lg[ch * 8 + e], ag[j][e]);
+        atomicAdd(&lb[ch * 8 + e], ab[j][e]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    unsafeAtomicAdd(&dgamma[c], lg[c]);
+    unsafeAtomicAdd(&dbeta[c], lb[c]);
+  }
+}
+
+extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                float* rstd, int M, int C, float eps, void* stream) {
+  NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
+  NK_CHECK_ARG(x && gamma && beta && y && mean && rstd);
+  int blocks = min((M + 3) / 4, 2048);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
+                     (bf16_t*)y, mean, rstd, M, C, eps);
+  return nk_check_launch("ln_fwd_kernel");
+}
+
+extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, int M,
+                                int C, void* stream) {
+  NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
+  NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta);
+  int blocks = min((M + 3) / 4, 1024);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma,
+                     dbeta, M, C);
+  return nk_check_launch("ln_bwd_kernel");
+}

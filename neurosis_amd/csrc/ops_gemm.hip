@@ -1,0 +1,139 @@
+// C-ABI launchers for the contraction family: nn.Linear and nn.Conv2d forward / dgrad / wgrad.
+// Each maps its problem onto the MFMA tile engine (gemm.hip) by choosing operand modes.
+#include "../../include/neurosis_hip.h"
+#include "nk_gemm.h"
+#include <string.h>
+
+static NkGemmParams zero_params() {
+  NkGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.alpha = 1.0f;
+  p.fRowsPerBatch = make_fastdiv(1);
+  p.ga.fWo = p.ga.fHoWo = p.ga.fC = p.ga.fKW = make_fastdiv(1);
+  p.gb.fWo = p.gb.fHoWo = p.gb.fC = p.gb.fKW = make_fastdiv(1);
+  p.tw.fCout = make_fastdiv(1);
+  return p;
+}
+
+extern "C" int nk_linear_fwd(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                             int M, int N, int K, long ldx, long ldw, long ldr, long ldy, float alpha,
+                             void* stream) {
+  NkGemmParams p = zero_params();
+  p.A = (const bf16_t*)x; p.lda = ldx;
+  p.B = (const bf16_t*)w; p.ldb = ldw;
+  p.M = M; p.N = N; p.K = K;
+  p.C = y; p.ldc = ldy;
+  p.bias = bias;
+  p.residual = (const bf16_t*)residual; p.ldr = ldr;
+  p.alpha = alpha;
+  return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_KC, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add, void* dx, int M, int N, int K,
+                               long lddy, long ldw, long ldadd, long lddx, void* stream) {
+  // dx[M,K] = dy[M,N] @ w[N,K]  : reduction over N; w is r-contiguous (r = K index)
+  NkGemmParams p = zero_params();
+  p.A = (const bf16_t*)dy; p.lda = lddy;
+  p.B = (const bf16_t*)w; p.ldb = ldw;
+  p.M = M; p.N = K; p.K = N;
+  p.C = dx; p.ldc = lddx;
+  p.residual = (const bf16_t*)dx_add; p.ldr = ldadd;
+  return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_MC, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy,
+                               long ldx, long lddw, int accumulate, void* stream) {
+  // dw[N,K] (+)= dy[M,N]^T @ x[M,K] : reduction over M; both operands r-contiguous
+  NkGemmParams p = zero_params();
+  p.A = (const bf16_t*)dy; p.lda = lddy;
+  p.B = (const bf16_t*)x; p.ldb = ldx;
+  p.M = N; p.N = K; p.K = M;
+  p.C = dw; p.ldc = lddw;
+  p.accumulate = accumulate;
+  return nk_gemm_dispatch(p, NK_OP_MC, NK_OP_MC, 1, lddw == K, (hipStream_t)stream);
+}
+
+static int check_conv(const NkConvDesc* d) {
+  NK_CHECK_ARG(d != nullptr);
+  NK_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0);
+  NK_CHECK_ARG(d->KH > 0 && d->KW > 0 && (d->stride == 1 || d->stride == 2));
+  NK_CHECK_ARG((d->Cin & 7) == 0 && (d->Cout & 7) == 0);
+  NK_CHECK_ARG(!(d->upsample && d->stride != 1));
+  const int Hin = d->upsample ? 2 * d->H : d->H, Win = d->upsample ? 2 * d->W : d->W;
+  NK_CHECK_ARG(d->Ho > 0 && d->Wo > 0);
+  // the last output pixel's first tap must start inside the (left/top padded) input
+  NK_CHECK_ARG((d->Ho - 1) * d->stride - d->pad_t < Hin && (d->Wo - 1) * d->stride - d->pad_l < Win);
+  NK_CHECK_ARG((long)d->N * Hin * Win * (long)d->Cin < (1l << 31) && (long)d->N * d->Ho * d->Wo * (long)d->Cout < (1l << 31));
+  return NK_OK;
+}
+
+// gather of the conv INPUT x[N,H,W,Cin] indexed by output pixels (forward and wgrad)
+static NkGather fwd_gather(const NkConvDesc* d) {
+  NkGather g;
+  memset(&g, 0, sizeof(g));
+  g.H = d->H; g.W = d->W; g.C = d->Cin;
+  g.Ho = d->Ho; g.Wo = d->Wo; g.KW = d->KW;
+  g.rs = d->stride; g.ks = 1;
+  g.off_h = -d->pad_t; g.off_w = -d->pad_l;
+  g.div = d->upsample ? 2 : 1;
+  g.need_even = 0;
+  // upsample: hnum runs over the virtual 2x grid; hnum>>1 < H is the same bound as hnum < 2H
+  g.fWo = make_fastdiv(d->Wo); g.fHoWo = make_fastdiv(d->Ho * d->Wo);
+  g.fC = make_fastdiv(d->Cin); g.fKW = make_fastdiv(d->KW);
+  return g;
+}
+
+extern "C" int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, const float* bias,
+                             const void* rowvec, const void* residual, void* y, void* stream) {
+  if (int e = check_conv(d)) return e;
+  NkGemmParams p = zero_params();
+  p.A = (const bf16_t*)x;
+  p.ga = fwd_gather(d);
+  p.B = (const bf16_t*)w; p.ldb = (long)d->KH * d->KW * d->Cin;
+  p.M = d->N * d->Ho * d->Wo; p.N = d->Cout; p.K = d->KH * d->KW * d->Cin;
+  p.C = y; p.ldc = d->Cout;
+  p.bias = bias;
+  p.rowvec = (const bf16_t*)rowvec; p.ld_rowvec = d->Cout;
+  p.fRowsPerBatch = make_fastdiv(d->Ho * d->Wo);
+  p.residual = (const bf16_t*)residual; p.ldr = d->Cout;
+  return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_KC, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int nk_conv2d_dgrad(const NkConvDesc* d, const void* dy, const void* w, void* dx, void* stream) {
+  // dx[n,hi,wi,ci] = sum_{kh,kw,co} dy[n,(hi+pad-kh)/s,(wi+pad-kw)/s,co] * w[co,kh,kw,ci]
+  // rows = pixels of the conv input grid (the virtual 2x grid when upsample=1; reduce with
+  // nk_upsample2x_bwd afterwards), k = (tap, co)
+  if (int e = check_conv(d)) return e;
+  const int Hin = d->upsample ? 2 * d->H : d->H, Win = d->upsample ? 2 * d->W : d->W;
+  NkGemmParams p = zero_params();
+  NkGather g;
+  memset(&g, 0, sizeof(g));
+  g.H = d->Ho; g.W = d->Wo; g.C = d->Cout;
+  g.Ho = Hin; g.Wo = Win; g.KW = d->KW;
+  g.rs = 1; g.ks = -1;
+  g.off_h = d->pad_t; g.off_w = d->pad_l;
+  g.div = d->stride; g.need_even = d->stride == 2;
+  g.fWo = make_fastdiv(Win); g.fHoWo = make_fastdiv(Hin * Win);
+  g.fC = make_fastdiv(d->Cout); g.fKW = make_fastdiv(d->KW);
+  p.A = (const bf16_t*)dy; p.ga = g;
+  p.B = (const bf16_t*)w;
+  p.tw.co_stride = (long)d->KH * d->KW * d->Cin;
+  p.tw.tap_stride = d->Cin;
+  p.tw.fCout = make_fastdiv(d->Cout);
+  p.M = d->N * Hin * Win; p.N = d->Cin; p.K = d->KH * d->KW * d->Cout;
+  p.C = dx; p.ldc = d->Cin;
+  return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_MCT, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, int accumulate,
+                               void* stream) {
+  // dw[co, (tap,ci)] (+)= sum_pix dy[pix, co] * x[gather(pix, tap), ci]
+  if (int e = check_conv(d)) return e;
+  NkGemmParams p = zero_params();
+  p.A = (const bf16_t*)dy; p.lda = d->Cout;
+  p.B = (const bf16_t*)x; p.gb = fwd_gather(d);
+  p.M = d->Cout; p.N = d->KH * d->KW * d->Cin; p.K = d->N * d->Ho * d->Wo;
+  p.C = dw; p.ldc = p.N;
+  p.accumulate = accumulate;
+  return nk_gemm_dispatch(p, NK_OP_MC, NK_OP_MCG, 1, 1, (hipStream_t)stream);
+}

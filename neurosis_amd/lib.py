@@ -1,0 +1,101 @@
+"""ctypes binding of libneurosis_hip.so (the C-ABI declared in include/neurosis_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback behind these calls.  If the
+shared object is missing or a kernel launch fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "libneurosis_hip.so"
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class NkConvDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad_t", "pad_l", "Ho", "Wo", "upsample")]
+
+
+class NkAttnDesc(C.Structure):
+    _fields_ = (
+        [(n, i32) for n in ("B", "H", "Lq", "Lk", "D")]
+        + [(n, i64) for n in ("sq", "sk", "sv", "so", "bq", "bk", "bv", "bo", "sdq", "sdk", "sdv", "sdo", "bdq", "bdk", "bdv", "bdo")]
+        + [("scale", f32)]
+    )
+
+
+cdp, adp = C.POINTER(NkConvDesc), C.POINTER(NkAttnDesc)
+
+# name -> argtypes; every entry point returns int (0 = ok).  Mirrors include/neurosis_hip.h one to one.
+SIGNATURES: dict[str, list] = {
+    "nk_linear_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, f32, vp],
+    "nk_linear_dgrad": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
+    "nk_linear_wgrad": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp],
+    "nk_conv2d_fwd": [cdp, vp, vp, vp, vp, vp, vp, vp],
+    "nk_conv2d_dgrad": [cdp, vp, vp, vp, vp],
+    "nk_conv2d_wgrad": [cdp, vp, vp, vp, i32, vp],
+    "nk_attention_fwd": [adp, vp, vp, vp, vp, vp, vp],
+    "nk_attention_bwd": [adp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "nk_softmax_rows": [vp, i64, i32, vp],
+    "nk_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "nk_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "nk_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "nk_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "nk_geglu_fwd": [vp, vp, i64, i32, vp],
+    "nk_geglu_bwd": [vp, vp, vp, i64, i32, vp],
+    "nk_silu_fwd": [vp, vp, i64, vp],
+    "nk_silu_bwd": [vp, vp, vp, i64, vp],
+    "nk_add": [vp, vp, vp, i64, vp],
+    "nk_cat_channels": [vp, vp, vp, i64, i32, i32, vp],
+    "nk_split_channels": [vp, vp, vp, i64, i32, i32, vp],
+    "nk_upsample2x_bwd": [vp, vp, i32, i32, i32, i32, vp],
+    "nk_nchw_to_nhwc": [vp, i32, vp, i32, i32, i32, i32, f32, vp],
+    "nk_nhwc_to_nchw": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "nk_cast_f32_to_bf16": [vp, vp, i64, vp],
+    "nk_cast_bf16_to_f32": [vp, vp, i64, vp],
+    "nk_colsum": [vp, vp, i64, i32, i64, i32, vp],
+    "nk_timestep_embedding": [vp, vp, i32, i32, f32, vp],
+    "nk_edm_prepare": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "nk_edm_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "nk_adamw_flat": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
+}
+
+_lib = None
+
+
+class NkError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("NEUROSIS_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise NkError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C neurosis_amd/csrc`). There is no CPU fallback for the product path."
+        )
+    lib = C.CDLL(str(path))
+    lib.nk_last_error.restype = C.c_char_p
+    lib.nk_last_error.argtypes = []
+    lib.nk_abi_version.restype = i32
+    lib.nk_abi_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise NkError(f"{name} failed (rc={rc}): {lib.nk_last_error().decode()}")

@@ -1,0 +1,461 @@
+"""Tensor-level wrappers over the C-ABI (neurosis_amd.lib) and the forward/backward op pairs the modules
+are composed from.
+
+Conventions
+  * activations are bf16 CUDA(=HIP) tensors.  A "token matrix" is a 2-D tensor [M, C] whose last stride is
+    1 (it may be a column slice of a wider buffer).  An image batch is an `Img`: a token matrix of its
+    pixels in channels-last order plus (N, H, W).
+  * every `*_fwd` returns `(out, bwd)`; `bwd(grad_out, ...)` returns the input gradient(s) and writes the
+    parameter gradients IN PLACE into `param.grad` (fp32), through the HIP kernels.  Nothing here calls
+    a PyTorch compute kernel on activation-sized data.
+  * PyTorch provides memory (torch.empty), streams and autograd plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+from torch import Tensor
+
+from . import lib
+from .lib import NkAttnDesc, NkConvDesc, call
+
+BF16 = torch.bfloat16
+
+
+class _State:
+    grad_accumulate = False  # False: weight-grad kernels overwrite; True: they add (micro-batch accumulation)
+    param_epoch = 0  # bumped whenever fp32 masters change (optimizer step / load_state_dict)
+
+
+state = _State()
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check2d(t: Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != BF16 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a 2-D bf16 CUDA tensor with unit inner stride, got {tuple(t.shape)} {t.dtype} {t.stride()} {t.device}")
+
+
+@dataclass
+class Img:
+    """Channels-last image batch: t is [N*H*W, C] (row = pixel)."""
+
+    t: Tensor
+    N: int
+    H: int
+    W: int
+
+    @property
+    def C(self) -> int:
+        return self.t.shape[1]
+
+    @staticmethod
+    def from_nchw(x: Tensor) -> "Img":
+        """View a logical-NCHW bf16 tensor in channels_last memory format as an Img (no copy); otherwise convert."""
+        N, Cc, H, W = x.shape
+        if x.dtype == BF16 and x.permute(0, 2, 3, 1).is_contiguous():
+            return Img(x.permute(0, 2, 3, 1).reshape(N * H * W, Cc), N, H, W)
+        return Img(nchw_to_tokens(x, Cc), N, H, W)
+
+    def to_nchw(self) -> Tensor:
+        """Logical NCHW view (channels_last memory format) of the same storage."""
+        return self.t.view(self.N, self.H, self.W, self.C).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter plumbing: bf16 shadows and fp32 grads
+# ------------------------------------------------------------------------------------------------
+def shadow(p: Tensor) -> Tensor:
+    """bf16 copy of an fp32 parameter in the same physical layout (flat store view, or cached cast)."""
+    s = getattr(p, "_nk_shadow", None)
+    if s is not None and getattr(p, "_nk_shadow_epoch", -1) == state.param_epoch:
+        return s
+    if getattr(p, "_nk_store", None) is not None:
+        # store-managed: the store refreshes all shadows at once
+        p._nk_store.refresh()
+        return p._nk_shadow
+    flat = _phys_flat(p)
+    s = torch.empty(flat.numel(), dtype=BF16, device=p.device)
+    n = flat.numel()
+    if n % 8 == 0:
+        call("nk_cast_f32_to_bf16", flat.data_ptr(), s.data_ptr(), n, _stream())
+    else:  # tiny odd-sized parameters
+        pad = torch.zeros((n + 7) // 8 * 8, dtype=torch.float32, device=p.device)
+        pad[:n] = flat
+        s8 = torch.empty(pad.numel(), dtype=BF16, device=p.device)
+        call("nk_cast_f32_to_bf16", pad.data_ptr(), s8.data_ptr(), pad.numel(), _stream())
+        s = s8[:n]
+    p._nk_shadow = s
+    p._nk_shadow_epoch = state.param_epoch
+    return s
+
+
+def _phys_flat(p: Tensor) -> Tensor:
+    """The parameter's storage as a flat fp32 tensor in physical order (conv weights: [O][KH][KW][I])."""
+    d = p.detach()
+    if d.dim() == 4:
+        d = d.permute(0, 2, 3, 1)
+    if not d.is_contiguous():
+        raise ValueError("parameter storage must be dense (conv weights in channels_last memory format)")
+    return d.reshape(-1)
+
+
+def grad_flat(p: Tensor) -> Tensor:
+    """fp32 gradient buffer of p in physical order (allocated zeroed on first use)."""
+    if p.grad is None:
+        g = torch.zeros_like(p, memory_format=torch.preserve_format)
+        p.grad = g
+    g = p.grad
+    if g.dim() == 4:
+        g = g.permute(0, 2, 3, 1)
+    if not g.is_contiguous():
+        raise ValueError("parameter .grad must share the parameter's physical layout")
+    return g.reshape(-1)
+
+
+def w2d(p: Tensor) -> Tensor:
+    """bf16 shadow as the [out, K] matrix the kernels read."""
+    return shadow(p).view(p.shape[0], -1)
+
+
+def g2d(p: Tensor) -> Tensor:
+    return grad_flat(p).view(p.shape[0], -1)
+
+
+def conv_weight_param(out_ch: int, in_ch: int, kh: int, kw: int) -> torch.nn.Parameter:
+    """fp32 OIHW parameter whose storage is [O][KH][KW][I] (channels_last), the layout the kernels read."""
+    base = torch.empty(out_ch, kh, kw, in_ch)
+    return torch.nn.Parameter(base.permute(0, 3, 1, 2))
+
+
+# ------------------------------------------------------------------------------------------------
+# layout / dtype boundary
+# ------------------------------------------------------------------------------------------------
+def nchw_to_tokens(x: Tensor, cpad: int, scale: float = 1.0) -> Tensor:
+    """NCHW (fp32 or bf16, contiguous) -> channels-last bf16 [N*H*W, cpad] (extra channels zero)."""
+    N, Cc, H, W = x.shape
+    x = x.contiguous()
+    if x.dtype not in (torch.float32, BF16):
+        raise ValueError(f"unsupported dtype {x.dtype}")
+    out = torch.empty(N * H * W, cpad, dtype=BF16, device=x.device)
+    call("nk_nchw_to_nhwc", x.data_ptr(), int(x.dtype == torch.float32), out.data_ptr(), N, Cc, H * W, cpad, scale, _stream())
+    return out
+
+
+def tokens_to_nchw(t: Tensor, N: int, Cc: int, H: int, W: int, dtype=torch.float32) -> Tensor:
+    """channels-last bf16 [N*H*W, cpad] -> contiguous NCHW tensor of `dtype` holding the first Cc channels."""
+    _check2d(t, "t")
+    out = torch.empty(N, Cc, H, W, dtype=dtype, device=t.device)
+    call("nk_nhwc_to_nchw", t.data_ptr(), out.data_ptr(), int(dtype == torch.float32), N, Cc, H * W, t.shape[1], _stream())
+    return out
+
+
+def cast_bf16(x: Tensor) -> Tensor:
+    """fp32 -> bf16 of a contiguous tensor (numel % 8 == 0)."""
+    if x.dtype == BF16:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    n = x.numel()
+    if n % 8:
+        raise ValueError("cast_bf16 needs numel % 8 == 0")
+    call("nk_cast_f32_to_bf16", x.data_ptr(), out.data_ptr(), n, _stream())
+    return out
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("add: contiguous tensors of equal shape expected")
+    out = torch.empty_like(a)
+    call("nk_add", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear
+# ------------------------------------------------------------------------------------------------
+def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, alpha: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    """y = alpha * x @ w^T + bias + residual ; x [M,K], w [N,K] bf16, bias fp32 [N], residual bf16 [M,N]."""
+    _check2d(x, "x")
+    _check2d(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm_nt: K mismatch {x.shape} vs {w.shape}")
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=x.device)
+    if residual is not None:
+        _check2d(residual, "residual")
+    call("nk_linear_fwd", x.data_ptr(), w.data_ptr(), _p(bias), _p(residual), out.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+         residual.stride(0) if residual is not None else 0, out.stride(0), float(alpha), _stream())
+    return out
+
+
+def gemm_nn(dy: Tensor, w: Tensor, dx_add: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """dx = dy @ w + dx_add ; dy [M,N], w [N,K]."""
+    _check2d(dy, "dy")
+    _check2d(w, "w")
+    M, N = dy.shape
+    K = w.shape[1]
+    if w.shape[0] != N:
+        raise ValueError(f"gemm_nn: N mismatch {dy.shape} vs {w.shape}")
+    if out is None:
+        out = torch.empty(M, K, dtype=BF16, device=dy.device)
+    if dx_add is not None:
+        _check2d(dx_add, "dx_add")
+    call("nk_linear_dgrad", dy.data_ptr(), w.data_ptr(), _p(dx_add), out.data_ptr(), M, N, K, dy.stride(0), w.stride(0),
+         dx_add.stride(0) if dx_add is not None else 0, out.stride(0), _stream())
+    return out
+
+
+def gemm_tn_f32(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool) -> None:
+    """dw (+)= dy^T @ x ; dy [M,N], x [M,K], dw fp32 [N,K]."""
+    _check2d(dy, "dy")
+    _check2d(x, "x")
+    M, N = dy.shape
+    K = x.shape[1]
+    if x.shape[0] != M or dw.shape != (N, K) or dw.dtype != torch.float32 or dw.stride(1) != 1:
+        raise ValueError(f"gemm_tn_f32: bad shapes {dy.shape} {x.shape} {dw.shape}")
+    call("nk_linear_wgrad", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), _stream())
+
+
+def colsum(dy: Tensor, out: Tensor, accumulate: bool) -> None:
+    _check2d(dy, "dy")
+    call("nk_colsum", dy.data_ptr(), out.data_ptr(), dy.shape[0], dy.shape[1], dy.stride(0), int(accumulate), _stream())
+
+
+def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor] = None, need_dx: bool = True):
+    """nn.Linear forward on a token matrix, with optional fused residual add.
+    bwd(dy, dx_add=None) -> dx (None if need_dx is False); writes weight.grad / bias.grad."""
+    y = gemm_nt(x, w2d(weight), bias, residual)
+
+    def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
+        gemm_tn_f32(dy, x, g2d(weight), state.grad_accumulate)
+        if bias is not None:
+            colsum(dy, grad_flat(bias), True)
+        if not need_dx:
+            return None
+        return gemm_nn(dy, w2d(weight), dx_add)
+
+    return y, bwd
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv2d (implicit GEMM)
+# ------------------------------------------------------------------------------------------------
+def _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, upsample) -> NkConvDesc:
+    return NkConvDesc(N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, int(upsample))
+
+
+def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, padding=1, upsample: bool = False,
+               rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None, need_dx: bool = True,
+               asym_pad: bool = False):
+    """nn.Conv2d forward on channels-last data as implicit GEMM.
+    padding: int (symmetric) ; asym_pad=True reproduces ConstantPad2d((0,1,0,1)) + padding 0 (model.py:71-79).
+    rowvec: bf16 [N, Cout] added to every pixel of image n (ResBlock emb_out); residual: bf16 [N*Ho*Wo, Cout].
+    bwd(dy) -> (dx Img | None, d_rowvec | None)."""
+    Cout, Cin, KH, KW = weight.shape
+    if x.C != Cin:
+        raise ValueError(f"conv2d: input has {x.C} channels, weight expects {Cin}")
+    Hin, Win = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
+    if asym_pad:
+        pad_t = pad_l = 0
+        Ho = (Hin + 1 - KH) // stride + 1
+        Wo = (Win + 1 - KW) // stride + 1
+    else:
+        pad_t = pad_l = int(padding)
+        Ho = (Hin + 2 * pad_t - KH) // stride + 1
+        Wo = (Win + 2 * pad_l - KW) // stride + 1
+    d = _conv_desc(x.N, x.H, x.W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, upsample)
+    y = torch.empty(x.N * Ho * Wo, Cout, dtype=BF16, device=x.t.device)
+    _check2d(x.t, "x")
+    if not x.t.is_contiguous():
+        raise ValueError("conv2d: x must be dense channels-last")
+    call("nk_conv2d_fwd", C.byref(d), x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(), _stream())
+    out = Img(y, x.N, Ho, Wo)
+
+    def bwd(dy: Tensor):
+        _check2d(dy, "dy")
+        if not dy.is_contiguous():
+            raise ValueError("conv2d bwd: dy must be dense")
+        call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), int(state.grad_accumulate), _stream())
+        if bias is not None:
+            colsum(dy, grad_flat(bias), True)
+        drow = None
+        if rowvec is not None:
+            drow32 = torch.empty(x.N, Cout, dtype=torch.float32, device=dy.device)
+            for n in range(x.N):
+                colsum(dy[n * Ho * Wo:(n + 1) * Ho * Wo], drow32[n], False)
+            drow = cast_bf16(drow32)
+        dx = None
+        if need_dx:
+            dxt = torch.empty(x.N * Hin * Win, Cin, dtype=BF16, device=dy.device)
+            call("nk_conv2d_dgrad", C.byref(d), dy.data_ptr(), w2d(weight).data_ptr(), dxt.data_ptr(), _stream())
+            if upsample:
+                dsm = torch.empty(x.N * x.H * x.W, Cin, dtype=BF16, device=dy.device)
+                call("nk_upsample2x_bwd", dxt.data_ptr(), dsm.data_ptr(), x.N, x.H, x.W, Cin, _stream())
+                dxt = dsm
+            dx = Img(dxt, x.N, x.H, x.W)
+        return dx, drow
+
+    return out, bwd
+
+
+# ------------------------------------------------------------------------------------------------
+# norms / activations
+# ------------------------------------------------------------------------------------------------
+def groupnorm_fwd(x: Img, weight: Tensor, bias: Tensor, groups: int, eps: float, silu: bool):
+    """GroupNorm (+SiLU).  bwd(dy, dx_add=None) -> dx token matrix."""
+    if not x.t.is_contiguous():
+        raise ValueError("groupnorm: x must be dense channels-last")
+    N, HW, Cc = x.N, x.H * x.W, x.C
+    y = torch.empty_like(x.t)
+    mean = torch.empty(N, groups, dtype=torch.float32, device=x.t.device)
+    rstd = torch.empty_like(mean)
+    ws = torch.empty(N, groups, 2, dtype=torch.float32, device=x.t.device)
+    call("nk_groupnorm_fwd", x.t.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+         ws.data_ptr(), N, HW, Cc, groups, float(eps), int(silu), _stream())
+
+    def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
+        dx = torch.empty_like(x.t)
+        ws2 = torch.empty(N, groups, 2, dtype=torch.float32, device=dy.device)
+        call("nk_groupnorm_bwd", dy.data_ptr(), x.t.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+             _p(dx_add), dx.data_ptr(), grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws2.data_ptr(), N, HW, Cc, groups,
+             int(silu), _stream())
+        return dx
+
+    return Img(y, x.N, x.H, x.W), bwd
+
+
+def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
+    """LayerNorm over the last dim of a dense token matrix.  bwd(dy, dx_add=None) -> dx."""
+    _check2d(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("layernorm: x must be dense")
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    call("nk_layernorm_fwd", x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, Cc, float(eps), _stream())
+
+    def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
+        dx = torch.empty_like(x)
+        call("nk_layernorm_bwd", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add), dx.data_ptr(),
+             grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), M, Cc, _stream())
+        return dx
+
+    return y, bwd
+
+
+def geglu_fwd(u: Tensor):
+    _check2d(u, "u")
+    M, I2 = u.shape
+    inner = I2 // 2
+    y = torch.empty(M, inner, dtype=BF16, device=u.device)
+    call("nk_geglu_fwd", u.data_ptr(), y.data_ptr(), M, inner, _stream())
+
+    def bwd(dy: Tensor):
+        du = torch.empty_like(u)
+        call("nk_geglu_bwd", dy.data_ptr(), u.data_ptr(), du.data_ptr(), M, inner, _stream())
+        return du
+
+    return y, bwd
+
+
+def silu_fwd(x: Tensor):
+    y = torch.empty_like(x)
+    call("nk_silu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+
+    def bwd(dy: Tensor):
+        dx = torch.empty_like(x)
+        call("nk_silu_bwd", dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel(), _stream())
+        return dx
+
+    return y, bwd
+
+
+def cat_fwd(a: Img, b: Img):
+    """torch.cat([a, b], dim=1) on channels-last images.  bwd(dout) -> (da, db) token matrices."""
+    if (a.N, a.H, a.W) != (b.N, b.H, b.W):
+        raise ValueError("cat: spatial shapes differ")
+    rows = a.t.shape[0]
+    out = torch.empty(rows, a.C + b.C, dtype=BF16, device=a.t.device)
+    call("nk_cat_channels", a.t.data_ptr(), b.t.data_ptr(), out.data_ptr(), rows, a.C, b.C, _stream())
+    Ca, Cb = a.C, b.C
+
+    def bwd(dout: Tensor):
+        da = torch.empty(rows, Ca, dtype=BF16, device=dout.device)
+        db = torch.empty(rows, Cb, dtype=BF16, device=dout.device)
+        call("nk_split_channels", dout.data_ptr(), da.data_ptr(), db.data_ptr(), rows, Ca, Cb, _stream())
+        return da, db
+
+    return Img(out, a.N, a.H, a.W), bwd
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head: int):
+    """softmax(q k^T / sqrt(d)) v.  q [B*Lq, H*D], k/v [B*Lk, H*D] token matrices (column slices allowed).
+    bwd(do) -> (dq, dk, dv) dense token matrices."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _check2d(t, n)
+    Lq, Lk = q.shape[0] // B, k.shape[0] // B
+    HD = heads * dim_head
+    o = torch.empty(B * Lq, HD, dtype=BF16, device=q.device)
+    lse = torch.empty(B, heads, Lq, dtype=torch.float32, device=q.device)
+    d = NkAttnDesc()
+    d.B, d.H, d.Lq, d.Lk, d.D = B, heads, Lq, Lk, dim_head
+    d.sq, d.sk, d.sv, d.so = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    d.bq, d.bk, d.bv, d.bo = Lq * q.stride(0), Lk * k.stride(0), Lk * v.stride(0), Lq * o.stride(0)
+    d.scale = float(dim_head) ** -0.5
+    call("nk_attention_fwd", C.byref(d), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), _stream())
+
+    def bwd(do: Tensor, dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None):
+        _check2d(do, "do")
+        dq = torch.empty(B * Lq, HD, dtype=BF16, device=do.device) if dq is None else dq
+        dk = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dk is None else dk
+        dv = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dv is None else dv
+        d.sdq, d.sdk, d.sdv, d.sdo = dq.stride(0), dk.stride(0), dv.stride(0), do.stride(0)
+        d.bdq, d.bdk, d.bdv, d.bdo = Lq * dq.stride(0), Lk * dk.stride(0), Lk * dv.stride(0), Lq * do.stride(0)
+        delta = torch.empty(B, heads, Lq, dtype=torch.float32, device=do.device)
+        call("nk_attention_bwd", C.byref(d), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(),
+             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), _stream())
+        return dq, dk, dv
+
+    return o, bwd
+
+
+def attention_unfused(q: Tensor, k: Tensor, v: Tensor, B: int) -> Tensor:
+    """Single-head attention with any head dim via two MFMA GEMMs and a row softmax (inference only;
+    the VAE mid block, modules/diffusion/model.py:224-243).  q/k/v dense [B*L, D]."""
+    L = q.shape[0] // B
+    D = q.shape[1]
+    out = torch.empty_like(q)
+    s = torch.empty(L, L, dtype=BF16, device=q.device)
+    for b in range(B):
+        sl = slice(b * L, (b + 1) * L)
+        gemm_nt(q[sl], k[sl], alpha=float(D) ** -0.5, out=s)
+        call("nk_softmax_rows", s.data_ptr(), L, L, _stream())
+        gemm_nn(s, v[sl], out=out[sl])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# misc
+# ------------------------------------------------------------------------------------------------
+def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tensor:
+    tf = t.to(torch.float32).contiguous()
+    out = torch.empty(tf.shape[0], dim, dtype=BF16, device=t.device)
+    call("nk_timestep_embedding", tf.data_ptr(), out.data_ptr(), tf.shape[0], dim, float(max_period), _stream())
+    return out

@@ -1,0 +1,287 @@
+"""Op-level parity of the HIP kernels (through the C-ABI) against plain PyTorch fp32 on the CPU.
+
+Tolerances (stated per SURVEY section 8(c)): kernels read bf16 operands, accumulate in fp32 and write
+bf16, so the normalised max error budget per op is 2e-2 (bf16 has 8 significant bits: 2^-8 = 3.9e-3 per
+rounding); fp32 outputs (weight gradients, statistics) are held to 1e-2 of their max magnitude because
+their bf16 INPUTS are exact in both paths and only the accumulation order differs (observed ~1e-5).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+TOL_BF16 = 2e-2
+TOL_F32 = 1e-2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from neurosis_amd import ops as o
+
+    return o
+
+
+def dev(x, dtype=torch.bfloat16):
+    return x.to("cuda", dtype=dtype)
+
+
+def rnd(*shape, scale=1.0, seed=None):
+    g = torch.Generator().manual_seed(seed if seed is not None else (sum(shape) * 7919 + len(shape)))
+    return bf16_round(torch.randn(*shape, generator=g) * scale)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 320), (308, 640, 2048), (4, 1280, 320), (1000, 72, 136), (16384, 640, 640)])
+def test_linear_fwd(ops, M, N, K):
+    x, w, b, r = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N), rnd(M, N)
+    ref = x @ w.t() + b + r
+    got = ops.gemm_nt(dev(x), dev(w), dev(b, torch.float32), dev(r))
+    assert_close(got, ref, TOL_BF16, "linear_fwd")
+
+
+def test_linear_fwd_strided_alpha(ops):
+    M, N, K = 200, 96, 64
+    xf = rnd(M, 3 * K)
+    w = rnd(N, K, scale=0.1)
+    x = dev(xf)[:, K:2 * K]
+    got = ops.gemm_nt(x, dev(w), alpha=0.25)
+    assert_close(got, 0.25 * xf[:, K:2 * K] @ w.t(), TOL_BF16, "linear_fwd strided")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 200, 320), (4096, 1280, 640), (8, 1280, 2816)])
+def test_linear_dgrad(ops, M, N, K):
+    dy, w, a = rnd(M, N), rnd(N, K, scale=N ** -0.5), rnd(M, K)
+    got = ops.gemm_nn(dev(dy), dev(w), dev(a))
+    assert_close(got, dy @ w + a, TOL_BF16, "linear_dgrad")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 200, 320), (16384, 640, 640), (308, 1280, 2048), (4, 1280, 320)])
+def test_linear_wgrad(ops, M, N, K):
+    dy, x = rnd(M, N), rnd(M, K)
+    ref = dy.t() @ x
+    dw = torch.full((N, K), 7.0, device="cuda")
+    ops.gemm_tn_f32(dev(dy), dev(x), dw, False)
+    assert_close(dw, ref, TOL_F32, "linear_wgrad store")
+    ops.gemm_tn_f32(dev(dy), dev(x), dw, True)
+    assert_close(dw, 2 * ref, TOL_F32, "linear_wgrad accumulate")
+
+
+def test_colsum(ops):
+    dy = rnd(5000, 2560)
+    out = torch.zeros(2560, device="cuda")
+    ops.colsum(dev(dy), out, False)
+    assert_close(out, dy.sum(0), TOL_F32, "colsum")
+
+
+# ------------------------------------------------------------------------------------------------
+def _conv_case(ops, N, H, W, Cin, Cout, k, stride, padding, upsample=False, asym=False, rowvec=False, residual=False):
+    x = rnd(N, Cin, H, W)
+    w = rnd(Cout, Cin, k, k, scale=(Cin * k * k) ** -0.5)
+    b = rnd(Cout)
+    xi = x
+    if upsample:
+        xi = F.interpolate(x, scale_factor=2, mode="nearest")
+    if asym:
+        xi = F.pad(xi, (0, 1, 0, 1))
+    xi = xi.requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xi, wr, b, stride=stride, padding=0 if asym else padding)
+    rv = rs = None
+    if rowvec:
+        rv = rnd(N, Cout)
+        ref = ref + rv[:, :, None, None]
+    if residual:
+        rs = rnd(*ref.shape)
+        ref = ref + rs
+    dy = rnd(*ref.shape)
+    ref.backward(dy)
+
+    weight = torch.nn.Parameter(dev(w, torch.float32).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2))
+    bias = torch.nn.Parameter(dev(b, torch.float32))
+    img = ops.Img(dev(x).permute(0, 2, 3, 1).reshape(-1, Cin).contiguous(), N, H, W)
+    rvd = dev(rv) if rv is not None else None
+    rsd = dev(rs).permute(0, 2, 3, 1).reshape(-1, Cout).contiguous() if rs is not None else None
+    out, bwd = ops.conv2d_fwd(img, weight, bias, stride=stride, padding=padding, upsample=upsample, rowvec=rvd, residual=rsd, asym_pad=asym)
+    got = out.t.view(N, out.H, out.W, Cout).permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert_close(got, ref, TOL_BF16, "conv fwd")
+    dx, drow = bwd(dev(dy).permute(0, 2, 3, 1).reshape(-1, Cout).contiguous())
+    dxr = xi.grad
+    if asym:
+        dxr = dxr[:, :, :-1, :-1]
+    if upsample:
+        dxr = dxr.view(N, Cin, H, 2, W, 2).sum((3, 5))
+    assert_close(dx.t.view(N, H, W, Cin).permute(0, 3, 1, 2), dxr, TOL_BF16, "conv dgrad")
+    assert_close(weight.grad, wr.grad, TOL_F32, "conv wgrad")
+    assert_close(bias.grad, dy.sum((0, 2, 3)), TOL_F32, "conv bias grad")
+    if rowvec:
+        assert_close(drow, dy.sum((2, 3)), TOL_BF16, "conv rowvec grad")
+
+
+def test_conv3x3_s1(ops):
+    _conv_case(ops, 2, 16, 16, 64, 128, 3, 1, 1, rowvec=True, residual=True)
+
+
+def test_conv3x3_ragged(ops):
+    _conv_case(ops, 3, 19, 13, 40, 72, 3, 1, 1)
+
+
+def test_conv3x3_s2(ops):
+    _conv_case(ops, 2, 16, 16, 64, 64, 3, 2, 1)
+
+
+def test_conv3x3_s2_asym(ops):
+    _conv_case(ops, 2, 16, 16, 32, 32, 3, 2, 0, asym=True)
+
+
+def test_conv3x3_upsample(ops):
+    _conv_case(ops, 2, 8, 8, 64, 64, 3, 1, 1, upsample=True)
+
+
+def test_conv3x3_real_channels(ops):
+    _conv_case(ops, 1, 32, 32, 320, 320, 3, 1, 1)
+
+
+def test_conv3x3_pad_channels(ops):
+    # the 4-channel latent convs run with channels padded to 8 (zeros)
+    _conv_case(ops, 2, 16, 16, 8, 320, 3, 1, 1)
+    _conv_case(ops, 2, 16, 16, 320, 8, 3, 1, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,C,silu,eps", [(2, 16, 16, 320, True, 1e-5), (2, 8, 8, 2560, True, 1e-5), (3, 9, 7, 640, False, 1e-6), (1, 32, 32, 128, True, 1e-6)])
+def test_groupnorm(ops, N, H, W, C, silu, eps):
+    x = (rnd(N, C, H, W) * 2 + 0.5)
+    x = bf16_round(x).requires_grad_(True)
+    gamma, beta = rnd(C) * 0.5 + 1, rnd(C) * 0.1
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.group_norm(x, 32, gr, br, eps)
+    if silu:
+        ref = F.silu(ref)
+    dy, extra = rnd(N, C, H, W), rnd(N, C, H, W)
+    ref.backward(dy)
+    w, b = torch.nn.Parameter(dev(gamma, torch.float32)), torch.nn.Parameter(dev(beta, torch.float32))
+    tok = lambda t: dev(t.detach()).permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+    out, bwd = ops.groupnorm_fwd(ops.Img(tok(x), N, H, W), w, b, 32, eps, silu)
+    assert_close(out.t.view(N, H, W, C).permute(0, 3, 1, 2), ref, TOL_BF16, "gn fwd")
+    dx = bwd(tok(dy), tok(extra))
+    assert_close(dx.view(N, H, W, C).permute(0, 3, 1, 2), x.grad + extra, TOL_BF16, "gn dx")
+    assert_close(w.grad, gr.grad, TOL_F32, "gn dgamma")
+    assert_close(b.grad, br.grad, TOL_F32, "gn dbeta")
+
+
+@pytest.mark.parametrize("M,C", [(1000, 640), (512, 1280), (77, 320)])
+def test_layernorm(ops, M, C):
+    x = bf16_round(rnd(M, C) * 1.5 + 0.3).requires_grad_(True)
+    gamma, beta = rnd(C) * 0.5 + 1, rnd(C) * 0.1
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(x, (C,), gr, br, 1e-5)
+    dy, extra = rnd(M, C), rnd(M, C)
+    ref.backward(dy)
+    w, b = torch.nn.Parameter(dev(gamma, torch.float32)), torch.nn.Parameter(dev(beta, torch.float32))
+    out, bwd = ops.layernorm_fwd(dev(x.detach()), w, b, 1e-5)
+    assert_close(out, ref, TOL_BF16, "ln fwd")
+    dx = bwd(dev(dy), dev(extra))
+    assert_close(dx, x.grad + extra, TOL_BF16, "ln dx")
+    assert_close(w.grad, gr.grad, TOL_F32, "ln dgamma")
+    assert_close(b.grad, br.grad, TOL_F32, "ln dbeta")
+
+
+def test_geglu_silu_add_cat(ops):
+    M, I = 300, 2560
+    u = rnd(M, 2 * I).requires_grad_(True)
+    a, g = u.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    dy = rnd(M, I)
+    ref.backward(dy)
+    y, bwd = ops.geglu_fwd(dev(u.detach()))
+    assert_close(y, ref, TOL_BF16, "geglu fwd")
+    assert_close(bwd(dev(dy)), u.grad, TOL_BF16, "geglu bwd")
+
+    x = rnd(4, 1280).requires_grad_(True)
+    r = F.silu(x)
+    d = rnd(4, 1280)
+    r.backward(d)
+    y, bwd = ops.silu_fwd(dev(x.detach()))
+    assert_close(y, r, TOL_BF16, "silu fwd")
+    assert_close(bwd(dev(d)), x.grad, TOL_BF16, "silu bwd")
+
+    p, q = rnd(100, 64), rnd(100, 64)
+    assert_close(ops.add(dev(p), dev(q)), p + q, TOL_BF16, "add")
+
+    A, Bc = rnd(2 * 5 * 7, 320), rnd(2 * 5 * 7, 640)
+    out, bwd = ops.cat_fwd(ops.Img(dev(A), 2, 5, 7), ops.Img(dev(Bc), 2, 5, 7))
+    ref = torch.cat([A, Bc], 1)
+    assert torch.equal(out.t.float().cpu(), ref)
+    da, db = bwd(out.t)
+    assert torch.equal(da.float().cpu(), A) and torch.equal(db.float().cpu(), Bc)
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, B, H, D):
+    Lq, Lk = q.shape[0] // B, k.shape[0] // B
+    sp = lambda t, L: t.view(B, L, H, D).transpose(1, 2)
+    o = F.scaled_dot_product_attention(sp(q, Lq), sp(k, Lk), sp(v, Lk))
+    return o.transpose(1, 2).reshape(B * Lq, H * D)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,D", [(2, 4, 256, 256, 64), (2, 5, 200, 77, 64), (1, 2, 1000, 1000, 64), (2, 3, 130, 77, 40), (1, 2, 96, 96, 160), (1, 1, 64, 200, 80)])
+def test_attention(ops, B, H, Lq, Lk, D):
+    q, k, v = rnd(B * Lq, H * D), rnd(B * Lk, H * D, seed=5), rnd(B * Lk, H * D, seed=6)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, B, H, D)
+    do = rnd(B * Lq, H * D, seed=9)
+    ref.backward(do)
+    o, bwd = ops.attention_fwd(dev(q), dev(k), dev(v), B, H, D)
+    assert_close(o, ref, TOL_BF16, "attn fwd")
+    dq, dk, dv = bwd(dev(do))
+    assert_close(dq, qr.grad, TOL_BF16, "attn dq")
+    assert_close(dk, kr.grad, TOL_BF16, "attn dk")
+    assert_close(dv, vr.grad, TOL_BF16, "attn dv")
+
+
+def test_attention_fused_qkv_slices_and_spike(ops):
+    """q/k/v as column slices of one buffer; one key spiked so the online-softmax rescale path is taken late."""
+    B, H, L, D = 1, 2, 320, 64
+    qkv = rnd(B * L, 3 * H * D)
+    qkv[300, H * D:2 * H * D] *= 12.0  # a dominant key in the last tile
+    q, k, v = qkv.split(H * D, dim=1)
+    ref = _attn_ref(q, k, v, B, H, D)
+    g = dev(qkv)
+    o, _ = ops.attention_fwd(g[:, :H * D], g[:, H * D:2 * H * D], g[:, 2 * H * D:], B, H, D)
+    assert_close(o, ref, TOL_BF16, "attn fused-slices")
+
+
+def test_attention_unfused_d512(ops):
+    B, L, D = 2, 256, 512
+    q, k, v = rnd(B * L, D), rnd(B * L, D, seed=1), rnd(B * L, D, seed=2)
+    ref = _attn_ref(q, k, v, B, 1, D)
+    got = ops.attention_unfused(dev(q), dev(k), dev(v), B)
+    assert_close(got, ref, TOL_BF16, "attn unfused d512")
+
+
+# ------------------------------------------------------------------------------------------------
+def test_layout_and_timestep(ops):
+    x = rnd(2, 4, 16, 12)
+    t = ops.nchw_to_tokens(dev(x, torch.float32), 8)
+    ref = torch.zeros(2, 16, 12, 8)
+    ref[..., :4] = x.permute(0, 2, 3, 1)
+    assert torch.equal(t.float().cpu().view(2, 16, 12, 8), ref)
+    back = ops.tokens_to_nchw(t, 2, 4, 16, 12)
+    assert torch.equal(back.cpu(), x)
+    big = rnd(2, 70, 9, 5)
+    tb = ops.nchw_to_tokens(dev(big), 72)
+    assert torch.equal(tb.float().cpu().view(2, 9, 5, 72)[..., :70], big.permute(0, 2, 3, 1))
+
+    ts = torch.tensor([0.0, 1.0, 500.0, 999.0])
+    got = ops.timestep_embedding(ts.cuda(), 320)
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    args = ts[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert float((got.float().cpu() - ref).abs().max()) < 1e-2
