@@ -1,0 +1,207 @@
+"""VAE Encoder on MI355X: the class surface of neurosis.modules.diffusion.model.Encoder
+(/root/reference/src/neurosis/modules/diffusion/model.py:456-606) over the HIP kernels.
+
+The hot path only ever runs the encoder forward under no_grad (DiffusionEngine.encode_first_stage,
+models/diffusion.py:186-197), so this mirror is forward-only: same constructor arguments, module tree and
+state_dict keys (conv_in, down.{l}.block.{i}.{norm1,conv1,norm2,conv2,nin_shortcut}, down.{l}.downsample.conv,
+mid.{block_1,attn_1,block_2}, norm_out, conv_out, quant_conv).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from ... import ops
+from ...nn import Conv2d
+from ...ops import BF16, Img
+
+
+def Normalize(in_channels: int, num_groups: int = 32) -> nn.GroupNorm:
+    """modules/layers.py:5-7."""
+    return nn.GroupNorm(num_groups=num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def _gn(x: Img, norm: nn.GroupNorm, silu: bool) -> Img:
+    return ops.groupnorm_fwd(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)[0]
+
+
+class Downsample(nn.Module):
+    """model.py:65-82: ConstantPad2d((0,1,0,1)) + 3x3 stride-2 conv, as one implicit-GEMM gather."""
+
+    def __init__(self, in_channels: int, with_conv: bool):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("resamp_with_conv=False is not used by the SD/SDXL VAE")
+        self.with_conv = with_conv
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0, asym_pad=True)
+
+    def fwd(self, x: Img) -> Img:
+        return self.conv.fwd(x, need_dx=False)[0]
+
+
+class ResnetBlock(nn.Module):
+    """model.py:85-134 with temb=None."""
+
+    def __init__(self, *, in_channels: int, out_channels: Optional[int] = None, conv_shortcut: bool = False, dropout: float = 0.0, temb_channels: int = 512):
+        super().__init__()
+        self.in_channels = in_channels
+        out_channels = in_channels if out_channels is None else out_channels
+        self.out_channels = out_channels
+        self.use_conv_shortcut = conv_shortcut
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if temb_channels > 0:
+            self.temb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = nn.Identity()
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if self.in_channels != self.out_channels:
+            if self.use_conv_shortcut:
+                self.conv_shortcut = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+            else:
+                self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+
+    def fwd(self, x: Img) -> Img:
+        h = self.conv1.fwd(_gn(x, self.norm1, True), need_dx=False)[0]
+        h = _gn(h, self.norm2, True)
+        if self.in_channels != self.out_channels:
+            if self.use_conv_shortcut:
+                s = self.conv_shortcut.fwd(x, need_dx=False)[0].t
+            else:
+                s = ops.gemm_nt(x.t, ops.w2d(self.nin_shortcut.weight), self.nin_shortcut.bias)
+        else:
+            s = x.t
+        return self.conv2.fwd(h, residual=s, need_dx=False)[0]
+
+
+class AttnBlock(nn.Module):
+    """model.py:144-243 (AttnBlock / MemoryEfficientAttnBlock / TorchSDPAttnBlock): single-head self-attention over
+    H*W tokens with head dim = C (512 for the SD VAE): q k^T and p v as MFMA GEMMs around a row softmax."""
+
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.k = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.v = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.proj_out = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+
+    def fwd(self, x: Img) -> Img:
+        hn = _gn(x, self.norm, False)
+        q, k, v = (ops.gemm_nt(hn.t, ops.w2d(m.weight), m.bias) for m in (self.q, self.k, self.v))
+        o = ops.attention_unfused(q, k, v, x.N)
+        y = ops.gemm_nt(o, ops.w2d(self.proj_out.weight), self.proj_out.bias, residual=x.t)
+        return Img(y, x.N, x.H, x.W)
+
+
+MemoryEfficientAttnBlock = AttnBlock
+
+
+def make_attn(in_channels: int, attn_type: str = "vanilla", attn_kwargs=None) -> nn.Module:
+    """model.py:255-283.  "vanilla" (AttnBlock) and "vanilla-xformers" (MemoryEfficientAttnBlock, what the SD/SDXL
+    configs name) are the same function and map to the HIP AttnBlock.  The reference's "torch-sdp" block
+    (TorchSDPAttnBlock, model.py:224-243) views the NCHW q/k/v memory as (B, HW, 1, C) WITHOUT permuting, i.e. it
+    attends over scrambled tokens -- a different function that no shipped config selects; it is refused rather than
+    silently replaced (SURVEY quirk list)."""
+    if attn_type in ("vanilla", "vanilla-xformers"):
+        return AttnBlock(in_channels)
+    if attn_type == "none":
+        return nn.Identity()
+    if attn_type == "torch-sdp":
+        raise ValueError("attn_type 'torch-sdp' (TorchSDPAttnBlock) scrambles tokens in the reference; use 'vanilla' or 'vanilla-xformers'")
+    raise ValueError(f"attn_type {attn_type} unknown or outside the SD/SDXL path")
+
+
+class Encoder(nn.Module):
+    """model.py:456-606."""
+
+    def __init__(self, *, ch: int, out_ch: int, ch_mult: Sequence[int] = (1, 2, 4, 8), num_res_blocks: int, attn_resolutions: Sequence[int],
+                 dropout: float = 0.0, resamp_with_conv: bool = True, in_channels: int, resolution: int, z_channels: int, double_z: bool = True,
+                 use_linear_attn: bool = False, attn_type: str = "vanilla", embed_dim: int = 256, standalone: bool = False, **kwargs):
+        super().__init__()
+        self.ch = ch
+        self.temb_ch = 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.z_channels = z_channels
+        self.double_z = double_z
+        self.conv_in = Conv2d(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.in_ch_mult = in_ch_mult
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block = nn.ModuleList()
+            attn = nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=self.temb_ch, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(make_attn(block_in, attn_type=attn_type))
+            down = nn.Module()
+            down.block = block
+            down.attn = attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res = curr_res // 2
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = Conv2d(block_in, 2 * z_channels if double_z else z_channels, kernel_size=3, stride=1, padding=1)
+        self.max_batch_size = None
+        self.standalone = standalone
+        if self.standalone:
+            qc = (1 + double_z) * z_channels
+            self.quant_conv = Conv2d(qc, (1 + double_z) * embed_dim, 1)
+        else:
+            self.quant_conv = nn.Identity()
+
+    def fwd(self, x: Img) -> Img:
+        """encode + quant_conv on an Img whose channels are already padded to a multiple of 8."""
+        h = self.conv_in.fwd(x, need_dx=False)[0]
+        for i_level in range(self.num_resolutions):
+            for i_block in range(self.num_res_blocks):
+                h = self.down[i_level].block[i_block].fwd(h)
+                if len(self.down[i_level].attn) > 0:
+                    h = self.down[i_level].attn[i_block].fwd(h)
+            if i_level != self.num_resolutions - 1:
+                h = self.down[i_level].downsample.fwd(h)
+        h = self.mid.block_1.fwd(h)
+        if not isinstance(self.mid.attn_1, nn.Identity):
+            h = self.mid.attn_1.fwd(h)
+        h = self.mid.block_2.fwd(h)
+        h = self.conv_out.fwd(_gn(h, self.norm_out, True), need_dx=False)[0]
+        if self.standalone:
+            h = self.quant_conv.fwd(h, need_dx=False)[0]
+        return h
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, regularize: bool = False) -> Tensor:
+        """model.py:585-606.  With regularize=True returns the DiagonalGaussian mode = the mean half of the
+        moments (regularizers.py:31-41, distributions.py:28-37,71-72; the discarded KL term is not computed).
+        Returns fp32 NCHW."""
+        N, Cin, H, W = x.shape
+        bs = self.max_batch_size or N
+        outs = []
+        for i in range(0, N, bs):
+            xb = x[i:i + bs]
+            n = xb.shape[0]
+            img = Img(ops.nchw_to_tokens(xb.float() if xb.dtype not in (torch.float32, BF16) else xb, (Cin + 7) // 8 * 8), n, H, W)
+            h = self.fwd(img)
+            zc = h.C if not self.standalone else self.quant_conv.out_channels
+            zc_real = self.conv_out.out_channels if not self.standalone else self.quant_conv.out_channels
+            keep = zc_real // 2 if (regularize and self.double_z) else zc_real
+            outs.append(ops.tokens_to_nchw(h.t, n, keep, h.H, h.W, dtype=torch.float32))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)

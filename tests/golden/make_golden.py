@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Generates the golden vectors under tests/golden/ by running the REFERENCE (neggles/neurosis, read-only at
+/root/reference) on the CPU in the authoring container.  The reference never travels to the GPU box; only
+the small fixtures written here do.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.pt / *.json
+
+Third-party packages the reference imports but this image lacks (lightning, torchvision, open_clip, ...) are
+replaced by empty stand-in modules at import time only; xformers is left genuinely
+absent because the reference handles that ImportError itself.  Nothing of the reference's source is copied:
+the fixtures hold inputs, outputs, gradients and the (name, shape) list of its state_dicts.
+
+Weights are a pure function of (parameter name, shape) -- see `synth_state_dict` -- so no checkpoint is
+stored; zero-initialised modules get non-zero values so gradients are non-trivial.
+"""
+from __future__ import annotations
+
+import importlib.abc
+import importlib.machinery
+import json
+import sys
+import types
+import zlib
+from pathlib import Path
+from unittest import mock
+
+import torch
+
+HERE = Path(__file__).resolve().parent
+REF_SRC = Path("/root/reference/src")
+
+STUB_ROOTS = {
+    "torchvision", "lightning", "lightning_fabric", "pytorch_lightning", "open_clip", "diffusers", "kornia", "jsonargparse", "wandb", "omegaconf",
+    "natsort", "pytorch_optimizer", "torchmetrics", "cv2", "pymongo", "adlfs", "pynvml", "bitsandbytes", "deepspeed", "s3fs", "boto3", "botocore",
+    "colorcet", "matplotlib", "imageio", "clip", "dreamsim", "lpips", "timm", "peft", "gridfs", "bson", "webdataset", "scipy_stub",
+}
+
+
+class _StubLoader(importlib.abc.Loader):
+    def create_module(self, spec):
+        m = types.ModuleType(spec.name)
+        m.__path__ = []  # behave as a package
+        m.__getattr__ = lambda name: _dummy(spec.name, name)  # type: ignore[attr-defined]
+        return m
+
+    def exec_module(self, module):
+        if module.__name__ == "lightning.pytorch" or module.__name__ == "pytorch_lightning":
+            module.LightningModule = type("LightningModule", (torch.nn.Module,), {})
+            module.LightningDataModule = type("LightningDataModule", (), {})
+            module.Callback = type("Callback", (), {})
+
+
+class _DummyMeta(type):
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _dummy(cls.__name__, name)
+
+    def __call__(cls, *a, **k):
+        return type.__call__(cls)
+
+    def __or__(cls, other):
+        return cls
+
+    def __ror__(cls, other):
+        return cls
+
+
+def _dummy(mod: str, name: str):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    return _DummyMeta(name, (), {"__init__": lambda self, *a, **k: None, "__class_getitem__": classmethod(lambda cls, item: cls),
+                                 "__getattr__": lambda self, n: _dummy(name, n), "__call__": lambda self, *a, **k: self})
+
+
+class _StubFinder(importlib.abc.MetaPathFinder):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, _StubLoader(), is_package=True)
+        return None
+
+
+def import_reference():
+    sys.meta_path.insert(0, _StubFinder())
+    sys.path.insert(0, str(REF_SRC))
+    import neurosis.modules.diffusion as nd  # noqa
+    import neurosis.modules.diffusion.model as nmodel  # noqa
+
+    return nd, nmodel
+
+
+# ------------------------------------------------------------------------------------------------
+def synth_tensor(name: str, shape, kind_hint: str = "") -> torch.Tensor:
+    """Deterministic value for a parameter, a pure function of its name and shape."""
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    shape = tuple(shape)
+    leaf = name.rsplit(".", 1)[-1]
+    is_norm = any(t in name for t in (".norm", "norm1", "norm2", "norm3", "norm_out", "in_layers.0", "out_layers.0", "out.0"))
+    if leaf == "weight" and len(shape) == 1 and is_norm:
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if leaf == "bias":
+        return 0.05 * torch.randn(shape, generator=g)
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return torch.randn(shape, generator=g) * (1.0 / max(fan_in, 1)) ** 0.5
+
+
+def synth_state_dict(shapes: dict) -> dict:
+    return {k: synth_tensor(k, v) for k, v in shapes.items()}
+
+
+UNET_TINY = dict(
+    in_channels=4, model_channels=32, out_channels=4, num_res_blocks=2, attention_resolutions=[4, 2], channel_mult=[1, 2, 4],
+    num_head_channels=16, use_linear_in_transformer=True, transformer_depth=[1, 1, 2], context_dim=64, adm_in_channels=48,
+    num_classes="sequential", spatial_transformer_attn_type="torch-sdp", use_checkpoint=False,
+)
+# SD1.5-style: conv proj_in/out (use_linear False), num_heads instead of head channels, attention at every level, no y
+UNET_SD15_TINY = dict(
+    in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4],
+    num_heads=4, transformer_depth=1, context_dim=48, spatial_transformer_attn_type="torch-sdp", use_checkpoint=False,
+)
+VAE_TINY = dict(
+    ch=32, out_ch=3, ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=64, z_channels=4,
+    double_z=True, attn_type="vanilla", embed_dim=4, standalone=True,
+)
+GRAD_KEYS = [
+    "input_blocks.0.0.weight", "out.2.weight", "time_embed.0.weight", "input_blocks.4.1.transformer_blocks.0.attn1.to_q.weight",
+    "input_blocks.4.1.transformer_blocks.0.attn2.to_k.weight", "middle_block.1.transformer_blocks.1.ff.net.0.proj.weight",
+    "output_blocks.2.2.conv.weight", "input_blocks.3.0.op.weight", "output_blocks.8.0.skip_connection.weight", "middle_block.0.in_layers.0.weight",
+    "input_blocks.7.1.norm.bias", "output_blocks.5.1.transformer_blocks.0.norm2.weight", "label_emb.0.2.bias",
+]
+
+
+def unet_case(nd, cfg: dict, name: str, B: int, HW: int, with_y: bool):
+    torch.manual_seed(0)
+    net = nd.UNetModel(**cfg).eval()
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synth_state_dict(shapes))
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 4, HW, HW, generator=g)
+    noise = torch.randn(B, 4, HW, HW, generator=g)
+    ctx = torch.randn(B, 7, cfg["context_dim"], generator=g)
+    y = torch.randn(B, cfg["adm_in_channels"], generator=g) if with_y else None
+    sigma = torch.tensor([0.35, 2.7, 9.1, 0.05][:B])
+
+    # the reference's own loss / denoiser stack with injected sigma (fresh denoiser per step)
+    denoiser = nd.DiscreteDenoiser(preconditioning=nd.EpsPreconditioning(), num_idx=1000, discretization=nd.LegacyDDPMDiscretization())
+    table = denoiser.sigmas.detach().clone()
+    wrapper = nd.OpenAIWrapper(net)
+    cond = {"crossattn": ctx}
+    if with_y:
+        cond["vector"] = y
+    z_t = x + sigma[:, None, None, None] * noise
+    d_out = denoiser(wrapper, z_t, sigma, cond, "D")
+    weight = nd.EpsWeighting()(sigma)
+    loss = ((d_out.float() - x.float()) ** 2).flatten(1).mean(1) * weight.float()  # BatchMSELoss(mean) * w, loss.py:153-157
+    loss.mean().backward()
+    idx = denoiser.sigma_to_idx(denoiser.possibly_quantize_sigma(sigma))
+    with torch.no_grad():
+        f_out = net(z_t * (1.0 / (table[idx] ** 2 + 1.0) ** 0.5)[:, None, None, None], idx, ctx, y)
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if k in GRAD_KEYS}
+    gnorm = {k: float(p.grad.norm()) for k, p in net.named_parameters()}
+    fixture = dict(cfg=cfg, x=x, noise=noise, context=ctx, y=y, sigma=sigma, sigma_table=table, c_noise_idx=idx, z_t=z_t.detach(), F_out=f_out,
+                   D_out=d_out.detach(), loss=loss.detach(), grads=grads, grad_norms=gnorm)
+    torch.save(fixture, HERE / f"{name}.pt")
+    (HERE / f"{name}_keys.json").write_text(json.dumps(shapes, indent=0))
+    print(f"{name}: loss={loss.tolist()} params={sum(int(torch.tensor(s).prod()) for s in shapes.values())}")
+
+
+def vae_case(nmodel):
+    enc = nmodel.Encoder(**VAE_TINY).eval()
+    shapes = {k: list(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(synth_state_dict(shapes))
+    g = torch.Generator().manual_seed(99)
+    img = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    with torch.no_grad():
+        z = enc(img, regularize=True)
+        moments = enc(img, regularize=False)
+    torch.save(dict(cfg=VAE_TINY, image=img, z=z, moments=moments), HERE / "vae_encoder_tiny.pt")
+    (HERE / "vae_encoder_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
+    print("vae: z", tuple(z.shape), float(z.abs().mean()))
+
+
+def op_cases(nd):
+    """Small known-answer vectors for the scalar glue: timestep embedding and the sigma table."""
+    from neurosis.modules.diffusion.util import timestep_embedding
+
+    t = torch.tensor([0, 1, 17, 500, 999])
+    emb = timestep_embedding(t, 320)
+    disc = nd.LegacyDDPMDiscretization()
+    table = disc(1000, do_append_zero=False, flip=False).detach()
+    torch.save(dict(t=t, emb320=emb, ddpm_table=table), HERE / "glue_vectors.pt")
+    print("glue: table", table.shape, float(table[0]), float(table[-2]), float(table[-1]))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    nd, nmodel = import_reference()
+    unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
+    unet_case(nd, UNET_SD15_TINY, "unet_sd15_tiny", B=2, HW=16, with_y=False)
+    vae_case(nmodel)
+    op_cases(nd)

@@ -1,0 +1,72 @@
+"""Host-side (CPU) checks of the drop-in boundary: module trees, state_dict keys and shapes, sigma tables
+and denoiser coefficients, against fixtures captured from the reference."""
+import json
+from pathlib import Path
+
+import pytest
+import torch
+
+import neurosis_amd.modules.diffusion as D
+from tests.golden.make_golden import UNET_SD15_TINY, UNET_TINY, VAE_TINY, synth_state_dict
+
+G = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.mark.parametrize("name,cfg,cls", [("unet_sdxl_tiny", UNET_TINY, "UNetModel"), ("unet_sd15_tiny", UNET_SD15_TINY, "UNetModel"), ("vae_encoder_tiny", VAE_TINY, "Encoder")])
+def test_state_dict_keys_and_shapes_match_reference(name, cfg, cls):
+    ref = json.loads((G / f"{name}_keys.json").read_text())
+    mod = getattr(D, cls)(**cfg)
+    mine = {k: list(v.shape) for k, v in mod.state_dict().items()}
+    assert list(mine.keys()) == list(ref.keys())
+    assert mine == ref
+    mod.load_state_dict(synth_state_dict(ref))  # strict
+
+
+def test_full_size_sdxl_topology_on_meta():
+    cfg = dict(adm_in_channels=2816, num_classes="sequential", use_checkpoint=True, in_channels=4, out_channels=4, model_channels=320,
+               attention_resolutions=[4, 2], num_res_blocks=2, channel_mult=[1, 2, 4], num_head_channels=64, use_linear_in_transformer=True,
+               transformer_depth=[1, 2, 10], context_dim=2048, spatial_transformer_attn_type="softmax-xformers")
+    with torch.device("meta"):
+        net = D.UNetModel(**cfg)
+    n = sum(p.numel() for p in net.parameters())
+    assert n == 2_567_463_684, n  # SDXL-base UNet (SURVEY: 2 567.5 M)
+    from neurosis_amd.modules.attention import BasicTransformerBlock
+
+    assert sum(isinstance(m, BasicTransformerBlock) for m in net.modules()) == 70
+
+
+def test_sigma_table_and_denoiser_coefficients():
+    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization())
+    assert torch.equal(den.sigmas, fx["sigma_table"])  # 1001 entries, trailing 0.0 (quirk Q1)
+    assert not den.sigmas.requires_grad  # detached (quirk Q5)
+    c_skip, c_out, c_in, c_noise = den.coefficients(fx["sigma"])
+    assert torch.equal(c_noise, fx["c_noise_idx"])
+    sq = den.sigmas[c_noise]
+    assert torch.allclose(c_out, -sq) and torch.allclose(c_in, 1 / (sq**2 + 1) ** 0.5) and torch.equal(c_skip, torch.ones_like(sq))
+    assert torch.allclose(D.EpsWeighting()(fx["sigma"]), fx["sigma"] ** -2.0)
+
+
+def test_errors_match_reference():
+    net = D.UNetModel(in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[], channel_mult=[1], num_heads=1)
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 4, 8, 8), torch.zeros(1), None, y=torch.zeros(1, 4))  # y for a non-class-conditional model
+    from neurosis_amd.modules.attention import BasicTransformerBlock
+
+    with pytest.raises(ValueError):
+        BasicTransformerBlock(32, 2, 16, attn_mode="nope")
+
+
+def test_product_path_never_imports_the_oracle():
+    import ast
+
+    root = Path(__file__).resolve().parent.parent / "neurosis_amd"
+    for f in root.rglob("*.py"):
+        tree = ast.parse(f.read_text())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom) and node.module:
+                names = [node.module]
+            assert not any(n.split(".")[0] == "oracle" for n in names), f"{f} imports the oracle"
