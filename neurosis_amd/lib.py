@@ -9,6 +9,9 @@ import ctypes as C
 import os
 from pathlib import Path
 
+import torch  # noqa: F401  -- must come first: PyTorch-ROCm bundles the HIP runtime (libamdhip64) this library binds to;
+# loading libneurosis_hip.so before torch would pull in /opt/rocm's copy and leave two runtimes in one process
+
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libneurosis_hip.so"
 

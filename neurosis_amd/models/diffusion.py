@@ -1,0 +1,108 @@
+"""DiffusionEngine: the training-step slice of neurosis.models.diffusion.DiffusionEngine
+(/root/reference/src/neurosis/models/diffusion.py:35-233) without Lightning.
+
+What is mirrored: the constructor's model wiring (OpenAIWrapper around the UNet, the VAE dismantled into
+`vae_encoder` with its quant_conv, models/diffusion.py:73,146-164), get_input, encode_first_stage, forward and
+training_step, and the `model.diffusion_model.*` / `vae_encoder.*` state_dict prefixes.  What replaces
+Lightning: `training_step` returns loss.mean() exactly as the reference does; `optimizer_step` and the
+data-parallel exchange are explicit methods because there is no Trainer (bench.py and the tests drive them).
+Hooks, EMA, samplers, logging and checkpoint IO are outside SURVEY section 8(a).
+"""
+from __future__ import annotations
+
+from math import ceil
+from typing import Callable, Optional
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+from ..modules.diffusion import Denoiser, DiffusionLoss, OpenAIWrapper, UNetModel
+from ..nn import FlatParamStore
+from .autoencoder import AutoencoderKL
+
+
+class PrecomputedConditioner(nn.Module):
+    """Stand-in for GeneralConditioner (modules/encoders/embedding.py:90-149, frozen text encoders: out of scope):
+    returns the conditioning tensors the batch already carries."""
+
+    def forward(self, batch: dict) -> dict:
+        out = {}
+        for k in ("crossattn", "vector", "concat"):
+            if k in batch and batch[k] is not None:
+                out[k] = batch[k]
+        return out
+
+
+class DiffusionEngine(nn.Module):
+    def __init__(self, model: UNetModel, denoiser: Denoiser, first_stage_model: Optional[AutoencoderKL], conditioner: Optional[nn.Module] = None,
+                 sampler=None, optimizer=None, scheduler=None, loss_fn: Optional[DiffusionLoss] = None, ckpt_path=None, use_ema: bool = False,
+                 scale_factor: float = 1.0, disable_first_stage_autocast: bool = False, input_key: str = "jpg", vae_batch_size: Optional[int] = None,
+                 log_sigmas: bool = False, **kwargs):
+        super().__init__()
+        if use_ema:
+            raise NotImplementedError("EMA is outside the hot path (use_ema: false in the reference configs)")
+        self.input_key = input_key
+        self.model = OpenAIWrapper(model)
+        self.denoiser = denoiser
+        self.conditioner = conditioner if conditioner is not None else PrecomputedConditioner()
+        self.loss_fn = loss_fn
+        self.scale_factor = scale_factor
+        self.vae_batch_size = vae_batch_size
+        self.log_sigmas = log_sigmas
+        self.vae_encoder = None
+        if first_stage_model is not None:
+            self._init_first_stage(first_stage_model)
+        self.global_step = 0
+        self.store: Optional[FlatParamStore] = None
+        self.last_log: dict = {}
+
+    def _init_first_stage(self, model: AutoencoderKL) -> None:
+        """models/diffusion.py:146-164: keep the encoder, move quant_conv onto it (the reference needs
+        ddconfig.standalone=true for this not to crash; here it always works)."""
+        model = model.eval()
+        model.freeze()
+        enc = model.encoder
+        enc.quant_conv = model.quant_conv
+        enc.standalone = True
+        self.vae_encoder = enc
+
+    def setup_flat_params(self) -> FlatParamStore:
+        """Re-home the trainable UNet parameters into the flat fp32/bf16/grad buffers (call after .cuda())."""
+        self.store = FlatParamStore([p for p in self.model.diffusion_model.parameters() if p.requires_grad])
+        return self.store
+
+    def get_input(self, batch: dict) -> Tensor:
+        inputs = batch[self.input_key]
+        if inputs.ndim == 3:
+            inputs = inputs.unsqueeze(0)
+        return inputs
+
+    @torch.no_grad()
+    def encode_first_stage(self, x: Tensor) -> Tensor:
+        """models/diffusion.py:186-197."""
+        n_samples = self.vae_batch_size or x.shape[0]
+        outs = [self.vae_encoder(x[n * n_samples:(n + 1) * n_samples], regularize=True) for n in range(ceil(x.shape[0] / n_samples))]
+        z = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        return self.scale_factor * z
+
+    def forward(self, x: Tensor, batch: dict, return_dict: bool = False, **inject):
+        cond = self.conditioner(batch)
+        return self.loss_fn._forward(self.model, self.denoiser, cond, x, batch, return_dict, **inject)
+
+    def training_step(self, batch: dict, batch_idx: int = 0, **inject) -> Tensor:
+        """models/diffusion.py:205-233.  `inject` may carry sigmas= / noise=."""
+        inputs = self.get_input(batch)
+        latents = self.encode_first_stage(inputs)
+        batch["global_step"] = self.global_step
+        loss = self(latents, batch, return_dict=False, **inject)
+        self.last_log = {"train/loss": loss.detach().mean(), "train/loss_s0": loss.detach()[0]}
+        return loss.mean()
+
+    def optimizer_step(self, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
+        """Fused flat AdamW (one kernel over masters, moments and bf16 shadows), then clears the gradients."""
+        if self.store is None:
+            raise RuntimeError("call setup_flat_params() first")
+        self.store.adamw_step(lr, betas, eps, weight_decay, grad_scale)
+        self.store.zero_grad()
+        self.global_step += 1
