@@ -37,7 +37,7 @@ int nk_linear_fwd(const void* x, const void* w, const float* bias, const void* r
 /* dx[M,K] = dy[M,N] @ w[N,K] + dx_add[M,K]                          (dx_add optional) */
 int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add, void* dx, int M, int N, int K,
                     long lddy, long ldw, long ldadd, long lddx, void* stream);
-/* dw[N,K] (+)= dy[M,N]^T @ x[M,K]   fp32 */
+/* dw[N,K] (+)= dy[M,N]^T @ x[M,K]   fp32.  accumulate: 0 overwrite, 1 add, 2 destination is known to be all zero */
 int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy, long ldx,
                     long lddw, int accumulate, void* stream);
 
@@ -88,20 +88,23 @@ int nk_softmax_rows(void* s, long M, int L, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32, C) (+ fused SiLU) on channels-last x [N][HW][C]
  * (openaimodel.py:247-250,281-283,797-799; attention.py:612 with eps 1e-6, no SiLU; layers.py:5-7 Normalize).
- * mean/rstd: [N][G] fp32 (saved for backward).  stats_ws / gsum_ws: fp32 workspace [N][G][2].
+ * mean/rstd: [N][G] fp32 (saved for backward).  ws: uninitialised fp32 workspace of nk_groupnorm_ws_floats elements
+ * (statistics are reduced through per-block partials, not atomics: deterministic, no memset).
  * Backward adds into dgamma/dbeta (fp32) and optionally adds dx_add into dx.
  * ---------------------------------------------------------------------------------------------- */
+long nk_groupnorm_ws_floats(int N, int HW, int C, int G); /* fp32 elements of `ws` (per-block partial sums) */
 int nk_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                     float* stats_ws, int N, int HW, int C, int G, float eps, int silu, void* stream);
+                     float* ws, int N, int HW, int C, int G, float eps, int silu, void* stream);
 int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
-                     const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* gsum_ws,
+                     const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
                      int N, int HW, int C, int G, int silu, void* stream);
 
 /* nn.LayerNorm(C) over rows of [M][C] (attention.py:468-470).  mean/rstd: [M] fp32. */
 int nk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      int M, int C, float eps, void* stream);
+long nk_layernorm_ws_floats(int M, int C);
 int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                     const void* dx_add, void* dx, float* dgamma, float* dbeta, int M, int C, void* stream);
+                     const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C, void* stream);
 
 /* GEGLU (attention.py:55-57): y[M][I] = u[:, :I] * gelu_erf(u[:, I:]) */
 int nk_geglu_fwd(const void* u, void* y, long M, int I, void* stream);
@@ -130,7 +133,8 @@ int nk_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 int nk_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 
 /* bias gradient: out[N] (+)= sum over rows of dy[M][N] (row stride ld) */
-int nk_colsum(const void* dy, float* out, long M, int N, long ld, int accumulate, void* stream);
+long nk_colsum_ws_floats(long M, int N);
+int nk_colsum(const void* dy, float* out, float* ws, long M, int N, long ld, int accumulate, void* stream);
 
 /* timestep_embedding (modules/diffusion/util.py:152-177): out[B][dim] bf16 = [cos | sin](t * freq) */
 int nk_timestep_embedding(const float* t, void* out, int B, int dim, float max_period, void* stream);

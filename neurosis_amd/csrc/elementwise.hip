@@ -276,15 +276,14 @@ extern "C" int nk_cast_bf16_to_f32(const void* src, float* dst, long n, void* st
 }
 
 // ---- bias gradient: out[n] (+)= sum_m dy[m][n] ---------------------------------------------------
-__global__ void colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ out, long M, int N, long ld,
-                              int rows_per) {
-  extern __shared__ float ls[];  // [N] slab sums
+// stage 1: per-block partial column sums part[split][N] (no atomics); stage 2: single-writer reduce over splits
+__global__ void colsum_partial_kernel(const bf16_t* __restrict__ dy, float* __restrict__ part, long M, int N, long ld,
+                                      int rows_per) {
+  __shared__ float ps[EW_THREADS * 8];  // per-thread partials, combined in a fixed order (bitwise reproducible)
   const int cpr = (N >> 3) / gridDim.y;
   const int ch0 = blockIdx.y * cpr;
   const int rows_par = EW_THREADS / cpr;
   const int tid = threadIdx.x;
-  for (int c = tid; c < cpr * 8; c += EW_THREADS) ls[c] = 0.f;
-  __syncthreads();
   const int chunk = tid % cpr, rsub = tid / cpr;
   const long row_lo = (long)blockIdx.x * rows_per;
   const long row_hi = row_lo + rows_per < M ? row_lo + rows_per : M;
@@ -299,23 +298,53 @@ __global__ void colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__
       for (int e = 0; e < 8; ++e) s[e] += f[e];
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&ls[chunk * 8 + e], s[e]);
+    for (int e = 0; e < 8; ++e) ps[(rsub * cpr + chunk) * 8 + e] = s[e];
   }
   __syncthreads();
-  for (int c = tid; c < cpr * 8; c += EW_THREADS) unsafeAtomicAdd(&out[ch0 * 8 + c], ls[c]);
+  for (int c = tid; c < cpr * 8; c += EW_THREADS) {
+    float a = 0.f;
+    for (int r = 0; r < rows_par; ++r) a += ps[r * cpr * 8 + c];
+    part[(long)blockIdx.x * N + ch0 * 8 + c] = a;
+  }
 }
-extern "C" int nk_colsum(const void* dy, float* out, long M, int N, long ld, int accumulate, void* stream_) {
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                             int nsplit, int N, int accumulate) {
+  __shared__ float sa[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float a = 0.f;
+  if (c < N)
+    for (int r = ty; r < nsplit; r += 16) a += part[(long)r * N + c];
+  sa[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && c < N) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) a += sa[j][tx];
+    out[c] = accumulate ? out[c] + a : a;
+  }
+}
+static int colsum_split(long M, int* rows_per) {
+  int rp = (int)((M + 255) / 256);
+  if (rp < 16) rp = 16;
+  *rows_per = rp;
+  return (int)((M + rp - 1) / rp);
+}
+extern "C" long nk_colsum_ws_floats(long M, int N) {
+  int rp;
+  return (long)colsum_split(M, &rp) * N + 64;
+}
+extern "C" int nk_colsum(const void* dy, float* out, float* ws, long M, int N, long ld, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  NK_CHECK_ARG(dy && out && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0);
-  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * N, stream) != hipSuccess) return NK_ERR_LAUNCH;
+  NK_CHECK_ARG(dy && out && ws && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0);
   int cpr = N >> 3, nz = (cpr + EW_THREADS - 1) / EW_THREADS;
   while (cpr % nz) ++nz;
-  int rows_per = (int)((M + 511) / 512);
-  if (rows_per < 16) rows_per = 16;
-  int nsplit = (int)((M + rows_per - 1) / rows_per);
-  hipLaunchKernelGGL(colsum_kernel, dim3(nsplit, nz), dim3(EW_THREADS), (cpr / nz) * 8 * sizeof(float), stream,
-                     (const bf16_t*)dy, out, M, N, ld, rows_per);
-  return nk_check_launch("colsum");
+  int rows_per;
+  int nsplit = colsum_split(M, &rows_per);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nsplit, nz), dim3(EW_THREADS), 0, stream,
+                     (const bf16_t*)dy, ws, M, N, ld, rows_per);
+  if (int e = nk_check_launch("colsum_partial")) return e;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, ws, out, nsplit, N, accumulate);
+  return nk_check_launch("colsum_reduce");
 }
 
 // ---- sinusoidal timestep embedding (modules/diffusion/util.py:152-177): [cos | sin] -------------

@@ -427,11 +427,15 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   int splitk = 1;
   if (out_f32 && allow_splitk) splitk = pick_splitk(p.M, p.N, p.K, 32);
   set_split(p, splitk);
-  if (out_f32 && splitk > 1 && !p.accumulate) {
+  // accumulate: 0 = overwrite, 1 = add, 2 = the destination is known to be zero (flat gradient buffer right after
+  // zero_grad): plain stores when there is a single K split, atomics otherwise -- and no memset either way
+  if (out_f32 && splitk > 1 && p.accumulate == 0) {
     // split-K partials are summed with fp32 atomics, which need a zeroed destination
     NK_CHECK_ARG(p.ldc == p.N);
     if (hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess) return NK_ERR_LAUNCH;
     p.accumulate = 1;
+  } else if (p.accumulate == 2) {
+    p.accumulate = splitk > 1 ? 1 : 0;
   }
 
 #define NK_CASE(A_, B_)                                                          \

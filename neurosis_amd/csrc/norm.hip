@@ -17,23 +17,23 @@
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats,
                                                               int HW, int C, int G, int rows_per) {
-  __shared__ float gs[64 * 2];
+  // thread (rsub, chunk) accumulates 8 channels over its rows; partials are combined in a FIXED order
+  // (LDS staging, no atomics) so the statistics -- and therefore the forward -- are bitwise reproducible
+  __shared__ float ps[GN_THREADS * 8], pss[GN_THREADS * 8];
   const int n = blockIdx.y;
   const int cpr = (C >> 3) / gridDim.z;        // 16-byte chunks per row in this block's channel slab
   const int ch0 = blockIdx.z * cpr;            // first chunk of the slab
   const int rows_par = GN_THREADS / cpr;       // rows processed in parallel by the block
   const int tid = threadIdx.x;
   const int cpg = C / G;
-  for (int i = tid; i < 2 * G; i += GN_THREADS) gs[i] = 0.f;
-  __syncthreads();
   const int row_lo = blockIdx.x * rows_per;
   const int row_hi = min(HW, row_lo + rows_per);
   float s[8], ss[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-  const int chunk = ch0 + tid % cpr, rsub = tid / cpr;
+  const int chunk = tid % cpr, rsub = tid / cpr;
   if (rsub < rows_par) {
-    const bf16_t* base = x + ((long)n * HW) * C + chunk * 8;
+    const bf16_t* base = x + ((long)n * HW) * C + (ch0 + chunk) * 8;
     for (int r = row_lo + rsub; r < row_hi; r += rows_par) {
       float f[8];
       unpack8(*(const uint4_t*)(base + (long)r * C), f);
@@ -42,13 +42,32 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      int g = (chunk * 8 + e) / cpg;
-      atomicAdd(&gs[2 * g], s[e]);
-      atomicAdd(&gs[2 * g + 1], ss[e]);
+      ps[(rsub * cpr + chunk) * 8 + e] = s[e];
+      pss[(rsub * cpr + chunk) * 8 + e] = ss[e];
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * G; i += GN_THREADS) unsafeAtomicAdd(&stats[(long)n * 2 * G + i], gs[i]);
+  // per-block partial: part[n][blockIdx.x * gridDim.z + blockIdx.z][2G]; groups outside this slab get 0
+  float* part = stats + (((long)n * gridDim.x + blockIdx.x) * gridDim.z + blockIdx.z) * 2 * G;
+  for (int i = tid; i < 2 * G; i += GN_THREADS) {
+    const int g = i >> 1;
+    const float* src = (i & 1) ? pss : ps;
+    const int c_lo = max(g * cpg, ch0 * 8), c_hi = min((g + 1) * cpg, (ch0 + cpr) * 8);
+    float a = 0.f;
+    for (int c = c_lo; c < c_hi; ++c)
+      for (int r = 0; r < rows_par; ++r) a += src[r * cpr * 8 + (c - ch0 * 8)];
+    part[i] = a;
+  }
+}
+
+// sums the per-block partials of one image: out[n][2G] = sum_p part[n][p][2G]
+__global__ void gn_reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int G2) {
+  const int n = blockIdx.x;
+  for (int i = threadIdx.x; i < G2; i += blockDim.x) {
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += part[((long)n * nparts + p) * G2 + i];
+    out[(long)n * G2 + i] = a;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -108,36 +127,32 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 __global__ __launch_bounds__(GN_THREADS) void gn_bwd_stats_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                  float* __restrict__ gsum, float* __restrict__ dgamma,
-                                                                  float* __restrict__ dbeta, int HW, int C, int G, int silu,
-                                                                  int rows_per) {
+                                                                  float* __restrict__ gsum, float* __restrict__ chan_part,
+                                                                  int HW, int C, int G, int silu, int rows_per) {
+  __shared__ float pa[GN_THREADS * 8], pb[GN_THREADS * 8];   // per-thread partials, combined in a fixed order
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* ca = (float*)smem_raw;   // [C]
-  float* cb = ca + C;             // [C]
-  float* gs = cb + C;             // [2G]
+  float* ca = (float*)smem_raw;   // [slab channels] sum dz
+  float* cb = ca + C;             // [slab channels] sum dz*xhat
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
   const int cpg = C / G;
   const int cpr = (C >> 3) / gridDim.z;
   const int ch0 = blockIdx.z * cpr;
   const int rows_par = GN_THREADS / cpr;
-  for (int c = tid; c < C; c += GN_THREADS) { ca[c] = 0.f; cb[c] = 0.f; }
-  for (int i = tid; i < 2 * G; i += GN_THREADS) gs[i] = 0.f;
-  __syncthreads();
   const int row_lo = blockIdx.x * rows_per;
   const int row_hi = min(HW, row_lo + rows_per);
-  const int chunk = ch0 + tid % cpr, rsub = tid / cpr;
+  const int chunk = tid % cpr, rsub = tid / cpr;
   if (rsub < rows_par) {
     float a[8], b[8], mu[8], rs[8], ga[8], be[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      int c = chunk * 8 + e;
+      int c = (ch0 + chunk) * 8 + e;
       int g = c / cpg;
       a[e] = 0.f; b[e] = 0.f;
       mu[e] = mean[n * G + g]; rs[e] = rstd[n * G + g];
       ga[e] = gamma[c]; be[e] = beta[c];
     }
-    const long base = ((long)n * HW) * C + chunk * 8;
+    const long base = ((long)n * HW) * C + (ch0 + chunk) * 8;
     for (int r = row_lo + rsub; r < row_hi; r += rows_par) {
       float fx[8], fd[8];
       unpack8(*(const uint4_t*)(x + base + (long)r * C), fx);
@@ -153,21 +168,57 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_stats_kernel(const bf16_t* 
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      atomicAdd(&ca[chunk * 8 + e], a[e]);
-      atomicAdd(&cb[chunk * 8 + e], b[e]);
+      pa[(rsub * cpr + chunk) * 8 + e] = a[e];
+      pb[(rsub * cpr + chunk) * 8 + e] = b[e];
     }
   }
   __syncthreads();
-  for (int c = ch0 * 8 + tid; c < (ch0 + cpr) * 8; c += GN_THREADS) {
-    int g = c / cpg;
-    float av = ca[c], bv = cb[c], gm = gamma[c];
-    atomicAdd(&gs[2 * g], gm * av);
-    atomicAdd(&gs[2 * g + 1], gm * bv);
-    unsafeAtomicAdd(&dbeta[c], av);
-    unsafeAtomicAdd(&dgamma[c], bv);
+  // per channel of the slab: combine the rows_par partials; write channel partials for dgamma / dbeta
+  float* cp = chan_part + ((long)n * gridDim.x + blockIdx.x) * 2 * C;
+  for (int cl = tid; cl < cpr * 8; cl += GN_THREADS) {
+    float av = 0.f, bv = 0.f;
+    for (int r = 0; r < rows_par; ++r) { av += pa[r * cpr * 8 + cl]; bv += pb[r * cpr * 8 + cl]; }
+    const int c = ch0 * 8 + cl;
+    ca[cl] = av;
+    cb[cl] = bv;
+    cp[c] = bv;        // dgamma partial
+    cp[C + c] = av;    // dbeta partial
   }
   __syncthreads();
-  for (int i = tid; i < 2 * G; i += GN_THREADS) unsafeAtomicAdd(&gsum[(long)n * 2 * G + i], gs[i]);
+  float* part = gsum + (((long)n * gridDim.x + blockIdx.x) * gridDim.z + blockIdx.z) * 2 * G;
+  for (int i = tid; i < 2 * G; i += GN_THREADS) {
+    const int g = i >> 1;
+    const float* src = (i & 1) ? cb : ca;
+    const int c_lo = max(g * cpg, ch0 * 8), c_hi = min((g + 1) * cpg, (ch0 + cpr) * 8);
+    float acc = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) acc += gamma[c] * src[c - ch0 * 8];
+    part[i] = acc;
+  }
+}
+
+// dgamma[c] += sum_rows part[row][0][c] ; dbeta[c] += sum_rows part[row][1][c]
+// block = 64 channels x 16 row groups (1024 threads); single writer per channel, so no atomics
+__global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int nrows, int C) {
+  __shared__ float sa[16][64], sb[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+    for (int r = ty; r < nrows; r += 16) {
+      a += part[(long)r * 2 * C + c];
+      b += part[(long)r * 2 * C + C + c];
+    }
+  }
+  sa[ty][tx] = a;
+  sb[ty][tx] = b;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) { a += sa[j][tx]; b += sb[j][tx]; }
+    dgamma[c] += a;
+    dbeta[c] += b;
+  }
 }
 
 // GroupNorm backward, pass 2: dx = rstd * (dz*gamma - (s1 + xhat*s2)/cnt) (+ dx_add)
@@ -232,47 +283,66 @@ static int gn_nz(int C) {
 
 static int gn_rows_per(int N, int HW, int* nsplit) {
   // aim for ~2048 blocks in total
-  int want = (2048 + N - 1) / N;
+  int want = (1024 + N - 1) / N;
   int rows_per = (HW + want - 1) / want;
-  if (rows_per < 8) rows_per = 8;
+  if (rows_per < 32) rows_per = 32;
   *nsplit = (HW + rows_per - 1) / rows_per;
   return rows_per;
 }
 
+extern "C" long nk_groupnorm_ws_floats(int N, int HW, int C, int G) {
+  // fp32 elements of workspace nk_groupnorm_fwd / nk_groupnorm_bwd need (per-block partial sums)
+  int nsplit;
+  gn_rows_per(N, HW, &nsplit);
+  long parts = (long)N * nsplit * gn_nz(C) * 2 * G;   // group partials
+  long chan = (long)N * nsplit * 2 * C;                // channel partials (backward)
+  return parts + chan + (long)N * 2 * G + 64;
+}
+
 extern "C" int nk_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                float* rstd, float* stats_ws, int N, int HW, int C, int G, float eps, int silu,
+                                float* rstd, float* ws, int N, int HW, int C, int G, float eps, int silu,
                                 void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(N > 0 && HW > 0 && C > 0 && G > 0 && G <= 64);
   NK_CHECK_ARG((C & 7) == 0 && C % G == 0 && C <= GN_MAXC);
-  NK_CHECK_ARG(x && gamma && beta && y && mean && rstd && stats_ws);
+  NK_CHECK_ARG(x && gamma && beta && y && mean && rstd && ws);
   int nsplit;
   int rows_per = gn_rows_per(N, HW, &nsplit);
-  if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * G * N, stream) != hipSuccess) return NK_ERR_LAUNCH;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, N, gn_nz(C)), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, stats_ws, HW, C,
+  const int nz = gn_nz(C);
+  float* part = ws;
+  float* stats = ws + (long)N * nsplit * nz * 2 * G;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, N, nz), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, part, HW, C,
                      G, rows_per);
   if (int e = nk_check_launch("gn_stats_kernel")) return e;
+  hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(64), 0, stream, part, stats, nsplit * nz, 2 * G);
+  if (int e = nk_check_launch("gn_reduce_partials_kernel")) return e;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, N), dim3(GN_THREADS), 2 * C * sizeof(float), stream,
-                     (const bf16_t*)x, stats_ws, gamma, beta, (bf16_t*)y, mean, rstd, HW, C, G, eps, silu, rows_per);
+                     (const bf16_t*)x, stats, gamma, beta, (bf16_t*)y, mean, rstd, HW, C, G, eps, silu, rows_per);
   return nk_check_launch("gn_apply_kernel");
 }
 
 extern "C" int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                                 const float* mean, const float* rstd, const void* dx_add, void* dx, float* dgamma,
-                                float* dbeta, float* gsum_ws, int N, int HW, int C, int G, int silu, void* stream_) {
+                                float* dbeta, float* ws, int N, int HW, int C, int G, int silu, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(N > 0 && HW > 0 && C > 0 && G > 0 && G <= 64);
   NK_CHECK_ARG((C & 7) == 0 && C % G == 0 && C <= GN_MAXC);
-  NK_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && gsum_ws);
+  NK_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && ws);
   int nsplit;
   int rows_per = gn_rows_per(N, HW, &nsplit);
-  if (hipMemsetAsync(gsum_ws, 0, sizeof(float) * 2 * G * N, stream) != hipSuccess) return NK_ERR_LAUNCH;
-  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nsplit, N, gn_nz(C)), dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), stream,
-                     (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, gsum_ws, dgamma, dbeta, HW, C, G,
-                     silu, rows_per);
+  const int nz = gn_nz(C);
+  float* part = ws;
+  float* gsum = part + (long)N * nsplit * nz * 2 * G;
+  float* chan = gsum + (long)N * 2 * G;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nsplit, N, nz), dim3(GN_THREADS), 2 * C * sizeof(float), stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, part, chan, HW, C, G, silu, rows_per);
   if (int e = nk_check_launch("gn_bwd_stats_kernel")) return e;
+  hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(64), 0, stream, part, gsum, nsplit * nz, 2 * G);
+  if (int e = nk_check_launch("gn_reduce_partials_kernel")) return e;
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, chan, dgamma, dbeta, N * nsplit, C);
+  if (int e = nk_check_launch("colpart_reduce_kernel")) return e;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nsplit, N), dim3(GN_THREADS), 6 * C * sizeof(float), stream,
-                     (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, gsum_ws, (const bf16_t*)dx_add,
+                     (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, gsum, (const bf16_t*)dx_add,
                      (bf16_t*)dx, HW, C, G, silu, rows_per);
   return nk_check_launch("gn_bwd_apply_kernel");
 }
@@ -333,18 +403,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
-                                                     bf16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int C) {
+                                                     bf16_t* __restrict__ dx, float* __restrict__ dgamma /* partial ws */,
+                                                     int M, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* lg = (float*)smem_raw;   // [C]
-  float* lb = lg + C;             // [C]
+  float* lg = (float*)smem_raw;   // [4 waves][C]
+  float* lb = lg + 4 * C;         // [4 waves][C]
   const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int cpr = C >> 3;
   const float invC = 1.0f / (float)C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) { lg[c] = 0.f; lb[c] = 0.f; }
-  __syncthreads();
   float ag[LN_MAXCH][8], ab[LN_MAXCH][8], gm[LN_MAXCH][8];
 #pragma unroll
   for (int j = 0; j < LN_MAXCH; ++j) {
@@ -403,15 +472,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     if (ch < cpr) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        atomicAdd(&lg[ch * 8 + e], ag[j][e]);
-        atomicAdd(&lb[ch * 8 + e], ab[j][e]);
+        lg[wv * C + ch * 8 + e] = ag[j][e];
+        lb[wv * C + ch * 8 + e] = ab[j][e];
       }
     }
   }
   __syncthreads();
+  // per-block partials part[blockIdx.x][2][C] (waves combined in a fixed order); reduced by colpart_reduce_kernel
+  float* part = dgamma + (long)blockIdx.x * 2 * C;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    unsafeAtomicAdd(&dgamma[c], lg[c]);
-    unsafeAtomicAdd(&dbeta[c], lb[c]);
+    part[c] = (lg[c] + lg[C + c]) + (lg[2 * C + c] + lg[3 * C + c]);
+    part[C + c] = (lb[c] + lb[C + c]) + (lb[2 * C + c] + lb[3 * C + c]);
   }
 }
 
@@ -425,14 +496,23 @@ extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* 
   return nk_check_launch("ln_fwd_kernel");
 }
 
+static int ln_bwd_blocks(int M) {
+  int b = (M + 15) / 16;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return b;
+}
+extern "C" long nk_layernorm_ws_floats(int M, int C) { return (long)ln_bwd_blocks(M) * 2 * C + 64; }
+
 extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, int M,
-                                int C, void* stream) {
+                                const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
+                                int M, int C, void* stream) {
   NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
-  NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta);
-  int blocks = min((M + 3) / 4, 1024);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma,
-                     dbeta, M, C);
-  return nk_check_launch("ln_bwd_kernel");
+  NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws);
+  int blocks = ln_bwd_blocks(M);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 8 * C * sizeof(float), (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, ws, M, C);
+  if (int e = nk_check_launch("ln_bwd_kernel")) return e;
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, dgamma, dbeta, blocks, C);
+  return nk_check_launch("colpart_reduce_kernel");
 }

@@ -46,7 +46,7 @@ SIGNATURES: dict[str, list] = {
     "nk_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "nk_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "nk_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
-    "nk_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "nk_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "nk_geglu_fwd": [vp, vp, i64, i32, vp],
     "nk_geglu_bwd": [vp, vp, vp, i64, i32, vp],
     "nk_silu_fwd": [vp, vp, i64, vp],
@@ -59,11 +59,18 @@ SIGNATURES: dict[str, list] = {
     "nk_nhwc_to_nchw": [vp, vp, i32, i32, i32, i32, i32, vp],
     "nk_cast_f32_to_bf16": [vp, vp, i64, vp],
     "nk_cast_bf16_to_f32": [vp, vp, i64, vp],
-    "nk_colsum": [vp, vp, i64, i32, i64, i32, vp],
+    "nk_colsum": [vp, vp, vp, i64, i32, i64, i32, vp],
     "nk_timestep_embedding": [vp, vp, i32, i32, f32, vp],
     "nk_edm_prepare": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "nk_edm_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "nk_adamw_flat": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
+}
+
+# entry points that return a size (long) instead of a status
+SIZE_QUERIES: dict[str, list] = {
+    "nk_groupnorm_ws_floats": [i32, i32, i32, i32],
+    "nk_layernorm_ws_floats": [i32, i32],
+    "nk_colsum_ws_floats": [i64, i32],
 }
 
 _lib = None
@@ -93,8 +100,16 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = argtypes
         fn.restype = i32
+    for name, argtypes in SIZE_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = i64
     _lib = lib
     return lib
+
+
+def query(name: str, *args) -> int:
+    return int(getattr(load(), name)(*args))
 
 
 def call(name: str, *args) -> None:

@@ -70,6 +70,9 @@ class DiffusionEngine(nn.Module):
     def setup_flat_params(self) -> FlatParamStore:
         """Re-home the trainable UNet parameters into the flat fp32/bf16/grad buffers (call after .cuda())."""
         self.store = FlatParamStore([p for p in self.model.diffusion_model.parameters() if p.requires_grad])
+        # contract: the flat gradient buffer is all-zero before the first micro-batch of every optimizer step (it is born
+        # zeroed and optimizer_step() re-zeroes it), so weight-gradient kernels may store instead of memset+atomic-add
+        ops.state.assume_zeroed = True
         return self.store
 
     def get_input(self, batch: dict) -> Tensor:

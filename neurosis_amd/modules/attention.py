@@ -102,7 +102,7 @@ class CrossAttention(nn.Module):
         wq, wk, wv = self.to_q.weight, self.to_k.weight, self.to_v.weight
         inner = wq.shape[0]
         self_attn = context is None
-        acc = lambda: ops.state.grad_accumulate
+        acc = ops.wgrad_mode
         if self_attn and adjacent(wq, wk, wv):
             # one projection GEMM: [to_q; to_k; to_v] are back to back in the flat parameter store
             w_qkv = torch.as_strided(ops.shadow(wq), (3 * inner, wq.shape[1]), (wq.shape[1], 1))

@@ -20,17 +20,29 @@ import torch
 from torch import Tensor
 
 from . import lib
-from .lib import NkAttnDesc, NkConvDesc, call
+from .lib import NkAttnDesc, NkConvDesc, call, query
 
 BF16 = torch.bfloat16
 
 
 class _State:
     grad_accumulate = False  # False: weight-grad kernels overwrite; True: they add (micro-batch accumulation)
+    assume_zeroed = False  # True: .grad buffers are all-zero before the first micro-batch (engine zeroes after each step)
     param_epoch = 0  # bumped whenever fp32 masters change (optimizer step / load_state_dict)
 
 
 state = _State()
+
+
+def wgrad_mode() -> int:
+    """accumulate argument of the weight-gradient kernels (see include/neurosis_hip.h)."""
+    if state.grad_accumulate:
+        return 1
+    return 2 if state.assume_zeroed else 0
+
+
+def _ws(n_floats: int, device) -> Tensor:
+    return torch.empty(n_floats, dtype=torch.float32, device=device)
 
 
 def _p(t: Optional[Tensor]):
@@ -218,7 +230,7 @@ def gemm_nn(dy: Tensor, w: Tensor, dx_add: Optional[Tensor] = None, out: Optiona
     return out
 
 
-def gemm_tn_f32(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool) -> None:
+def gemm_tn_f32(dy: Tensor, x: Tensor, dw: Tensor, accumulate) -> None:
     """dw (+)= dy^T @ x ; dy [M,N], x [M,K], dw fp32 [N,K]."""
     _check2d(dy, "dy")
     _check2d(x, "x")
@@ -231,7 +243,9 @@ def gemm_tn_f32(dy: Tensor, x: Tensor, dw: Tensor, accumulate: bool) -> None:
 
 def colsum(dy: Tensor, out: Tensor, accumulate: bool) -> None:
     _check2d(dy, "dy")
-    call("nk_colsum", dy.data_ptr(), out.data_ptr(), dy.shape[0], dy.shape[1], dy.stride(0), int(accumulate), _stream())
+    M, N = dy.shape
+    ws = _ws(query("nk_colsum_ws_floats", M, N), dy.device)
+    call("nk_colsum", dy.data_ptr(), out.data_ptr(), ws.data_ptr(), M, N, dy.stride(0), int(accumulate), _stream())
 
 
 def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor] = None, need_dx: bool = True):
@@ -240,7 +254,7 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
     y = gemm_nt(x, w2d(weight), bias, residual)
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
-        gemm_tn_f32(dy, x, g2d(weight), state.grad_accumulate)
+        gemm_tn_f32(dy, x, g2d(weight), wgrad_mode())
         if bias is not None:
             colsum(dy, grad_flat(bias), True)
         if not need_dx:
@@ -288,7 +302,7 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
         _check2d(dy, "dy")
         if not dy.is_contiguous():
             raise ValueError("conv2d bwd: dy must be dense")
-        call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), int(state.grad_accumulate), _stream())
+        call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(), _stream())
         if bias is not None:
             colsum(dy, grad_flat(bias), True)
         drow = None
@@ -322,13 +336,14 @@ def groupnorm_fwd(x: Img, weight: Tensor, bias: Tensor, groups: int, eps: float,
     y = torch.empty_like(x.t)
     mean = torch.empty(N, groups, dtype=torch.float32, device=x.t.device)
     rstd = torch.empty_like(mean)
-    ws = torch.empty(N, groups, 2, dtype=torch.float32, device=x.t.device)
+    nws = query("nk_groupnorm_ws_floats", N, HW, Cc, groups)
+    ws = _ws(nws, x.t.device)
     call("nk_groupnorm_fwd", x.t.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
          ws.data_ptr(), N, HW, Cc, groups, float(eps), int(silu), _stream())
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
         dx = torch.empty_like(x.t)
-        ws2 = torch.empty(N, groups, 2, dtype=torch.float32, device=dy.device)
+        ws2 = _ws(nws, dy.device)
         call("nk_groupnorm_bwd", dy.data_ptr(), x.t.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
              _p(dx_add), dx.data_ptr(), grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws2.data_ptr(), N, HW, Cc, groups,
              int(silu), _stream())
@@ -350,8 +365,9 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
         dx = torch.empty_like(x)
+        ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
         call("nk_layernorm_bwd", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add), dx.data_ptr(),
-             grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), M, Cc, _stream())
+             grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, _stream())
         return dx
 
     return y, bwd

@@ -25,13 +25,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_table_matches_header():
     syms = set(declared_symbols()) - {"nk_last_error", "nk_abi_version"}
-    assert syms == set(lib.SIGNATURES), (syms ^ set(lib.SIGNATURES))
+    bound = set(lib.SIGNATURES) | set(lib.SIZE_QUERIES)
+    assert syms == bound, (syms ^ bound)
 
 
 def test_argument_counts_match_header():
     text = (ROOT / "include" / "neurosis_hip.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    for name, argtypes in lib.SIGNATURES.items():
+    for name, argtypes in {**lib.SIGNATURES, **lib.SIZE_QUERIES}.items():
         m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
         assert m, name
         n = len([a for a in m.group(1).split(",") if a.strip()])

@@ -8,10 +8,16 @@ def grads(n, s):
     s.zero_grad(); _loss(n, fx).mean().backward(); torch.cuda.synchronize()
     return {k: p.grad.clone() for k, p in n.named_parameters()}
 a = grads(net, st); b = grads(net, st)
-worst = sorted(((rel_err(b[k], a[k]), k) for k in a), reverse=True)[:6]
-print("run-to-run:", worst)
+gmax = max(float(g.abs().max()) for g in a.values())
+def report(x, y, tag):
+    rows = []
+    for k in x:
+        scale = max(float(x[k].abs().max()), 1e-2 * gmax)
+        rows.append((float((y[k]-x[k]).abs().max())/scale, cosine(y[k], x[k]), float(x[k].norm()), k))
+    rows.sort(reverse=True)
+    print(tag, "gmax", gmax)
+    for r in rows[:8]: print("   ", r)
+report(a, b, "run-to-run")
 fx, net2, st2 = _build_unet("unet_sdxl_tiny", True, use_checkpoint=True)
 c = grads(net2, st2)
-worst = sorted(((rel_err(c[k], a[k]), k) for k in a), reverse=True)[:6]
-print("checkpoint vs plain:", worst)
-print("cos time_embed.0.weight", cosine(c["time_embed.0.weight"], a["time_embed.0.weight"]))
+report(a, c, "checkpoint")
