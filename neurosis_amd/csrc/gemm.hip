@@ -24,11 +24,13 @@
 // unfused attention products of the VAE mid block (K10).
 #include "nk_common.h"
 #include "nk_gemm.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
 #define BK 64
 #define NTHREADS 256
+#define GROUP_M 8
 #define KC_IMAGE_BYTES (128 * 128)          // [128 rows][64 k] bf16
 #define MC_ROW_BYTES (128 * 2 + 16)         // [64 k][128 r] bf16, rows padded by 16 B
 #define MC_IMAGE_BYTES (BK * MC_ROW_BYTES)  // 17408
@@ -228,75 +230,9 @@ struct Operand {
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
-template <int AMODE, int BMODE, int OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_kernel(const NkGemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware bijective remap: blocks that share an XCD (bid % 8) get a contiguous tile range
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ntn = (p.N + BN - 1) / BN;
-  const int mt = wg / ntn, nt = wg - mt * ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int kbeg = blockIdx.y * p.ksplit_len;
-  const int kend = min(p.K, kbeg + p.ksplit_len);
-  const int nk = (kend - kbeg + BK - 1) / BK;
-
-  Operand<AMODE> opa;
-  Operand<BMODE> opb;
-  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
-  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
-
-  float4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-  uint4_t ra[4], rb[4];
-  if (nk > 0) {
-    opa.load(kbeg, kend, ra, p.ga, p.tw);
-    opb.load(kbeg, kend, rb, p.gb, p.tw);
-    opa.store(smem, ra);
-    opb.store(smem + OPND_BYTES, rb);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-    const bool more = (kt + 1) < nk;
-    if (more) {
-      opa.load(kbeg + (kt + 1) * BK, kend, ra, p.ga, p.tw);
-      opb.load(kbeg + (kt + 1) * BK, kend, rb, p.gb, p.tw);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = Operand<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = Operand<BMODE>::frag(cur + OPND_BYTES, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      opa.store(nxt, ra);
-      opb.store(nxt + OPND_BYTES, rb);
-    }
-    __syncthreads();
-  }
-
+template <int OUT_F32>
+__device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* smem, float4_t (&acc)[4][4], int m0, int n0, int tid,
+                                                 int lane, int wm, int wn) {
   // ---- epilogue: accumulators -> LDS (fp32, [128][CS_LD]) -> coalesced global stores ----
   float* cs = (float*)smem;
 #pragma unroll
@@ -376,29 +312,362 @@ __global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_kernel(const NkGemmParams
   }
 }
 
+template <int AMODE, int BMODE, int OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap: blocks that share an XCD (bid % 8) get a contiguous tile range
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // grouped tile order: the ~64 tiles an XCD runs at once (32 CUs x 2 workgroups) form a GROUP_M x 8 patch of
+  // the tile grid, so their A panels and B panels (8 + 8 panels of 128 x K) stay resident in that XCD's 4 MiB L2
+  // instead of every workgroup streaming the whole B operand from the Infinity Cache
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int per_group = GROUP_M * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(GROUP_M, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int mt = first_m + (in_group - nt * gm);
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int kbeg = blockIdx.y * p.ksplit_len;
+  const int kend = min(p.K, kbeg + p.ksplit_len);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  Operand<AMODE> opa;
+  Operand<BMODE> opb;
+  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+
+  float4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  uint4_t ra[4], rb[4];
+  if (nk > 0) {
+    opa.load(kbeg, kend, ra, p.ga, p.tw);
+    opb.load(kbeg, kend, rb, p.gb, p.tw);
+    opa.store(smem, ra);
+    opb.store(smem + OPND_BYTES, rb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    const bool more = (kt + 1) < nk;
+#ifndef ABL_NOLOAD
+    if (more) {
+      opa.load(kbeg + (kt + 1) * BK, kend, ra, p.ga, p.tw);
+      opb.load(kbeg + (kt + 1) * BK, kend, rb, p.gb, p.tw);
+    }
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = Operand<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = Operand<BMODE>::frag(cur + OPND_BYTES, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#ifndef ABL_NOMFMA
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#else
+      { asm volatile("" :: "v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]), "v"(bfr[0]), "v"(bfr[1]), "v"(bfr[2]), "v"(bfr[3])); }
+#endif
+    }
+#ifndef ABL_NOLDSWRITE
+    if (more) {
+      opa.store(nxt, ra);
+      opb.store(nxt + OPND_BYTES, rb);
+    }
+#else
+    { asm volatile("" :: "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3])); }
+#endif
+    __syncthreads();
+  }
+
+  nk_gemm_epilogue<OUT_F32>(p, smem, acc, m0, n0, tid, lane, wm, wn);
+}
+
+// =============================================================================================
+// v2 main loop: LDS-DMA staging (global_load_lds_dwordx4).  Register staging costs a ds_write_b128 per 16 bytes,
+// and ds_write_b128 moves only ~79 B/clk/CU: at 128x128x64 tiles the LDS write path alone (830 clk per pair of
+// k-steps) plus fragment reads (512 clk) exceeds the MFMA time (1024 clk) -- measured: removing the MFMAs from the
+// register-staged kernel saved only 30 %.  LDS-DMA writes the tile straight from the memory pipe (no VGPRs, no
+// ds_write): a wave instruction deposits 64 lanes x 16 B = 1 KiB LINEARLY at a wave-uniform LDS address, while
+// the SOURCE address is per lane, so gathers, transposed operands and the bank swizzle are all expressed on the
+// source side; out-of-range / padding chunks are fetched from a zero page.
+//   KC image  [128 rows][8 slots of 16 B]: slot (row, c) holds source chunk c ^ (row & 7)          (ds_read_b128)
+//   MC image  [64 k][16 slots of 16 B]   : slot (k, c) holds source chunk c ^ swz(k),
+//             swz(k) = 2 * ((k & 3) | (((k >> 3) & 1) << 2))   -> the 8 k-rows one half-wave touches in a
+//             ds_read_b64_tr_b16 land on 8 disjoint 32-byte bank windows (conflict-free)
+// =============================================================================================
+__device__ __attribute__((aligned(64))) unsigned int nk_zero_page[16];
+
+typedef __attribute__((address_space(1))) const void* nk_gptr;
+typedef __attribute__((address_space(3))) void* nk_lptr;
+
+#define V2_OPND_BYTES 16384
+#define V2_STAGE_BYTES (2 * V2_OPND_BYTES)
+#define V2_SMEM_BYTES (BM * CS_LD * 4)   // 67584: epilogue staging is the larger need (2 stages = 65536)
+
+__device__ __forceinline__ int mc_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
+
+template <int MODE>
+struct OperandDMA {
+  const bf16_t* P;
+  long ld;
+  int R, r0, wave, lane;
+  int pn[4], pbh[4], pbw[4];   // KCG: pixel decode of this thread's 4 rows
+  int tkh[2], tkw[2], tc[2];   // MCG: tap / channel of this thread's r-chunk (two swizzle variants)
+  bool rvalid[4];              // KC*: row valid ; MC*: [0],[1] r-chunk variant valid
+
+  __device__ __forceinline__ int kc_row(int i) const { return wave * 32 + i * 8 + (lane >> 3); }
+  __device__ __forceinline__ int kc_chunk() const { return (lane & 7) ^ (lane >> 3); }
+  __device__ __forceinline__ int mc_k(int i) const { return wave * 16 + i * 4 + (lane >> 4); }
+  __device__ __forceinline__ int mc_chunk(int v) const { return (lane & 15) ^ (((lane >> 4) | (v << 2)) << 1); }
+
+  __device__ __forceinline__ void init(const bf16_t* p, long ld_, int R_, int r0_, int tid, const NkGather& g) {
+    P = p; ld = ld_; R = R_; r0 = r0_; wave = tid >> 6; lane = tid & 63;
+    if constexpr (MODE == OP_KC || MODE == OP_KCG) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int r = r0 + kc_row(i);
+        rvalid[i] = r < R;
+        if constexpr (MODE == OP_KCG) {
+          unsigned p_ = rvalid[i] ? (unsigned)r : 0u;
+          unsigned n = fdiv(p_, g.fHoWo);
+          unsigned rem = p_ - n * g.fHoWo.d;
+          unsigned ph = fdiv(rem, g.fWo);
+          unsigned pw = rem - ph * g.fWo.d;
+          pn[i] = (int)n;
+          pbh[i] = (int)ph * g.rs + g.off_h;
+          pbw[i] = (int)pw * g.rs + g.off_w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        int r = r0 + mc_chunk(v) * 8;
+        rvalid[v] = r < R;
+        if constexpr (MODE == OP_MCG) {
+          unsigned rr = rvalid[v] ? (unsigned)r : 0u;
+          unsigned tap = fdiv(rr, g.fC);
+          tc[v] = (int)(rr - tap * g.fC.d);
+          unsigned kh = fdiv(tap, g.fKW);
+          tkh[v] = (int)kh;
+          tkw[v] = (int)(tap - kh * g.fKW.d);
+        }
+      }
+    }
+  }
+
+  // issue this thread's 4 LDS-DMA loads of k-tile [k0, k0+BK) into the operand image at `img`
+  __device__ __forceinline__ void issue(int k0, int kend, char* img, const NkGather& g, const NkTapW& tw) const {
+    const bf16_t* src[4];
+    const bf16_t* zp = (const bf16_t*)nk_zero_page;
+    if constexpr (MODE == OP_KC) {
+      int k = k0 + kc_chunk() * 8;
+      bool kv = k < kend;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) src[i] = (kv && rvalid[i]) ? P + (long)(r0 + kc_row(i)) * ld + k : zp;
+    } else if constexpr (MODE == OP_KCG) {
+      int k = k0 + kc_chunk() * 8;
+      bool kv = k < kend;
+      unsigned kk = kv ? (unsigned)k : 0u;
+      unsigned tap = fdiv(kk, g.fC);
+      int c = (int)(kk - tap * g.fC.d);
+      unsigned kh = fdiv(tap, g.fKW);
+      int kw = (int)(tap - kh * g.fKW.d);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bool ok = kv && rvalid[i];
+        long off = gather_offset(g, pn[i], pbh[i], pbw[i], (int)kh, kw, c, ok);
+        src[i] = ok ? P + off : zp;
+      }
+    } else if constexpr (MODE == OP_MC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + mc_k(i);
+        const int v = i >> 1;
+        src[i] = (k < kend && rvalid[v]) ? P + (long)k * ld + r0 + mc_chunk(v) * 8 : zp;
+      }
+    } else if constexpr (MODE == OP_MCT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + mc_k(i);
+        const int v = i >> 1;
+        bool ok = k < kend && rvalid[v];
+        unsigned kk = ok ? (unsigned)k : 0u;
+        unsigned tap = fdiv(kk, tw.fCout);
+        unsigned co = kk - tap * tw.fCout.d;
+        src[i] = ok ? P + (long)co * tw.co_stride + (long)tap * tw.tap_stride + r0 + mc_chunk(v) * 8 : zp;
+      }
+    } else {  // OP_MCG
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + mc_k(i);
+        const int v = i >> 1;
+        bool ok = (k < kend) && rvalid[v];
+        unsigned p_ = ok ? (unsigned)k : 0u;
+        unsigned n = fdiv(p_, g.fHoWo);
+        unsigned rem = p_ - n * g.fHoWo.d;
+        unsigned ph = fdiv(rem, g.fWo);
+        unsigned pw = rem - ph * g.fWo.d;
+        long off = gather_offset(g, (int)n, (int)ph * g.rs + g.off_h, (int)pw * g.rs + g.off_w, tkh[v], tkw[v], tc[v], ok);
+        src[i] = ok ? P + off : zp;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave * 4 + i) * 1024), 16, 0, 0);
+  }
+
+  static __device__ __forceinline__ bf16x8_t frag(const char* img, int sub, int ks, int lane) {
+    if constexpr (MODE == OP_KC || MODE == OP_KCG) {
+      int row = sub + (lane & 15);
+      int chunk = ks * 4 + (lane >> 4);
+      int byte = row * 128 + ((chunk ^ (row & 7)) << 4);
+      return *(const bf16x8_t*)(img + byte);
+    } else {
+      int g = lane >> 4, i = lane & 15;
+      int q = i >> 2, p = i & 3;
+      int k = ks * 32 + 8 * g + q;
+      int col = sub + 4 * p;                       // element column; sub is a multiple of 16
+      int byte_lo = k * 256 + (((col >> 3) ^ mc_swz(k)) << 4) + (col & 7) * 2;
+      int k2 = k + 4;
+      int byte_hi = k2 * 256 + (((col >> 3) ^ mc_swz(k2)) << 4) + (col & 7) * 2;
+      typedef __attribute__((address_space(3))) short4_t* lds_p;
+      short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + byte_lo));
+      short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + byte_hi));
+      short8_t r;
+      r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+      r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+      return __builtin_bit_cast(bf16x8_t, r);
+    }
+  }
+};
+
+template <int AMODE, int BMODE, int OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_dma_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int per_group = GROUP_M * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(GROUP_M, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int mt = first_m + (in_group - nt * gm);
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int kbeg = blockIdx.y * p.ksplit_len;
+  const int kend = min(p.K, kbeg + p.ksplit_len);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  OperandDMA<AMODE> opa;
+  OperandDMA<BMODE> opb;
+  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+
+  float4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    opa.issue(kbeg, kend, smem, p.ga, p.tw);
+    opb.issue(kbeg, kend, smem + V2_OPND_BYTES, p.gb, p.tw);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    // vmcnt(0) + barrier: tile kt has landed for every wave, and every wave is done reading the other buffer
+    __syncthreads();
+    const char* cur = smem + (kt & 1) * V2_STAGE_BYTES;
+    if (kt + 1 < nk) {
+      char* nxt = smem + ((kt + 1) & 1) * V2_STAGE_BYTES;
+      opa.issue(kbeg + (kt + 1) * BK, kend, nxt, p.ga, p.tw);
+      opb.issue(kbeg + (kt + 1) * BK, kend, nxt + V2_OPND_BYTES, p.gb, p.tw);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = OperandDMA<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = OperandDMA<BMODE>::frag(cur + V2_OPND_BYTES, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  nk_gemm_epilogue<OUT_F32>(p, smem, acc, m0, n0, tid, lane, wm, wn);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+static bool use_v1() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NK_GEMM_V1"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 template <int AMODE, int BMODE, int OUT_F32>
 static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = nk_gemm_kernel<AMODE, BMODE, OUT_F32>;
+  auto kern1 = nk_gemm_kernel<AMODE, BMODE, OUT_F32>;
+  auto kern2 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
     attr_set = true;
   }
   int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, splitk, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SMEM_BYTES, stream, p);
+  if (use_v1()) hipLaunchKernelGGL(kern1, grid, dim3(NTHREADS), SMEM_BYTES, stream, p);
+  else hipLaunchKernelGGL(kern2, grid, dim3(NTHREADS), V2_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_kernel");
 }
 
 static int pick_splitk(int M, int N, int K, int max_split) {
+  // Split K only for grids far below one workgroup per CU.  Each extra split costs M*N*4 bytes of fp32 atomics at the
+  // chip-wide ~1.3 TB/s atomic rate (MI355X_MICROARCH.md), which is 923/K_red of the GEMM's own time per split -- 22 %
+  // per split at a 4096-row reduction -- while under-filled grids are back-filled by the kernels running concurrently
+  // on the other stream (dgrad chain vs weight-gradient stream).
   int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int nk = (K + BK - 1) / BK;
+  if (tiles >= 96) return 1;
   int s = 1;
-  // fill ~2 workgroups per CU (512 slots) but keep >= 8 k-steps per split
-  while (s < max_split && tiles * s < 512 && nk / (s * 2) >= 8) s *= 2;
+  while (s < max_split && tiles * s < 192 && nk / (s * 2) >= 8) s *= 2;
   return s;
 }
 

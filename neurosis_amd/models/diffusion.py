@@ -73,6 +73,8 @@ class DiffusionEngine(nn.Module):
         # contract: the flat gradient buffer is all-zero before the first micro-batch of every optimizer step (it is born
         # zeroed and optimizer_step() re-zeroes it), so weight-gradient kernels may store instead of memset+atomic-add
         ops.state.assume_zeroed = True
+        if ops.state.wgrad_stream is None:
+            ops.state.wgrad_stream = torch.cuda.Stream()
         return self.store
 
     def get_input(self, batch: dict) -> Tensor:

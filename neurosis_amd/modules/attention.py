@@ -116,7 +116,7 @@ class CrossAttention(nn.Module):
                 dqkv = torch.empty_like(qkv)
                 b_att(do, dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:])
                 g_qkv = torch.as_strided(ops.grad_flat(wq), (3 * inner, wq.shape[1]), (wq.shape[1], 1))
-                ops.gemm_tn_f32(dqkv, x, g_qkv, acc())
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dqkv, x, g_qkv, acc()), dqkv, x)
                 return ops.gemm_nn(dqkv, w_qkv), None
 
             return y, bwd
@@ -140,12 +140,16 @@ class CrossAttention(nn.Module):
                 dkv = torch.empty_like(kv)
                 dq, _, _ = b_att(do, None, dkv[:, :inner], dkv[:, inner:])
                 g_kv = torch.as_strided(ops.grad_flat(wk), (2 * inner, wk.shape[1]), (wk.shape[1], 1))
-                ops.gemm_tn_f32(dkv, ctx, g_kv, acc())
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dkv, ctx, g_kv, acc()), dkv, ctx)
             else:
                 dq, dk, dv = b_att(do)
-                ops.gemm_tn_f32(dk, ctx, ops.g2d(wk), acc())
-                ops.gemm_tn_f32(dv, ctx, ops.g2d(wv), acc())
-            ops.gemm_tn_f32(dq, x, ops.g2d(wq), acc())
+
+                def wg_kv():
+                    ops.gemm_tn_f32(dk, ctx, ops.g2d(wk), acc())
+                    ops.gemm_tn_f32(dv, ctx, ops.g2d(wv), acc())
+
+                ops.on_wgrad_stream(wg_kv, dk, dv, ctx)
+            ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dq, x, ops.g2d(wq), acc()), dq, x)
             dx = ops.gemm_nn(dq, ops.w2d(wq))
             dctx = None
             if self_attn or need_dctx:

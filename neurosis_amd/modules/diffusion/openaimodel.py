@@ -397,7 +397,7 @@ class UNetModel(nn.Module):
     def fwd(self, x: Img, timesteps: Tensor, context: Optional[Tensor], y: Optional[Tensor]):
         """x: Img with channels padded to a multiple of 8.  Returns (out Img (padded channels), bwd);
         bwd(dout tokens) -> dx tokens or None."""
-        hook = self.grad_ready_hook
+        hook_raw = self.grad_ready_hook
         t_emb = ops.timestep_embedding(timesteps, self.model_channels)
         emb, b_time = self._mlp_fwd(self.time_embed, t_emb, need_dx=False)
         b_label = None
@@ -422,6 +422,12 @@ class UNetModel(nn.Module):
         out, b_conv = self.out[2].fwd(hn)
 
         def bwd(dout: Tensor):
+            if hook_raw is not None:
+                def hook(m):
+                    ops.join_wgrad_stream()   # the block's weight gradients may still be in flight on the side stream
+                    hook_raw(m)
+            else:
+                hook = None
             dh, _ = b_conv(dout)
             dh = b_gn(dh.t)
             if hook:
@@ -461,6 +467,7 @@ class UNetModel(nn.Module):
             b_time(demb)
             if hook:
                 hook(self.time_embed)
+            ops.join_wgrad_stream()
             return dh
 
         return out, bwd

@@ -38,6 +38,7 @@ class NkFunction(torch.autograd.Function):
         if bwd is None:
             raise RuntimeError("neurosis_amd: backward called twice on the same graph (activations already freed)")
         gins = bwd(*gouts)
+        ops.join_wgrad_stream()  # parameter gradients written on the side stream are visible to whatever runs next
         if not isinstance(gins, tuple):
             gins = (gins,)
         fixed = []
@@ -139,6 +140,7 @@ class Conv2d(nn.Module):
                 res = b(dy)
             finally:
                 ops.state.grad_accumulate = acc
+            ops.join_wgrad_stream()
             with torch.no_grad():  # fold the padded gradient back (a few thousand elements)
                 g = wp.grad[: self.out_channels, : self.in_channels]
                 ops.grad_flat(self.weight)

@@ -29,6 +29,7 @@ class _State:
     grad_accumulate = False  # False: weight-grad kernels overwrite; True: they add (micro-batch accumulation)
     assume_zeroed = False  # True: .grad buffers are all-zero before the first micro-batch (engine zeroes after each step)
     param_epoch = 0  # bumped whenever fp32 masters change (optimizer step / load_state_dict)
+    wgrad_stream = None  # optional side HIP stream: weight-gradient GEMMs run there, concurrently with the dgrad chain
 
 
 state = _State()
@@ -39,6 +40,32 @@ def wgrad_mode() -> int:
     if state.grad_accumulate:
         return 1
     return 2 if state.assume_zeroed else 0
+
+
+def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor) -> None:
+    """Run `fn` (kernels that only WRITE parameter gradients) on the side stream if one is configured.
+
+    Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads them until the optimizer /
+    all-reduce), and most of them -- like the dgrad GEMMs they sit next to -- do not fill 256 CUs x 2 workgroups on
+    their own (e.g. 1280x1280 outputs = 100 tiles).  Issuing them on a second HIP stream lets the hardware co-schedule
+    both kernels' workgroups, which recovers the tile-quantisation tail of each without split-K atomics.
+    `reads` are the activation tensors fn consumes: they are pinned to the side stream for the caching allocator."""
+    side = state.wgrad_stream
+    if side is None:
+        fn()
+        return
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    for t in reads:
+        if t is not None:
+            t.record_stream(side)
+
+
+def join_wgrad_stream() -> None:
+    """Make the current stream wait for every weight-gradient kernel issued so far."""
+    if state.wgrad_stream is not None:
+        torch.cuda.current_stream().wait_stream(state.wgrad_stream)
 
 
 def _ws(n_floats: int, device) -> Tensor:
@@ -254,9 +281,12 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
     y = gemm_nt(x, w2d(weight), bias, residual)
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
-        gemm_tn_f32(dy, x, g2d(weight), wgrad_mode())
-        if bias is not None:
-            colsum(dy, grad_flat(bias), True)
+        def wg():
+            gemm_tn_f32(dy, x, g2d(weight), wgrad_mode())
+            if bias is not None:
+                colsum(dy, grad_flat(bias), True)
+
+        on_wgrad_stream(wg, dy, x)
         if not need_dx:
             return None
         return gemm_nn(dy, w2d(weight), dx_add)
@@ -302,9 +332,12 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
         _check2d(dy, "dy")
         if not dy.is_contiguous():
             raise ValueError("conv2d bwd: dy must be dense")
-        call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(), _stream())
-        if bias is not None:
-            colsum(dy, grad_flat(bias), True)
+        def wg():
+            call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(), _stream())
+            if bias is not None:
+                colsum(dy, grad_flat(bias), True)
+
+        on_wgrad_stream(wg, dy, x.t)
         drow = None
         if rowvec is not None:
             drow32 = torch.empty(x.N, Cout, dtype=torch.float32, device=dy.device)
