@@ -286,11 +286,15 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
+        from neurosis_amd import ops as _ops
+
         timer = GemmTimer()
         timer.install()
+        side, _ops.state.wgrad_stream = _ops.state.wgrad_stream, None  # no overlapping launches while timing kernels
         try:
             step()
         finally:
+            _ops.state.wgrad_stream = side
             timer.uninstall()
         f, ms, n, per = timer.summary()
         ach = f / (ms * 1e-3) / 1e12
