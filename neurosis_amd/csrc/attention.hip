@@ -34,6 +34,7 @@ struct AttnParams {
 
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1.0e30f)
+#define EXP2(x) __builtin_amdgcn_exp2f(x)   // raw v_exp_f32: arguments here are <= 0 or bounded, no range fix-up needed
 
 typedef __attribute__((address_space(3))) short4_t* lds_s4p;
 
@@ -148,37 +149,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       for (int ks = 0; ks < KS; ++ks)
         s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, RS, hf * 32, ks, lane), qf[ks], s[hf], 0, 0, 0);
     }
-    // mask keys beyond Lk, running max
-    float mloc = NEG_BIG;
+    // keys beyond Lk exist only in the last tile (wave-uniform branch)
     const int kbase = t * 64;
+    if (kbase + 64 > p.Lk) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int key = kbase + hf * 32 + acc_row(r, h5);
+          s[hf][r] = key < p.Lk ? s[hf][r] : NEG_BIG;
+        }
+    }
+    float mloc = s[0][0];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int key = kbase + hf * 32 + acc_row(r, h5);
-        float v = key < p.Lk ? s[hf][r] : NEG_BIG;
-        s[hf][r] = v;
-        mloc = fmaxf(mloc, v);
-      }
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[hf][r]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mnew = fmaxf(m, mloc);
-    const float alpha = exp2f((m - mnew) * c);
-    m = mnew;
     const float mc = mnew * c;
     float lsum = 0.f;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pv = exp2f(s[hf][r] * c - mc);
+        float pv = EXP2(s[hf][r] * c - mc);
         s[hf][r] = pv;
         lsum += pv;
       }
-    l = l * alpha + lsum;
+    if (__any(mnew > m)) {  // some query row's running max moved: rescale (alpha = 1 where it did not)
+      const float alpha = EXP2((m - mnew) * c);
+      l *= alpha;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    }
+    m = mnew;
+    l += lsum;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int qr = acc_row(r, h5);
-      float pv = exp2f(s[r] * c - s_lse[qr]);
+      float pv = EXP2(s[r] * c - s_lse[qr]);
       s[r] = pv;
       dp[r] = pv * (dp[r] - s_dl[qr]) * p.scale;
     }
@@ -446,9 +454,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int key = t * 64 + hf * 32 + acc_row(r, h5);
-        float pv = key < p.Lk ? exp2f(s[r] * c - lse2) : 0.f;
+        float pv = EXP2(s[r] * c - lse2);
         dp[r] = pv * (dp[r] - dlt) * p.scale;
+      }
+      if (t * 64 + hf * 32 + 32 > p.Lk) {   // keys beyond Lk exist only in the last tile (wave-uniform branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = (t * 64 + hf * 32 + acc_row(r, h5)) < p.Lk ? dp[r] : 0.f;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {

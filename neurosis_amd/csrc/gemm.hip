@@ -609,24 +609,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_dma_kernel(const NkGemmPa
     // vmcnt(0) + barrier: tile kt has landed for every wave, and every wave is done reading the other buffer
     __syncthreads();
     const char* cur = smem + (kt & 1) * V2_STAGE_BYTES;
+    // fragment reads of BOTH k sub-steps first, THEN the next tile's DMA, then the MFMAs.  hipcc (ROCm 7.2) puts an
+    // s_waitcnt vmcnt(0) in front of ds_read_b64_tr_b16 whenever an LDS-DMA is outstanding (it cannot prove the
+    // transposing read does not alias the DMA's LDS destination), which serialised the whole pipeline for the
+    // r-contiguous operand modes (-22 %); with the DMA issued after the reads there is nothing outstanding to wait for.
+    bf16x8_t af[2][4], bfr[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[ks][i] = OperandDMA<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[ks][j] = OperandDMA<BMODE>::frag(cur + V2_OPND_BYTES, wn * 64 + j * 16, ks, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * V2_STAGE_BYTES;
       opa.issue(kbeg + (kt + 1) * BK, kend, nxt, p.ga, p.tw);
       opb.issue(kbeg + (kt + 1) * BK, kend, nxt + V2_OPND_BYTES, p.gb, p.tw);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = OperandDMA<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = OperandDMA<BMODE>::frag(cur + V2_OPND_BYTES, wn * 64 + j * 16, ks, lane);
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
   }
   __syncthreads();
   nk_gemm_epilogue<OUT_F32>(p, smem, acc, m0, n0, tid, lane, wm, wn);

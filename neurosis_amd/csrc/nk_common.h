@@ -32,8 +32,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
   return __builtin_bit_cast(unsigned short, b);
 }
+typedef __attribute__((ext_vector_type(2))) float float2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  float2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));  // one v_cvt_pk_bf16_f32
 }
 __device__ __forceinline__ void unpack8(const uint4_t& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
