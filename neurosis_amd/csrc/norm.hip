@@ -497,7 +497,7 @@ extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* 
 }
 
 static int ln_bwd_blocks(int M) {
-  int b = (M + 15) / 16;
+  int b = (M + 7) / 8;   // 2 rows per wave: enough waves in flight to stream HBM, partials stay <= the tensor size
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return b;
