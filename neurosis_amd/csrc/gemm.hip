@@ -230,7 +230,7 @@ struct Operand {
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
-template <int OUT_F32>
+template <int OUT_F32, int TBM = BM, int TNT = NTHREADS>
 __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* smem, float4_t (&acc)[4][4], int m0, int n0, int tid,
                                                  int lane, int wm, int wn) {
   // ---- epilogue: accumulators -> LDS (fp32, [128][CS_LD]) -> coalesced global stores ----
@@ -249,8 +249,8 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
 
   if constexpr (OUT_F32) {
     float* C = (float*)p.C;
-    for (int it = 0; it < (BM * BN) / NTHREADS; ++it) {
-      int idx = tid + it * NTHREADS;
+    for (int it = 0; it < (TBM * BN) / TNT; ++it) {
+      int idx = tid + it * TNT;
       int row = idx >> 7, col = idx & 127;
       int m = m0 + row, n = n0 + col;
       if (m < p.M && n < p.N) {
@@ -264,8 +264,8 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
     bf16_t* C = (bf16_t*)p.C;
     const bool vec = (p.N & 7) == 0;
 #pragma unroll 2
-    for (int it = 0; it < (BM * BN / 8) / NTHREADS; ++it) {
-      int idx = tid + it * NTHREADS;
+    for (int it = 0; it < (TBM * BN / 8) / TNT; ++it) {
+      int idx = tid + it * TNT;
       int row = idx >> 4, cc = idx & 15;
       int m = m0 + row, n = n0 + cc * 8;
       if (m >= p.M || n >= p.N) continue;
@@ -428,16 +428,16 @@ typedef __attribute__((address_space(3))) void* nk_lptr;
 
 __device__ __forceinline__ int mc_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
 
-template <int MODE>
+template <int MODE, int NP = 4>
 struct OperandDMA {
   const bf16_t* P;
   long ld;
   int R, r0, wave, lane;
-  int pn[4], pbh[4], pbw[4];   // KCG: pixel decode of this thread's 4 rows
+  int pn[NP], pbh[NP], pbw[NP];   // KCG: pixel decode of this thread's rows
   int tkh[2], tkw[2], tc[2];   // MCG: tap / channel of this thread's r-chunk (two swizzle variants)
-  bool rvalid[4];              // KC*: row valid ; MC*: [0],[1] r-chunk variant valid
+  bool rvalid[NP < 2 ? 2 : NP];  // KC*: row valid ; MC*: [0],[1] r-chunk variant valid
 
-  __device__ __forceinline__ int kc_row(int i) const { return wave * 32 + i * 8 + (lane >> 3); }
+  __device__ __forceinline__ int kc_row(int i) const { return wave * (NP * 8) + i * 8 + (lane >> 3); }
   __device__ __forceinline__ int kc_chunk() const { return (lane & 7) ^ (lane >> 3); }
   __device__ __forceinline__ int mc_k(int i) const { return wave * 16 + i * 4 + (lane >> 4); }
   __device__ __forceinline__ int mc_chunk(int v) const { return (lane & 15) ^ (((lane >> 4) | (v << 2)) << 1); }
@@ -446,7 +446,7 @@ struct OperandDMA {
     P = p; ld = ld_; R = R_; r0 = r0_; wave = tid >> 6; lane = tid & 63;
     if constexpr (MODE == OP_KC || MODE == OP_KCG) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NP; ++i) {
         int r = r0 + kc_row(i);
         rvalid[i] = r < R;
         if constexpr (MODE == OP_KCG) {
@@ -477,15 +477,16 @@ struct OperandDMA {
     }
   }
 
-  // issue this thread's 4 LDS-DMA loads of k-tile [k0, k0+BK) into the operand image at `img`
+  // issue this thread's NP LDS-DMA loads of k-tile [k0, k0+BK) into the operand image at `img`
   __device__ __forceinline__ void issue(int k0, int kend, char* img, const NkGather& g, const NkTapW& tw) const {
-    const bf16_t* src[4];
+    static_assert(NP == 4 || MODE == OP_KC || MODE == OP_KCG, "r-contiguous modes are laid out for 4 pieces per thread");
+    const bf16_t* src[NP];
     const bf16_t* zp = (const bf16_t*)nk_zero_page;
     if constexpr (MODE == OP_KC) {
       int k = k0 + kc_chunk() * 8;
       bool kv = k < kend;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) src[i] = (kv && rvalid[i]) ? P + (long)(r0 + kc_row(i)) * ld + k : zp;
+      for (int i = 0; i < NP; ++i) src[i] = (kv && rvalid[i]) ? P + (long)(r0 + kc_row(i)) * ld + k : zp;
     } else if constexpr (MODE == OP_KCG) {
       int k = k0 + kc_chunk() * 8;
       bool kv = k < kend;
@@ -495,7 +496,7 @@ struct OperandDMA {
       unsigned kh = fdiv(tap, g.fKW);
       int kw = (int)(tap - kh * g.fKW.d);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NP; ++i) {
         bool ok = kv && rvalid[i];
         long off = gather_offset(g, pn[i], pbh[i], pbw[i], (int)kh, kw, c, ok);
         src[i] = ok ? P + off : zp;
@@ -534,8 +535,8 @@ struct OperandDMA {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave * 4 + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < NP; ++i)
+      __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave * NP + i) * 1024), 16, 0, 0);
   }
 
   static __device__ __forceinline__ bf16x8_t frag(const char* img, int sub, int ks, int lane) {
@@ -614,6 +615,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_dma_kernel(const NkGemmPa
     // transposing read does not alias the DMA's LDS destination), which serialised the whole pipeline for the
     // r-contiguous operand modes (-22 %); with the DMA issued after the reads there is nothing outstanding to wait for.
     bf16x8_t af[2][4], bfr[2][4];
+#ifndef ABL2_NOREAD
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -621,13 +623,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_dma_kernel(const NkGemmPa
 #pragma unroll
       for (int j = 0; j < 4; ++j) bfr[ks][j] = OperandDMA<BMODE>::frag(cur + V2_OPND_BYTES, wn * 64 + j * 16, ks, lane);
     }
+#else
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { af[ks][i] = __builtin_bit_cast(bf16x8_t, (uint4_t){(unsigned)kt, 1u, 2u, 3u}); bfr[ks][i] = af[ks][i]; }
+#endif
     __builtin_amdgcn_sched_barrier(0);
+#ifndef ABL2_NODMA
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * V2_STAGE_BYTES;
       opa.issue(kbeg + (kt + 1) * BK, kend, nxt, p.ga, p.tw);
       opb.issue(kbeg + (kt + 1) * BK, kend, nxt + V2_OPND_BYTES, p.gb, p.tw);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
+#ifndef ABL2_NOMFMA
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -635,14 +646,134 @@ __global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_dma_kernel(const NkGemmPa
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      asm volatile("" ::"v"(af[ks][0]), "v"(af[ks][1]), "v"(af[ks][2]), "v"(af[ks][3]), "v"(bfr[ks][0]), "v"(bfr[ks][1]), "v"(bfr[ks][2]), "v"(bfr[ks][3]));
+#endif
   }
   __syncthreads();
   nk_gemm_epilogue<OUT_F32>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
+// =============================================================================================
+// "big" variant (opt-in, see use_big) for grids of >= 2 rounds: 256x128x64 tiles, 512 threads (8 waves as 4x2, 64x64 per wave), ONE workgroup
+// per CU, a THREE-stage LDS-DMA ring (3 x 48 KiB) with counted s_waitcnt vmcnt and raw s_barrier so that two tiles
+// (96 KiB per CU) are always in flight.  Why: the 128x128 kernel is fed by LDS-DMA at ~15 TB/s chip-wide (29 B/clk/CU,
+// ablation: removing the MFMAs saves only 16 %), i.e. it is bound by bytes-in-flight / latency; this variant needs
+// 25 % fewer bytes per FLOP and keeps 1.5x more bytes in flight at the same 2 waves per SIMD.
+// k-contiguous operands only (Linear forward, Conv2d forward incl. the VAE encoder): the transposing LDS reads of the
+// r-contiguous modes make hipcc drain vmcnt(0), which would defeat the ring.
+// =============================================================================================
+#define BIG_BM 256
+#define BIG_NT 512
+#define BIG_STAGE_BYTES (32768 + 16384)
+#define BIG_NSTAGE 3
+#define BIG_SMEM_BYTES (BIG_NSTAGE * BIG_STAGE_BYTES)   // 147456 >= 256*132*4 = 135168 (epilogue staging)
+static_assert(BIG_SMEM_BYTES >= BIG_BM * CS_LD * 4, "big epilogue staging must fit");
+
+template <int AMODE, int OUT_F32>
+__global__ __launch_bounds__(BIG_NT, 2) void nk_gemm_big_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;            // 0..7
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BIG_BM - 1) / BIG_BM;
+  constexpr int GM = 4;                 // 4 x 8 tile patches: 32 workgroups per XCD at a time
+  const int per_group = GM * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GM;
+  const int gm = min(GM, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int mt = first_m + (in_group - nt * gm);
+  const int m0 = mt * BIG_BM, n0 = nt * BN;
+
+  const int kend = p.K;
+  const int nk = (p.K + BK - 1) / BK;
+
+  OperandDMA<AMODE, 4> opa;   // 8 waves x 4 pieces x 8 rows = 256 rows
+  OperandDMA<OP_KC, 2> opb;   // 8 waves x 2 pieces x 8 rows = 128 rows
+  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+
+  float4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < BIG_NSTAGE - 1; ++t)
+    if (t < nk) {
+      opa.issue(t * BK, kend, smem + t * BIG_STAGE_BYTES, p.ga, p.tw);
+      opb.issue(t * BK, kend, smem + t * BIG_STAGE_BYTES + 32768, p.gb, p.tw);
+    }
+  int cur_stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave issued 6 pieces per tile, in order; tile kt has landed once at most the 6 pieces of tile kt+1 remain
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave's share of tile kt is in LDS; every wave is done reading stage (kt-1)%3
+    if (kt + 2 < nk) {
+      int ns = cur_stage + 2; if (ns >= BIG_NSTAGE) ns -= BIG_NSTAGE;
+      opa.issue((kt + 2) * BK, kend, smem + ns * BIG_STAGE_BYTES, p.ga, p.tw);
+      opb.issue((kt + 2) * BK, kend, smem + ns * BIG_STAGE_BYTES + 32768, p.gb, p.tw);
+    }
+    const char* cur = smem + cur_stage * BIG_STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = OperandDMA<OP_KC>::frag(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (++cur_stage == BIG_NSTAGE) cur_stage = 0;
+  }
+  __syncthreads();
+  nk_gemm_epilogue<OUT_F32, BIG_BM, BIG_NT>(p, smem, acc, m0, n0, tid, lane, wm, wn);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+static bool use_big(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
+  // EXPERIMENTAL, opt-in (NK_GEMM_BIG=1): measured 5-10 % SLOWER than the 128x128 kernel at two workgroups per CU on
+  // every SDXL shape (e.g. 16384x5120x640: 653 vs 717 TFLOP/s), so it is not dispatched by default; kept as the base of
+  // the 256x256 variant planned next.
+  static int dis = -1;
+  if (dis < 0) { const char* e = getenv("NK_GEMM_BIG"); dis = (e && e[0] == '1') ? 0 : 1; }
+  if (dis || out_f32 || splitk != 1 || bmode != OP_KC || !(amode == OP_KC || amode == OP_KCG)) return false;
+  long tiles = (long)((p.M + BIG_BM - 1) / BIG_BM) * ((p.N + BN - 1) / BN);
+  return tiles >= 512 && p.K >= 4 * BK;
+}
+
+template <int AMODE>
+static int launch_big(const NkGemmParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = nk_gemm_big_kernel<AMODE, 0>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_SMEM_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(((p.M + BIG_BM - 1) / BIG_BM) * ((p.N + BN - 1) / BN), 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(BIG_NT), BIG_SMEM_BYTES, stream, p);
+  return nk_check_launch("nk_gemm_big_kernel");
+}
+
 static bool use_v1() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("NK_GEMM_V1"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -714,6 +845,9 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   } else if (p.accumulate == 2) {
     p.accumulate = splitk > 1 ? 1 : 0;
   }
+
+  if (use_big(p, amode, bmode, out_f32, splitk))
+    return amode == OP_KC ? launch_big<OP_KC>(p, stream) : launch_big<OP_KCG>(p, stream);
 
 #define NK_CASE(A_, B_)                                                          \
   if (amode == A_ && bmode == B_) {                                              \

@@ -1,0 +1,77 @@
+"""FlatDataParallel on the GPU: two ranks share cuda:0 (gloo moves the slices; RCCL itself needs one GPU per rank and is
+exercised by the driver's multi-GPU bench).  Checks the whole exchange path on device -- hook order, side-stream joins,
+slice reductions on the communication stream, grad_scale -- against the single-process gradient of the full batch."""
+import json
+import os
+import socket
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(fx, shapes):
+    import neurosis_amd.modules.diffusion as D
+    from neurosis_amd.models.diffusion import DiffusionEngine
+    from tests.golden.make_golden import synth_state_dict
+
+    net = D.UNetModel(**fx["cfg"])
+    net.load_state_dict(synth_state_dict(shapes))
+    net = net.cuda()
+    den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization()).cuda()
+    eng = DiffusionEngine(model=net, denoiser=den, first_stage_model=None,
+                          loss_fn=D.StandardDiffusionLoss(sigma_generator=D.InjectedSigmaGenerator(), loss_weighting=D.EpsWeighting()))
+    eng.setup_flat_params()
+    return eng
+
+
+def _loss(eng, fx, sel):
+    batch = {"crossattn": fx["context"][sel].cuda(), "vector": fx["y"][sel].cuda()}
+    return eng(fx["x"][sel].cuda(), batch, sigmas=fx["sigma"][sel].cuda(), noise=fx["noise"][sel].cuda())
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neurosis_amd.dp import FlatDataParallel
+
+    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
+    eng = _build(fx, shapes)
+    dp = FlatDataParallel(eng.model.diffusion_model, eng.store)
+    _loss(eng, fx, slice(rank, rank + 1)).mean().backward()
+    scale = dp.finish()
+    torch.cuda.synchronize()
+    mine = (eng.store.grad * scale).cpu()
+    if rank == 0:
+        eng2 = _build(fx, shapes)
+        _loss(eng2, fx, slice(0, world)).mean().backward()
+        torch.cuda.synchronize()
+        full = eng2.store.grad.cpu()
+        err = float((mine - full).abs().max() / full.abs().max())
+        cos = float(torch.dot(mine, full) / (mine.norm() * full.norm()))
+        out["err"], out["cos"], out["scale"] = err, cos, scale
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_data_parallel_two_ranks_one_gpu():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out["scale"] == 0.5
+    # bf16 activations: per-rank batches of 1 vs one batch of 2 round differently; same bound as the golden-vector test
+    assert out["cos"] >= 0.999 and out["err"] <= 5e-2, dict(out)

@@ -36,7 +36,8 @@ def rnd(*shape, scale=1.0, seed=None):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 320), (308, 640, 2048), (4, 1280, 320), (1000, 72, 136), (16384, 640, 640)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 320), (308, 640, 2048), (4, 1280, 320), (1000, 72, 136), (16384, 640, 640),
+                                   (32768, 2048, 320), (16300, 4104, 264)])  # the last two take the 256x128 ring kernel (>= 512 tiles)
 def test_linear_fwd(ops, M, N, K):
     x, w, b, r = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N), rnd(M, N)
     ref = x @ w.t() + b + r
@@ -145,6 +146,11 @@ def test_conv3x3_upsample(ops):
 
 def test_conv3x3_real_channels(ops):
     _conv_case(ops, 1, 32, 32, 320, 320, 3, 1, 1)
+
+
+def test_conv3x3_big_grid(ops):
+    # 131072 output pixels x 128 channels = 512 tiles of 256x128: the ring kernel with the gather loader
+    _conv_case(ops, 2, 256, 256, 64, 128, 3, 1, 1, rowvec=True, residual=True)
 
 
 def test_conv3x3_pad_channels(ops):
