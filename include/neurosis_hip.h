@@ -78,7 +78,8 @@ typedef struct NkAttnDesc {
 } NkAttnDesc;
 int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, void* o, float* lse,
                      void* stream);
-/* delta_ws: fp32 workspace [B][H][Lq] */
+/* delta_ws: uninitialised fp32 workspace of nk_attention_bwd_ws_floats(d) elements (row dots + cross-attention partials) */
+long nk_attention_bwd_ws_floats(const NkAttnDesc* d);
 int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, const void* o,
                      const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* delta_ws, void* stream);
 /* in-place row softmax on bf16 [M][L]: the unfused single-head d=512 attention of the VAE mid block

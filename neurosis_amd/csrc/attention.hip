@@ -30,6 +30,8 @@ struct AttnParams {
   long sdq, sdk, sdv, sdo;  // strides of gradients
   long bdq, bdk, bdv, bdo;
   float scale;
+  int qsplit;           // dK/dV kernel: workgroups per key block along the query range (partials in dkv_part)
+  float* dkv_part;      // [qsplit][2][B][Lk][H*D] fp32 partial dK / dV when qsplit > 1
 };
 
 #define LOG2E 1.4426950408889634f
@@ -266,7 +268,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, kl = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int kb = blockIdx.x / p.qsplit, qs = blockIdx.x - kb * p.qsplit;
+  const int k0 = kb * 128 + wave * 32;
   const float c = p.scale * LOG2E;
 
   const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * p.D;
@@ -275,6 +278,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
   const bf16_t* dOb = p.dO + (long)b * p.bdo + (long)hd * p.D;
   const float* lse = p.LSE + ((long)b * p.H + hd) * p.Lq;
   const float* dl = p.delta + ((long)b * p.H + hd) * p.Lq;
+  // this workgroup's slice of the query tiles
+  const int nt_all = (p.Lq + 31) / 32;
+  const int per = (nt_all + p.qsplit - 1) / p.qsplit;
+  const int t_lo = qs * per, t_hi = min(nt_all, t_lo + per);
 
   bf16x8_t kf[KS], vf[KS];
 #pragma unroll
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
-  const int nt = (p.Lq + 31) / 32;
+  const int nt = max(t_hi - t_lo, 0);
   TileLoader<32, DP> lq, ld_;
   float st_lse = 0.f, st_dl = 0.f;
   auto load_stats = [&](int q0) {
@@ -310,9 +317,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
       ((float*)(stage + 2 * TILE))[32 + tid] = st_dl;
     }
   };
-  lq.load(Qb, p.sq, 0, p.Lq, p.D, tid);
-  ld_.load(dOb, p.sdo, 0, p.Lq, p.D, tid);
-  load_stats(0);
+  lq.load(Qb, p.sq, t_lo * 32, p.Lq, p.D, tid);
+  ld_.load(dOb, p.sdo, t_lo * 32, p.Lq, p.D, tid);
+  load_stats(t_lo * 32);
   lq.store(smem, tid);
   ld_.store(smem + TILE, tid);
   store_stats(smem);
@@ -326,9 +333,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
     const float* s_dl = s_lse + 32;
     const bool more = t + 1 < nt;
     if (more) {
-      lq.load(Qb, p.sq, (t + 1) * 32, p.Lq, p.D, tid);
-      ld_.load(dOb, p.sdo, (t + 1) * 32, p.Lq, p.D, tid);
-      load_stats((t + 1) * 32);
+      lq.load(Qb, p.sq, (t_lo + t + 1) * 32, p.Lq, p.D, tid);
+      ld_.load(dOb, p.sdo, (t_lo + t + 1) * 32, p.Lq, p.D, tid);
+      load_stats((t_lo + t + 1) * 32);
     }
     float16_t s, dp;
 #pragma unroll
@@ -366,6 +373,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
 
   const int key = k0 + kl;
   if (key < p.Lk) {
+    if (p.qsplit > 1) {
+      // fp32 partials [qs][0=dK,1=dV][b][key][H*D]; summed in a fixed order by attn_dkv_reduce_kernel
+      const long hd_all = (long)p.H * p.D;
+      const long plane = (long)p.B * p.Lk * hd_all;
+      float* pk = p.dkv_part + ((long)qs * 2) * plane + ((long)b * p.Lk + key) * hd_all + (long)hd * p.D;
+      float* pv = pk + plane;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          int d = dt * 32 + 8 * r4 + 4 * h5;
+          if (d < p.D) {
+            *(float4_t*)(pk + d) = (float4_t){dk[dt][4 * r4 + 0], dk[dt][4 * r4 + 1], dk[dt][4 * r4 + 2], dk[dt][4 * r4 + 3]};
+            *(float4_t*)(pv + d) = (float4_t){dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1], dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]};
+          }
+        }
+      return;
+    }
     bf16_t* dKb = p.dK + (long)b * p.bdk + (long)key * p.sdk + (long)hd * p.D;
     bf16_t* dVb = p.dV + (long)b * p.bdv + (long)key * p.sdv + (long)hd * p.D;
 #pragma unroll
@@ -383,6 +408,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
           *(uint2_t*)(dVb + d) = v;
         }
       }
+  }
+}
+
+// dK / dV = sum over the query splits of the fp32 partials (fixed order), written bf16 with the caller's strides
+__global__ void attn_dkv_reduce_kernel(const AttnParams p) {
+  const long hd_all = (long)p.H * p.D;
+  const long rows = (long)p.B * p.Lk;
+  const long plane = rows * hd_all;
+  const long total = rows * (hd_all >> 2);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i / (hd_all >> 2);
+    int c4 = (int)(i - row * (hd_all >> 2)) * 4;
+    int b = (int)(row / p.Lk), key = (int)(row - (long)b * p.Lk);
+    float4_t ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.qsplit; ++s) {
+      const float* base = p.dkv_part + ((long)s * 2) * plane + row * hd_all + c4;
+      const float4_t x = *(const float4_t*)base, y = *(const float4_t*)(base + plane);
+      ak += x;
+      av += y;
+    }
+    uint2_t ok, ov;
+    ok.x = pack2bf(ak[0], ak[1]); ok.y = pack2bf(ak[2], ak[3]);
+    ov.x = pack2bf(av[0], av[1]); ov.y = pack2bf(av[2], av[3]);
+    *(uint2_t*)(p.dK + (long)b * p.bdk + (long)key * p.sdk + c4) = ok;
+    *(uint2_t*)(p.dV + (long)b * p.bdv + (long)key * p.sdv + c4) = ov;
   }
 }
 
@@ -538,6 +588,22 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
   return nk_check_launch("attn_fwd_kernel");
 }
 
+static int attn_qsplit(const NkAttnDesc* d) {
+  // a single key block (cross-attention, Lk = 77) gives only B*H workgroups that each walk the whole query range:
+  // split the query range so the grid has >= ~512 workgroups
+  if (d->Lk > 128 || d->Lq < 512) return 1;
+  int base = d->B * d->H;
+  int s = 1;
+  while (s < 16 && base * s < 512 && d->Lq / (s * 2) >= 128) s *= 2;
+  return s;
+}
+extern "C" long nk_attention_bwd_ws_floats(const NkAttnDesc* d) {
+  long delta = (long)d->B * d->H * d->Lq;
+  int s = attn_qsplit(d);
+  long part = s > 1 ? (long)s * 2 * d->B * d->Lk * d->H * d->D : 0;
+  return delta + part + 64;
+}
+
 extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, const void* o,
                                 const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* delta_ws,
                                 void* stream_) {
@@ -564,8 +630,10 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
     if (int e = nk_check_launch("attn_delta_kernel")) return e;
   }
   const int dp = attn_dp(d->D);
+  p.qsplit = attn_qsplit(d);
+  p.dkv_part = p.qsplit > 1 ? delta_ws + (((long)d->B * d->H * d->Lq + 3) & ~3l) : nullptr;
   {
-    dim3 grid((d->Lk + 127) / 128, d->H, d->B);
+    dim3 grid(((d->Lk + 127) / 128) * p.qsplit, d->H, d->B);
     const int smem = 2 * (2 * 32 * (dp * 2 + 16) + 256);
 #define KV_CASE(DP_)                                                                           \
   if (dp == DP_) {                                                                             \
@@ -575,6 +643,13 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
     KV_CASE(64) KV_CASE(96) KV_CASE(160)
 #undef KV_CASE
     if (int e = nk_check_launch("attn_bwd_dkdv_kernel")) return e;
+    if (p.qsplit > 1) {
+      long total = (long)d->B * d->Lk * ((long)d->H * d->D / 4);
+      long blocks = (total + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, p);
+      if (int e = nk_check_launch("attn_dkv_reduce_kernel")) return e;
+    }
   }
   {
     dim3 grid((d->Lq + 127) / 128, d->H, d->B);

@@ -60,13 +60,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
   }
 }
 
-// sums the per-block partials of one image: out[n][2G] = sum_p part[n][p][2G]
-__global__ void gn_reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int G2) {
+// sums the per-block partials of one image in a fixed order: out[n][2G] = sum_p part[n][p][2G]
+// block = G2 (<= 128) columns x (1024 / 128) row groups; each row group sums a strided subset, then a serial combine
+__global__ __launch_bounds__(1024) void gn_reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                 int nparts, int G2) {
+  __shared__ float sm[8][128];
   const int n = blockIdx.x;
-  for (int i = threadIdx.x; i < G2; i += blockDim.x) {
-    float a = 0.f;
-    for (int p = 0; p < nparts; ++p) a += part[((long)n * nparts + p) * G2 + i];
-    out[(long)n * G2 + i] = a;
+  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;   // 128 x 8
+  float a = 0.f;
+  if (tx < G2)
+    for (int p = ty; p < nparts; p += 8) a += part[((long)n * nparts + p) * G2 + tx];
+  sm[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && tx < G2) {
+#pragma unroll
+    for (int j = 1; j < 8; ++j) a += sm[j][tx];
+    out[(long)n * G2 + tx] = a;
   }
 }
 
@@ -314,7 +323,7 @@ extern "C" int nk_groupnorm_fwd(const void* x, const float* gamma, const float* 
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, N, nz), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, part, HW, C,
                      G, rows_per);
   if (int e = nk_check_launch("gn_stats_kernel")) return e;
-  hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(64), 0, stream, part, stats, nsplit * nz, 2 * G);
+  hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(1024), 0, stream, part, stats, nsplit * nz, 2 * G);
   if (int e = nk_check_launch("gn_reduce_partials_kernel")) return e;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, N), dim3(GN_THREADS), 2 * C * sizeof(float), stream,
                      (const bf16_t*)x, stats, gamma, beta, (bf16_t*)y, mean, rstd, HW, C, G, eps, silu, rows_per);
@@ -337,7 +346,7 @@ extern "C" int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamm
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nsplit, N, nz), dim3(GN_THREADS), 2 * C * sizeof(float), stream,
                      (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, part, chan, HW, C, G, silu, rows_per);
   if (int e = nk_check_launch("gn_bwd_stats_kernel")) return e;
-  hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(64), 0, stream, part, gsum, nsplit * nz, 2 * G);
+  hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(1024), 0, stream, part, gsum, nsplit * nz, 2 * G);
   if (int e = nk_check_launch("gn_reduce_partials_kernel")) return e;
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, chan, dgamma, dbeta, N * nsplit, C);
   if (int e = nk_check_launch("colpart_reduce_kernel")) return e;

@@ -71,6 +71,7 @@ SIZE_QUERIES: dict[str, list] = {
     "nk_groupnorm_ws_floats": [i32, i32, i32, i32],
     "nk_layernorm_ws_floats": [i32, i32],
     "nk_colsum_ws_floats": [i64, i32],
+    "nk_attention_bwd_ws_floats": [adp],
 }
 
 _lib = None

@@ -477,7 +477,7 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head:
         dv = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dv is None else dv
         d.sdq, d.sdk, d.sdv, d.sdo = dq.stride(0), dk.stride(0), dv.stride(0), do.stride(0)
         d.bdq, d.bdk, d.bdv, d.bdo = Lq * dq.stride(0), Lk * dk.stride(0), Lk * dv.stride(0), Lq * do.stride(0)
-        delta = torch.empty(B, heads, Lq, dtype=torch.float32, device=do.device)
+        delta = _ws(query("nk_attention_bwd_ws_floats", C.byref(d)), do.device)
         call("nk_attention_bwd", C.byref(d), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(),
              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), _stream())
         return dq, dk, dv
