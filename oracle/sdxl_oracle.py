@@ -79,8 +79,7 @@ def attention(sd: SD, p: str, x: Tensor, context: Optional[Tensor], heads: int) 
     b, _, inner = q.shape
     d = inner // heads
     q, k, v = (t.view(b, -1, heads, d).transpose(1, 2) for t in (q, k, v))
-    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)  # attention.py:410-412
     o = o.transpose(1, 2).reshape(b, -1, inner)
     return linear(sd, p + ".to_out.0", o)
 
