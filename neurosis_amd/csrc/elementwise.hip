@@ -448,18 +448,19 @@ extern "C" int nk_edm_prepare(const float* x, const float* eps, const float* sig
 // ---- EDM loss forward + its gradient w.r.t. the network output (loss.py:142-157, functions.py:91-94)
 // D = net_out*c_out + z_t*c_skip ; loss[b] = w[b] * mean_chw((D - target)^2)
 // dnet = upstream * w[b] * 2/(C*HW) * (D - target) * c_out       (bf16 channels-last, padded channels = 0)
-__global__ __launch_bounds__(256) void edm_loss_kernel(const bf16_t* __restrict__ net_out, const float* __restrict__ zt,
-                                                       const float* __restrict__ target, const float* __restrict__ c_out,
-                                                       const float* __restrict__ c_skip, const float* __restrict__ w,
-                                                       float* __restrict__ loss, bf16_t* __restrict__ dnet, int B, int C,
-                                                       int HW, int Cpad, float upstream) {
-  __shared__ float red[4];
-  const int b = blockIdx.y;
+// one workgroup per sample (the latents are MB-sized): a fixed-order reduction keeps the loss bit-reproducible
+__global__ __launch_bounds__(1024) void edm_loss_kernel(const bf16_t* __restrict__ net_out, const float* __restrict__ zt,
+                                                        const float* __restrict__ target, const float* __restrict__ c_out,
+                                                        const float* __restrict__ c_skip, const float* __restrict__ w,
+                                                        float* __restrict__ loss, bf16_t* __restrict__ dnet, int B, int C,
+                                                        int HW, int Cpad, float upstream) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
   const float co = c_out[b], cs = c_skip[b], wb = w[b];
   const float inv_cnt = 1.0f / ((float)C * (float)HW);
   const float gscale = upstream * wb * 2.0f * inv_cnt * co;
   float acc = 0.f;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
     for (int c = 0; c < Cpad; ++c) {
       float g = 0.f;
       if (c < C) {
@@ -475,17 +476,18 @@ __global__ __launch_bounds__(256) void edm_loss_kernel(const bf16_t* __restrict_
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(&loss[b], (red[0] + red[1] + red[2] + red[3]) * inv_cnt * wb);
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    loss[b] = t * inv_cnt * wb;
+  }
 }
 extern "C" int nk_edm_loss(const void* net_out, const float* zt, const float* target, const float* c_out,
                            const float* c_skip, const float* w, float* loss, void* dnet, int B, int C, int HW, int Cpad,
                            float upstream, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(net_out && zt && target && c_out && c_skip && w && loss && B > 0 && C > 0 && HW > 0 && Cpad >= C);
-  if (hipMemsetAsync(loss, 0, sizeof(float) * B, stream) != hipSuccess) return NK_ERR_LAUNCH;
-  int bx = (HW + 255) / 256;
-  if (bx > 64) bx = 64;
-  hipLaunchKernelGGL(edm_loss_kernel, dim3(bx, B), dim3(256), 0, stream, (const bf16_t*)net_out, zt, target, c_out,
+  hipLaunchKernelGGL(edm_loss_kernel, dim3(B), dim3(1024), 0, stream, (const bf16_t*)net_out, zt, target, c_out,
                      c_skip, w, loss, (bf16_t*)dnet, B, C, HW, Cpad, upstream);
   return nk_check_launch("edm_loss");
 }

@@ -804,9 +804,12 @@ static int pick_splitk(int M, int N, int K, int max_split) {
   // on the other stream (dgrad chain vs weight-gradient stream).
   int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int nk = (K + BK - 1) / BK;
-  if (tiles >= 96) return 1;
+  int lo = 96, hi = 192;
+  if (const char* e = getenv("NK_SPLIT_LO")) lo = atoi(e);
+  if (const char* e = getenv("NK_SPLIT_HI")) hi = atoi(e);
+  if (tiles >= lo) return 1;
   int s = 1;
-  while (s < max_split && tiles * s < 192 && nk / (s * 2) >= 8) s *= 2;
+  while (s < max_split && tiles * s < hi && nk / (s * 2) >= 8) s *= 2;
   return s;
 }
 

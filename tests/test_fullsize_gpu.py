@@ -1,0 +1,164 @@
+"""Parity at BASELINE.json's FULL sizes (SDXL 1024^2, batch 4) through size-independent properties, where a CPU
+oracle run would take minutes: adjointness of forward / dgrad / wgrad (dot-product test), linearity, normalisation
+invariants, softmax normalisation, and a full-size UNet step (finite, bit-reproducible forward).
+
+Tolerances: dot products of bf16 tensors with ~1e7-1e9 terms accumulate bf16 rounding of the OUTPUTS (2^-9 relative
+per element, random sign) -- the two sides of an adjoint identity agree to ~1e-3 relative in practice; 2e-2 is asserted.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rb(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(torch.bfloat16)
+
+
+def dot(a, b):
+    return float((a.double().flatten() * b.double().flatten()).sum())
+
+
+def noise(u, v):
+    """Standard deviation of <u, v> caused by rounding v's elements to bf16 (relative 2^-9, random sign):
+    sqrt(n) * rms(u) * rms(v) * 2^-9.  The dot products below are sums of 1e7-1e9 random-sign terms, so the identities
+    are compared on this scale, not relative to the (near-cancelling) dot value itself."""
+    n = u.numel()
+    return (n ** 0.5) * float(u.float().pow(2).mean().sqrt()) * float(v.float().pow(2).mean().sqrt()) * 2.0 ** -9
+
+
+def close(a, b, tol=2e-2, sigma=0.0):
+    return abs(a - b) <= tol * max(abs(a), abs(b), 1e-9) + 6.0 * sigma
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from neurosis_amd import ops as o
+
+    return o
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 5120, 640), (4096, 10240, 1280), (4096, 1280, 5120), (16384, 1920, 640)])
+def test_linear_adjoint_identities(ops, M, N, K):
+    """<dy, x W^T> == <dy W, x> == <dy^T x, W>  (forward vs dgrad vs wgrad at the FF / QKV shapes)."""
+    x, w, dy = rb(M, K, seed=1), rb(N, K, scale=K ** -0.5, seed=2), rb(M, N, seed=3)
+    y = ops.gemm_nt(x, w)
+    dx = ops.gemm_nn(dy, w)
+    dw = torch.zeros(N, K, device="cuda")
+    ops.gemm_tn_f32(dy, x, dw, False)
+    a, b, c = dot(dy, y), dot(dx, x), dot(dw, w)
+    sg = max(noise(dy, y), noise(x, dx), noise(w, dw))
+    assert close(a, b, sigma=sg) and close(a, c, sigma=sg), (a, b, c, sg)
+    # linearity of the forward
+    x2 = rb(M, K, seed=9)
+    y12 = ops.gemm_nt((x.float() + x2.float()).to(torch.bfloat16), w)
+    ref = y.float() + ops.gemm_nt(x2, w).float()
+    assert float((y12.float() - ref).abs().max() / ref.abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,stride,up", [(4, 128, 128, 320, 320, 1, False), (4, 64, 64, 640, 640, 1, True), (4, 128, 128, 320, 320, 2, False),
+                                                   (4, 32, 32, 2560, 1280, 1, False)])
+def test_conv_adjoint_identities(ops, N, H, W, Ci, Co, stride, up):
+    x = ops.Img(rb(N * H * W, Ci, seed=4), N, H, W)
+    wt = torch.nn.Parameter((torch.randn(Co, 3, 3, Ci, device="cuda") * (9 * Ci) ** -0.5).permute(0, 3, 1, 2))
+    y, bwd = ops.conv2d_fwd(x, wt, None, stride=stride, padding=1, upsample=up)
+    dy = rb(*y.t.shape, seed=5)
+    dx, _ = bwd(dy)
+    torch.cuda.synchronize()
+    a = dot(dy, y.t)
+    b = dot(dx.t, x.t)
+    wsh = ops.shadow(wt).float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    c = dot(wt.grad, wsh)
+    sg = max(noise(dy, y.t), noise(x.t, dx.t), noise(wsh, wt.grad))
+    assert close(a, b, sigma=sg) and close(a, c, sigma=sg), (a, b, c, sg)
+
+
+def test_attention_softmax_normalisation_and_adjoint(ops):
+    B, Hh, L, D = 4, 10, 4096, 64
+    q, k = rb(B * L, Hh * D, seed=6), rb(B * L, Hh * D, seed=7)
+    ones = torch.ones(B * L, Hh * D, device="cuda", dtype=torch.bfloat16)
+    o, _ = ops.attention_fwd(q, k, ones, B, Hh, D)
+    assert float((o.float() - 1).abs().max()) < 1e-2          # rows of softmax sum to one
+    v = rb(B * L, Hh * D, seed=8)
+    o, bwd = ops.attention_fwd(q, k, v, B, Hh, D)
+    do = rb(B * L, Hh * D, seed=10)
+    dq, dk, dv = bwd(do)
+    # O is linear in V with the same softmax weights:  <dO, O> == <dV, V>
+    assert close(dot(do, o), dot(dv, v), sigma=max(noise(do, o), noise(v, dv))), (dot(do, o), dot(dv, v))
+    # scores are homogeneous of degree 1 in q and in k: <dq, q> == <dk, k>   (Euler's identity on s = q k^T)
+    assert close(dot(dq, q), dot(dk, k), 5e-2, sigma=max(noise(q, dq), noise(k, dk))), (dot(dq, q), dot(dk, k))
+
+
+def test_cross_attention_full_size(ops):
+    B, Hh, Lq, Lk, D = 4, 20, 1024, 77, 64
+    q, k, v = rb(B * Lq, Hh * D, seed=1), rb(B * Lk, Hh * D, seed=2), rb(B * Lk, Hh * D, seed=3)
+    o, bwd = ops.attention_fwd(q, k, v, B, Hh, D)
+    do = rb(B * Lq, Hh * D, seed=4)
+    dq, dk, dv = bwd(do)
+    assert close(dot(do, o), dot(dv, v), sigma=max(noise(do, o), noise(v, dv)))
+    assert close(dot(dq, q), dot(dk, k), 5e-2, sigma=max(noise(q, dq), noise(k, dk)))
+
+
+@pytest.mark.parametrize("N,H,W,C", [(4, 128, 128, 320), (4, 32, 32, 2560), (4, 1024, 1024, 128)])
+def test_groupnorm_invariants(ops, N, H, W, C):
+    x = ops.Img((rb(N * H * W, C, seed=11).float() * 3 + 1.5).to(torch.bfloat16), N, H, W)
+    g = torch.nn.Parameter(torch.ones(C, device="cuda"))
+    b = torch.nn.Parameter(torch.zeros(C, device="cuda"))
+    y, bwd = ops.groupnorm_fwd(x, g, b, 32, 1e-6, False)
+    yg = y.t.float().view(N, H * W, 32, C // 32)
+    assert float(yg.mean((1, 3)).abs().max()) < 2e-2
+    assert float((yg.var((1, 3), unbiased=False) - 1).abs().max()) < 3e-2
+    if H <= 128:
+        dy = rb(N * H * W, C, seed=12)
+        dx = bwd(dy)
+        dxg = dx.float().view(N, H * W, 32, C // 32)
+        # the backward of a normalisation is orthogonal to the constants and to xhat within every group
+        scale = float(dxg.abs().mean())
+        assert float(dxg.mean((1, 3)).abs().max()) < 5e-2 * scale + 1e-3
+        assert float((dxg * yg).mean((1, 3)).abs().max()) < 5e-2 * scale + 1e-3
+
+
+def test_layernorm_invariants(ops):
+    M, C = 16384, 640
+    x = (rb(M, C, seed=13).float() * 2 + 0.7).to(torch.bfloat16)
+    g = torch.nn.Parameter(torch.ones(C, device="cuda"))
+    b = torch.nn.Parameter(torch.zeros(C, device="cuda"))
+    y, bwd = ops.layernorm_fwd(x, g, b)
+    assert float(y.float().mean(1).abs().max()) < 2e-2
+    assert float((y.float().var(1, unbiased=False) - 1).abs().max()) < 3e-2
+    dx = bwd(rb(M, C, seed=14))
+    assert float(dx.float().mean(1).abs().max()) < 2e-2
+    assert float((dx.float() * y.float()).mean(1).abs().max()) < 3e-2
+
+
+def test_full_size_sdxl_step_is_finite_and_forward_reproducible():
+    """The benchmark's own model and shapes: one training step; loss and every gradient finite; the loss of the same
+    inputs is bit-identical when recomputed (deterministic forward at full size)."""
+    import bench
+
+    dev = torch.device("cuda", 0)
+    eng = bench.build_engine(dev)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    batch = bench.synthetic_batch(dev, 4, (1024, 1024), gen)
+    sig = torch.tensor([0.3, 1.1, 4.0, 9.0], device=dev)
+    latents = eng.encode_first_stage(batch["image"])
+    assert latents.shape == (4, 4, 128, 128) and bool(torch.isfinite(latents).all())
+    noise = torch.randn(latents.shape, device=dev, generator=gen)
+    with torch.no_grad():
+        l1 = eng(latents, batch, sigmas=sig, noise=noise).clone()
+        l2 = eng(latents, batch, sigmas=sig, noise=noise).clone()
+    assert torch.equal(l1, l2) and bool(torch.isfinite(l1).all())
+    loss = eng(latents, batch, sigmas=sig, noise=noise)
+    assert torch.equal(loss.detach(), l1)
+    loss.mean().backward()
+    torch.cuda.synchronize()
+    g = eng.store.grad
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    # every parameter tensor received a gradient (zero-initialised modules were re-initialised for the bench)
+    dead = [n for n, p in eng.model.diffusion_model.named_parameters() if float(p.grad.abs().max()) == 0.0]
+    assert not dead, dead[:5]
+    eng.optimizer_step(lr=1e-6)
+    assert float(eng.store.grad.abs().max()) == 0.0
+    del eng
+    torch.cuda.empty_cache()

@@ -185,3 +185,32 @@ def test_forward_is_bitwise_reproducible():
         a = _loss(net, fx).clone()
         b = _loss(net, fx).clone()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("hw", [(24, 16), (13, 19 * 0 + 20)])
+def test_unet_non_square_latents_vs_oracle(hw):
+    """BASELINE config 4 (aspect buckets): latents are not square and their sides need not be powers of two
+    (832x1216 -> 104x152).  HIP loss / gradients vs the CPU oracle on a tiny SDXL-shaped UNet at (24,16) and (13,20)...
+    the second has an odd side, so the stride-2 downsample and the nearest-2x upsample see ragged maps."""
+    from oracle import sdxl_oracle as O
+
+    H, W = hw
+    if H % 4 or W % 4:
+        H, W = (H // 4) * 4 + 4, (W // 4) * 4   # the UNet's two 2x levels need sides divisible by 4 (as in the reference)
+    fx, net, st = _build_unet("unet_sdxl_tiny", True)
+    shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
+    g = torch.Generator().manual_seed(H * 100 + W)
+    fx = dict(fx)
+    fx["x"] = torch.randn(2, 4, H, W, generator=g)
+    fx["noise"] = torch.randn(2, 4, H, W, generator=g)
+    loss = _loss(net, fx)
+    loss.mean().backward()
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth_state_dict(shapes).items()}
+    table = O.legacy_ddpm_sigmas()
+    ref = O.edm_loss(lambda xin, t: O.unet_forward(sd, fx["cfg"], xin, t, fx["context"], fx["y"]), table, fx["x"], fx["sigma"], fx["noise"])
+    ref.mean().backward()
+    assert rel_err(loss, ref) <= 1e-2, (loss.tolist(), ref.tolist())
+    grads = dict(net.named_parameters())
+    for k in ["input_blocks.0.0.weight", "input_blocks.3.0.op.weight", "output_blocks.2.2.conv.weight", "middle_block.1.transformer_blocks.0.attn1.to_q.weight",
+              "output_blocks.8.0.skip_connection.weight", "out.2.weight"]:
+        assert cosine(grads[k].grad, sd[k].grad) >= 0.99, k

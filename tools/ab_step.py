@@ -15,8 +15,12 @@ def main():
     variants = {}
     side = ops.state.wgrad_stream
     variants["base"] = lambda: None
-    variants["no_side_stream"] = lambda: setattr(ops.state, "wgrad_stream", None)
-    def restore(): ops.state.wgrad_stream = side
+    def setenv(lo, hi):
+        os.environ["NK_SPLIT_LO"] = str(lo); os.environ["NK_SPLIT_HI"] = str(hi)
+    variants["split_256_512"] = lambda: setenv(256, 512)
+    variants["split_512_1024"] = lambda: setenv(512, 1024)
+    variants["split_none"] = lambda: setenv(0, 0)
+    def restore(): ops.state.wgrad_stream = side; setenv(96, 192)
     for _ in range(2): step()
     res = {k: [] for k in variants}
     for rnd in range(3):

@@ -1,0 +1,38 @@
+"""Per-shape time of the tile engine inside one real training step (serialized launches, HIP events)."""
+import sys, torch, collections
+sys.path.insert(0, ".")
+import bench
+from neurosis_amd import ops
+dev = torch.device("cuda", 0)
+eng = bench.build_engine(dev)
+gen = torch.Generator(device=dev).manual_seed(42); gen_cpu = torch.Generator().manual_seed(42)
+def step():
+    batch = bench.synthetic_batch(dev, 4, (1024, 1024), gen)
+    sig = bench.draw_sigmas(4, gen_cpu, dev)
+    loss = eng.training_step(batch, 0, sigmas=sig); loss.backward(); eng.optimizer_step(lr=1e-6)
+for _ in range(2): step()
+timer = bench.GemmTimer()
+orig_flops = timer.flops
+shapes = []
+def flops(name, args):
+    if name.startswith("nk_linear"):
+        key = (name, args[5], args[6], args[7]) if name == "nk_linear_fwd" else ((name, args[4], args[5], args[6]) if name == "nk_linear_dgrad" else (name, args[3], args[4], args[5]))
+    else:
+        d = args[0]._obj
+        key = (name, d.N * d.Ho * d.Wo, d.Cout, d.KH * d.KW * d.Cin)
+    shapes.append(key)
+    return orig_flops(name, args)
+timer.flops = flops
+timer.install()
+side, ops.state.wgrad_stream = ops.state.wgrad_stream, None
+step()
+ops.state.wgrad_stream = side
+timer.uninstall()
+torch.cuda.synchronize()
+agg = collections.OrderedDict()
+for key, (name, f, s, e) in zip(shapes, timer.records):
+    a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += f; a[2] += s.elapsed_time(e)
+tot = sum(a[2] for a in agg.values())
+print(f"total {tot:.1f} ms over {len(timer.records)} launches")
+for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:40]:
+    print(f"{key[0]:16s} M/N/K={key[1]:>8d} {key[2]:>6d} {key[3]:>6d}  x{a[0]:4d}  {a[2]:7.2f} ms  {a[1]/a[2]/1e9:7.0f} TF/s  ({a[2]/a[0]*1e3:7.1f} us each)")
