@@ -230,19 +230,19 @@ struct Operand {
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
-template <int OUT_F32, int TBM = BM, int TNT = NTHREADS>
-__device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* smem, float4_t (&acc)[4][4], int m0, int n0, int tid,
+template <int OUT_F32, int TBM = BM, int TNT = NTHREADS, int NJ = 4>
+__device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* smem, float4_t (&acc)[4][NJ], int m0, int n0, int tid,
                                                  int lane, int wm, int wn) {
   // ---- epilogue: accumulators -> LDS (fp32, [128][CS_LD]) -> coalesced global stores ----
   float* cs = (float*)smem;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        int col = wn * 64 + j * 16 + (lane & 15);
+        int col = wn * (NJ * 16) + j * 16 + (lane & 15);
         cs[row * CS_LD + col] = acc[i][j][r];
       }
   __syncthreads();
@@ -439,7 +439,11 @@ struct OperandDMA {
 
   __device__ __forceinline__ int kc_row(int i) const { return wave * (NP * 8) + i * 8 + (lane >> 3); }
   __device__ __forceinline__ int kc_chunk() const { return (lane & 7) ^ (lane >> 3); }
-  __device__ __forceinline__ int mc_k(int i) const { return wave * 16 + i * 4 + (lane >> 4); }
+  __device__ __forceinline__ int mc_k(int i) const { return (wave * NP + i) * 4 + (lane >> 4); }
+  __device__ __forceinline__ int mc_var(int i) const { return (((wave * NP + i) * 4) >> 3) & 1; }   // (k >> 3) & 1 of that piece
+  // two-way selects instead of runtime-indexed arrays (hipcc puts those in scratch)
+  __device__ __forceinline__ bool mc_valid(int v) const { return v ? rvalid[1] : rvalid[0]; }
+  __device__ __forceinline__ int sel(const int (&a)[2], int v) const { return v ? a[1] : a[0]; }
   __device__ __forceinline__ int mc_chunk(int v) const { return (lane & 15) ^ (((lane >> 4) | (v << 2)) << 1); }
 
   __device__ __forceinline__ void init(const bf16_t* p, long ld_, int R_, int r0_, int tid, const NkGather& g) {
@@ -479,7 +483,6 @@ struct OperandDMA {
 
   // issue this thread's NP LDS-DMA loads of k-tile [k0, k0+BK) into the operand image at `img`
   __device__ __forceinline__ void issue(int k0, int kend, char* img, const NkGather& g, const NkTapW& tw) const {
-    static_assert(NP == 4 || MODE == OP_KC || MODE == OP_KCG, "r-contiguous modes are laid out for 4 pieces per thread");
     const bf16_t* src[NP];
     const bf16_t* zp = (const bf16_t*)nk_zero_page;
     if constexpr (MODE == OP_KC) {
@@ -503,17 +506,17 @@ struct OperandDMA {
       }
     } else if constexpr (MODE == OP_MC) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NP; ++i) {
         int k = k0 + mc_k(i);
-        const int v = i >> 1;
-        src[i] = (k < kend && rvalid[v]) ? P + (long)k * ld + r0 + mc_chunk(v) * 8 : zp;
+        const int v = mc_var(i);
+        src[i] = (k < kend && mc_valid(v)) ? P + (long)k * ld + r0 + mc_chunk(v) * 8 : zp;
       }
     } else if constexpr (MODE == OP_MCT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NP; ++i) {
         int k = k0 + mc_k(i);
-        const int v = i >> 1;
-        bool ok = k < kend && rvalid[v];
+        const int v = mc_var(i);
+        bool ok = k < kend && mc_valid(v);
         unsigned kk = ok ? (unsigned)k : 0u;
         unsigned tap = fdiv(kk, tw.fCout);
         unsigned co = kk - tap * tw.fCout.d;
@@ -521,16 +524,16 @@ struct OperandDMA {
       }
     } else {  // OP_MCG
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NP; ++i) {
         int k = k0 + mc_k(i);
-        const int v = i >> 1;
-        bool ok = (k < kend) && rvalid[v];
+        const int v = mc_var(i);
+        bool ok = (k < kend) && mc_valid(v);
         unsigned p_ = ok ? (unsigned)k : 0u;
         unsigned n = fdiv(p_, g.fHoWo);
         unsigned rem = p_ - n * g.fHoWo.d;
         unsigned ph = fdiv(rem, g.fWo);
         unsigned pw = rem - ph * g.fWo.d;
-        long off = gather_offset(g, (int)n, (int)ph * g.rs + g.off_h, (int)pw * g.rs + g.off_w, tkh[v], tkw[v], tc[v], ok);
+        long off = gather_offset(g, (int)n, (int)ph * g.rs + g.off_h, (int)pw * g.rs + g.off_w, sel(tkh, v), sel(tkw, v), sel(tc, v), ok);
         src[i] = ok ? P + off : zp;
       }
     }
@@ -564,13 +567,18 @@ struct OperandDMA {
   }
 };
 
-template <int AMODE, int BMODE, int OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_dma_kernel(const NkGemmParams p) {
+// NW = 4: waves 2x2, 64x64 per wave, 2 waves per SIMD at two workgroups per CU.
+// NW = 8: waves 2x4, 64x32 per wave, 4 waves per SIMD: same tile, same LDS, twice the waves to cover each other's
+//         DMA waits and fragment-read latency (under-filled grids run one workgroup per CU, i.e. 1 vs 2 waves per SIMD).
+template <int AMODE, int BMODE, int OUT_F32, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NJ = NW == 4 ? 4 : 2;      // 16-column MFMA tiles per wave
+  constexpr int NP = 16 / NW;              // DMA pieces per thread per operand tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NW == 4 ? (wave >> 1) : (wave >> 2), wn = NW == 4 ? (wave & 1) : (wave & 3);
 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
@@ -591,16 +599,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_dma_kernel(const NkGemmPa
   const int kend = min(p.K, kbeg + p.ksplit_len);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  OperandDMA<AMODE> opa;
-  OperandDMA<BMODE> opb;
+  OperandDMA<AMODE, NP> opa;
+  OperandDMA<BMODE, NP> opb;
   opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
   opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
 
-  float4_t acc[4][4];
+  float4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
     opa.issue(kbeg, kend, smem, p.ga, p.tw);
@@ -614,46 +622,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_dma_kernel(const NkGemmPa
     // s_waitcnt vmcnt(0) in front of ds_read_b64_tr_b16 whenever an LDS-DMA is outstanding (it cannot prove the
     // transposing read does not alias the DMA's LDS destination), which serialised the whole pipeline for the
     // r-contiguous operand modes (-22 %); with the DMA issued after the reads there is nothing outstanding to wait for.
-    bf16x8_t af[2][4], bfr[2][4];
-#ifndef ABL2_NOREAD
+    bf16x8_t af[2][4], bfr[2][NJ];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[ks][i] = OperandDMA<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[ks][j] = OperandDMA<BMODE>::frag(cur + V2_OPND_BYTES, wn * 64 + j * 16, ks, lane);
+      for (int j = 0; j < NJ; ++j) bfr[ks][j] = OperandDMA<BMODE>::frag(cur + V2_OPND_BYTES, wn * (NJ * 16) + j * 16, ks, lane);
     }
-#else
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { af[ks][i] = __builtin_bit_cast(bf16x8_t, (uint4_t){(unsigned)kt, 1u, 2u, 3u}); bfr[ks][i] = af[ks][i]; }
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#ifndef ABL2_NODMA
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * V2_STAGE_BYTES;
       opa.issue(kbeg + (kt + 1) * BK, kend, nxt, p.ga, p.tw);
       opb.issue(kbeg + (kt + 1) * BK, kend, nxt + V2_OPND_BYTES, p.gb, p.tw);
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#ifndef ABL2_NOMFMA
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-#else
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      asm volatile("" ::"v"(af[ks][0]), "v"(af[ks][1]), "v"(af[ks][2]), "v"(af[ks][3]), "v"(bfr[ks][0]), "v"(bfr[ks][1]), "v"(bfr[ks][2]), "v"(bfr[ks][3]));
-#endif
   }
   __syncthreads();
-  nk_gemm_epilogue<OUT_F32>(p, smem, acc, m0, n0, tid, lane, wm, wn);
+  nk_gemm_epilogue<OUT_F32, BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // =============================================================================================
@@ -744,7 +737,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void nk_gemm_big_kernel(const NkGemmPara
     if (++cur_stage == BIG_NSTAGE) cur_stage = 0;
   }
   __syncthreads();
-  nk_gemm_epilogue<OUT_F32, BIG_BM, BIG_NT>(p, smem, acc, m0, n0, tid, lane, wm, wn);
+  nk_gemm_epilogue<OUT_F32, BIG_BM, BIG_NT, 4>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -784,16 +777,22 @@ template <int AMODE, int BMODE, int OUT_F32>
 static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
   static bool attr_set = false;
   auto kern1 = nk_gemm_kernel<AMODE, BMODE, OUT_F32>;
-  auto kern2 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32>;
+  auto kern4 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32, 4>;
+  auto kern8 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32, 8>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern4, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
     attr_set = true;
   }
   int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, splitk, 1);
+  // 8 waves per 128x128 tile by default: measured +4..14 % over 4 waves on every SDXL shape (A/B: NK_GEMM_NW=4)
+  int nw = 8;
+  if (const char* e = getenv("NK_GEMM_NW")) nw = atoi(e);
   if (use_v1()) hipLaunchKernelGGL(kern1, grid, dim3(NTHREADS), SMEM_BYTES, stream, p);
-  else hipLaunchKernelGGL(kern2, grid, dim3(NTHREADS), V2_SMEM_BYTES, stream, p);
+  else if (nw == 8) hipLaunchKernelGGL(kern8, grid, dim3(512), V2_SMEM_BYTES, stream, p);
+  else hipLaunchKernelGGL(kern4, grid, dim3(NTHREADS), V2_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_kernel");
 }
 

@@ -187,7 +187,7 @@ def test_forward_is_bitwise_reproducible():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("hw", [(24, 16), (13, 19 * 0 + 20)])
+@pytest.mark.parametrize("hw", [(24, 16), (12, 20)])
 def test_unet_non_square_latents_vs_oracle(hw):
     """BASELINE config 4 (aspect buckets): latents are not square and their sides need not be powers of two
     (832x1216 -> 104x152).  HIP loss / gradients vs the CPU oracle on a tiny SDXL-shaped UNet at (24,16) and (13,20)...

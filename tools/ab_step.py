@@ -17,10 +17,8 @@ def main():
     variants["base"] = lambda: None
     def setenv(lo, hi):
         os.environ["NK_SPLIT_LO"] = str(lo); os.environ["NK_SPLIT_HI"] = str(hi)
-    variants["split_256_512"] = lambda: setenv(256, 512)
-    variants["split_512_1024"] = lambda: setenv(512, 1024)
-    variants["split_none"] = lambda: setenv(0, 0)
-    def restore(): ops.state.wgrad_stream = side; setenv(96, 192)
+    variants["nw4"] = lambda: os.environ.__setitem__("NK_GEMM_NW", "4")
+    def restore(): ops.state.wgrad_stream = side; setenv(96, 192); os.environ["NK_GEMM_NW"] = "8"
     for _ in range(2): step()
     res = {k: [] for k in variants}
     for rnd in range(3):
