@@ -234,6 +234,8 @@ def main():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the multi-rank control flow)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,13 +243,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from neurosis_amd import lib
     from neurosis_amd.dp import FlatDataParallel
@@ -291,7 +298,8 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank replays the step (it contains the gradient all-reduce: a collective); only rank 0 reports
         from neurosis_amd import ops as _ops
 
         timer = GemmTimer()

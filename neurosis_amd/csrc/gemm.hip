@@ -249,6 +249,20 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
 
   if constexpr (OUT_F32) {
     float* C = (float*)p.C;
+    if (!p.accumulate && (p.N & 3) == 0 && (p.ldc & 3) == 0) {
+      // plain stores: 16 B per lane, a wave covers two 256-byte row segments per instruction
+      for (int it = 0; it < (TBM * BN / 4) / TNT; ++it) {
+        int idx = tid + it * TNT;
+        int row = idx >> 5, c4 = (idx & 31) * 4;
+        int m = m0 + row, n = n0 + c4;
+        if (m < p.M && n < p.N) {
+          float4_t v = *(const float4_t*)(cs + row * CS_LD + c4);
+          v *= p.alpha;
+          *(float4_t*)(C + (long)m * p.ldc + n) = v;
+        }
+      }
+      return;
+    }
     for (int it = 0; it < (TBM * BN) / TNT; ++it) {
       int idx = tid + it * TNT;
       int row = idx >> 7, col = idx & 127;
