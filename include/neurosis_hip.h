@@ -41,6 +41,11 @@ int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add, void* dx,
 int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy, long ldx,
                     long lddw, int accumulate, void* stream);
 
+/* `count` (<= 8) weight gradients of identical shape in ONE launch: the three 1280x1280 projections of a transformer
+ * block are 100 tiles each, far below one workgroup per CU on their own.  dy / x / dw are HOST arrays of device pointers. */
+int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, int count, int M, int N, int K,
+                            long lddy, long ldx, long lddw, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * nn.Conv2d as implicit GEMM  (openaimodel.py:124 Upsample.conv, :183-190 Downsample.op, :247-301 ResBlock convs,
  * :622-624 input conv, :797-801 out conv; model.py:71-79 asymmetric-pad stride-2 conv, :98-102, :519, :540 VAE convs).

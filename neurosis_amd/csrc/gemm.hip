@@ -248,7 +248,7 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
   __syncthreads();
 
   if constexpr (OUT_F32) {
-    float* C = (float*)p.C;
+    float* C = (float*)(p.nbatch ? p.Cb[blockIdx.z] : p.C);
     if (!p.accumulate && (p.N & 3) == 0 && (p.ldc & 3) == 0) {
       // plain stores: 16 B per lane, a wave covers two 256-byte row segments per instruction
       for (int it = 0; it < (TBM * BN / 4) / TNT; ++it) {
@@ -275,7 +275,7 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
       }
     }
   } else {
-    bf16_t* C = (bf16_t*)p.C;
+    bf16_t* C = (bf16_t*)(p.nbatch ? p.Cb[blockIdx.z] : p.C);
     const bool vec = (p.N & 7) == 0;
 #pragma unroll 2
     for (int it = 0; it < (TBM * BN / 8) / TNT; ++it) {
@@ -556,6 +556,45 @@ struct OperandDMA {
       __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave * NP + i) * 1024), 16, 0, 0);
   }
 
+  // ---- running form (stream-K kernel): the k position and, for the plain strided modes, this thread's source pointers
+  // are carried from slab to slab, so a k-step costs one 64-bit add and one select per piece (operands are re-initialised
+  // inside the k loop there, which keeps hipcc from hoisting the row * ld products the way it does for issue()) ----
+  int kcur;
+  const bf16_t* rp[NP];
+  long rstep;
+  __device__ __forceinline__ void start(int k_begin) {
+    kcur = k_begin;
+    if constexpr (MODE == OP_KC) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) rp[i] = P + (long)(r0 + kc_row(i)) * ld + (k_begin + kc_chunk() * 8);
+      rstep = BK;
+    } else if constexpr (MODE == OP_MC) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) rp[i] = P + (long)(k_begin + mc_k(i)) * ld + r0 + mc_chunk(mc_var(i)) * 8;
+      rstep = (long)BK * ld;
+    }
+  }
+  __device__ __forceinline__ void issue_next(int kend, char* img, const NkGather& g, const NkTapW& tw) {
+    if constexpr (MODE == OP_KC || MODE == OP_MC) {
+      const bf16_t* zp = (const bf16_t*)nk_zero_page;
+      const bf16_t* src[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        bool ok;
+        if constexpr (MODE == OP_KC) ok = (kcur + kc_chunk() * 8 < kend) && rvalid[i];
+        else ok = (kcur + mc_k(i) < kend) && mc_valid(mc_var(i));
+        src[i] = ok ? rp[i] : zp;
+        rp[i] += rstep;
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave * NP + i) * 1024), 16, 0, 0);
+    } else {
+      issue(kcur, kend, img, g, tw);
+    }
+    kcur += BK;
+  }
+
   static __device__ __forceinline__ bf16x8_t frag(const char* img, int sub, int ks, int lane) {
     if constexpr (MODE == OP_KC || MODE == OP_KCG) {
       int row = sub + (lane & 15);
@@ -615,8 +654,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
 
   OperandDMA<AMODE, NP> opa;
   OperandDMA<BMODE, NP> opb;
-  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
-  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+  opa.init(p.nbatch ? p.Ab[blockIdx.z] : p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.nbatch ? p.Bb[blockIdx.z] : p.B, p.ldb, p.N, n0, tid, p.gb);
 
   float4_t acc[4][NJ];
 #pragma unroll
@@ -661,6 +700,311 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
   }
   __syncthreads();
   nk_gemm_epilogue<OUT_F32, BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
+}
+
+// =============================================================================================
+// stream-K main kernel (default).  Measured on the 128x128 data-parallel kernel above: a k-step costs 0.94 us per
+// round of 512 tiles, but every round also pays ~4.5 us of fixed cost (first loads from a cold pipeline, LDS-staged
+// epilogue, all 512 workgroups loading and then storing in lock-step), and the SDXL shapes quantise badly (320 tiles on
+// 512 slots; 100-tile weight gradients): 166 ms of tile-engine time per step against 79 ms at the marginal rate.
+//   * PERSISTENT workgroups (<= 2 per CU) each own an equal contiguous share of the (tile, k-step) iteration space,
+//     so the chip is full whatever the tile count; no split-K atomics, no memset, deterministic.
+//   * the LDS-DMA producer runs one slab ahead of the MFMA consumer ACROSS tile boundaries: the next tile's first
+//     slab is in flight while this tile's epilogue runs.
+//   * the epilogue goes straight from the accumulator registers to global memory: MFMA operands are swapped (D = B.A^T,
+//     so a lane holds 4 consecutive columns of one row) and one v_permlane16_swap per register pair widens that to 8
+//     consecutive columns (16 B of bf16 / 32 B of fp32 per lane) -- no LDS staging, no barrier, the ring stays free.
+//   * a tile shared by several workgroups: every workgroup but the last writes its fp32 partial (register order, fully
+//     coalesced) to the workspace and raises a flag; the LAST one (highest ticket) adds them in fixed order and runs
+//     the fused epilogue.  Workgroups walk their share from its END, so a partial is written at the start of a run and
+//     consumed at the end of the neighbour's.  A waiter only waits for LOWER-indexed workgroups of its own XCD, which the
+//     dispatcher has already handed out; the wait is bounded anyway (a failed launch is flagged, never a hang).
+// =============================================================================================
+#define SK_NT 512
+#define SK_SMEM_BYTES (2 * V2_STAGE_BYTES)
+#define SK_MAX_GRID 512
+#define SK_TILE_FLOATS (BM * BN)
+
+__device__ __forceinline__ void sk_decode(const NkGemmParams& p, int t, int ntm, int ntn, int& m0, int& n0, int& z) {
+  const int per = ntm * ntn;
+  z = p.nbatch ? t / per : 0;
+  const int wg = t - z * per;
+  const int per_group = GROUP_M * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(GROUP_M, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  m0 = (first_m + (in_group - nt * gm)) * BM;
+  n0 = nt * BN;
+}
+
+// accumulators -> global, fused bias / rowvec / residual.  acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)]
+//                                                                           [n0 + wn*32 + j*16 + (lane>>4)*4 + r]
+template <int OUT_F32>
+__device__ __forceinline__ void sk_epilogue(const NkGemmParams& p, void* Cv, float4_t (&acc)[4][2], int m0, int n0, int lane,
+                                            int wm, int wn) {
+  const int g = lane >> 4;
+  // after the row swap: lanes g=0 hold columns 0-7 of the wave's 32, g=1 16-23, g=2 8-15, g=3 24-31
+  const int n = n0 + wn * 32 + (g & 1) * 16 + (g >> 1) * 8;
+  const int mrow = m0 + wm * 64 + (lane & 15);
+  const bool n_ok = n < p.N;
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+  if constexpr (!OUT_F32) {
+    if (p.bias && n_ok) {
+      if ((p.N & 7) == 0) {
+        const float4_t b0 = *(const float4_t*)(p.bias + n), b1 = *(const float4_t*)(p.bias + n + 4);
+        bias[0] = b0[0]; bias[1] = b0[1]; bias[2] = b0[2]; bias[3] = b0[3];
+        bias[4] = b1[0]; bias[5] = b1[1]; bias[6] = b1[2]; bias[7] = b1[3];
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) bias[e] = p.bias[n + e];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // every lane takes part in the swap; the bounds predicates come after it
+      // (plain float temporaries: __builtin_bit_cast applied directly to an ext-vector element read element 0 for every r)
+      const float a_own = acc[i][0][r], b_own = acc[i][1][r];
+      auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a_own), __float_as_uint(b_own), false, false);
+      v[r] = __uint_as_float(sw[0]) * p.alpha;
+      v[4 + r] = __uint_as_float(sw[1]) * p.alpha;
+    }
+    const int m = mrow + i * 16;
+    if (!(n_ok && m < p.M)) continue;
+    if constexpr (OUT_F32) {
+      float* dst = (float*)Cv + (long)m * p.ldc + n;
+      if ((p.N & 3) == 0 && (p.ldc & 3) == 0 && n + 8 <= p.N) {
+        float4_t lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+        if (p.accumulate) { lo += *(const float4_t*)dst; hi += *(const float4_t*)(dst + 4); }
+        *(float4_t*)dst = lo;
+        *(float4_t*)(dst + 4) = hi;
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
+      }
+    } else {
+      bf16_t* C = (bf16_t*)Cv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias[e];
+      if ((p.N & 7) == 0) {
+        if (p.rowvec) {
+          unsigned b = fdiv((unsigned)m, p.fRowsPerBatch);
+          float t[8];
+          unpack8(*(const uint4_t*)(p.rowvec + (long)b * p.ld_rowvec + n), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if (p.residual) {
+          float t[8];
+          unpack8(*(const uint4_t*)(p.residual + (long)m * p.ldr + n), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        *(uint4_t*)(C + (long)m * p.ldc + n) = pack8(v);
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          float x = v[e];
+          if (p.rowvec) x += bf2f(p.rowvec[(long)fdiv((unsigned)m, p.fRowsPerBatch) * p.ld_rowvec + n + e]);
+          if (p.residual) x += bf2f(p.residual[(long)m * p.ldr + n + e]);
+          C[(long)m * p.ldc + n + e] = f2bf(x);
+        }
+      }
+    }
+  }
+}
+
+// Partial tiles travel between workgroups (possibly on different XCDs, i.e. different L2s) with agent-scope (sc1)
+// write-through stores and sc1 loads: a release FENCE would write back the whole L2 (measured: +150 us per launch).
+// Layout: [wave][q = i*2+j][lane] float4 -- every instruction moves one contiguous KiB; the eight q-planes of a wave
+// are reached with immediate offsets from the middle of its 8 KiB region.
+__device__ __forceinline__ void sk_store_partial(float* ws_tile, const float4_t (&acc)[4][2], int wave, int lane) {
+  const char* ptr = (const char*)ws_tile + wave * 8192 + 4096 + lane * 16;
+  asm volatile(
+      "global_store_dwordx4 %0, %1, off offset:-4096 sc1\n"
+      "global_store_dwordx4 %0, %2, off offset:-3072 sc1\n"
+      "global_store_dwordx4 %0, %3, off offset:-2048 sc1\n"
+      "global_store_dwordx4 %0, %4, off offset:-1024 sc1\n"
+      "global_store_dwordx4 %0, %5, off sc1\n"
+      "global_store_dwordx4 %0, %6, off offset:1024 sc1\n"
+      "global_store_dwordx4 %0, %7, off offset:2048 sc1\n"
+      "global_store_dwordx4 %0, %8, off offset:3072 sc1\n"
+      "s_waitcnt vmcnt(0)"
+      :
+      : "v"(ptr), "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[2][0]), "v"(acc[2][1]), "v"(acc[3][0]), "v"(acc[3][1])
+      : "memory");
+}
+
+__device__ __forceinline__ void sk_add_partial(const float* ws_tile, float4_t (&acc)[4][2], int wave, int lane) {
+  const char* ptr = (const char*)ws_tile + wave * 8192 + 4096 + lane * 16;
+  float4_t r0, r1, r2, r3, r4, r5, r6, r7;
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off offset:-4096 sc1\n"
+      "global_load_dwordx4 %1, %8, off offset:-3072 sc1\n"
+      "global_load_dwordx4 %2, %8, off offset:-2048 sc1\n"
+      "global_load_dwordx4 %3, %8, off offset:-1024 sc1\n"
+      "global_load_dwordx4 %4, %8, off sc1\n"
+      "global_load_dwordx4 %5, %8, off offset:1024 sc1\n"
+      "global_load_dwordx4 %6, %8, off offset:2048 sc1\n"
+      "global_load_dwordx4 %7, %8, off offset:3072 sc1\n"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"(ptr)
+      : "memory");
+  acc[0][0] += r0; acc[0][1] += r1; acc[1][0] += r2; acc[1][1] += r3;
+  acc[2][0] += r4; acc[2][1] += r5; acc[3][0] += r6; acc[3][1] += r7;
+}
+
+// One workgroup's list of (tile, k-step range) segments: first its share of the stream-K region (walked from the end),
+// then its data-parallel tiles (round r: tile dp_tile0 + r*nb + l, so the workgroups of an XCD sit on ADJACENT tiles at
+// any moment and share operand panels in L2 -- contiguous per-workgroup tile ranges measured 1.9x slower per k-step).
+struct SkCursor {
+  int sk_s, sk_end, r;
+  __device__ __forceinline__ bool next(int nk, int sk_tile0, int dp_tile0, int R, int nb, int l, int& t, int& k0, int& k1, int& ts) {
+    if (sk_end > sk_s) {
+      const int tl = (sk_end - 1) / nk;
+      ts = tl * nk;
+      const int seg_s = max(sk_s, ts);
+      k0 = seg_s - ts; k1 = sk_end - ts; sk_end = seg_s;
+      t = sk_tile0 + tl;
+      return true;
+    }
+    if (r < R) { t = dp_tile0 + r * nb + l; k0 = 0; k1 = nk; ts = 0; ++r; return true; }
+    return false;
+  }
+};
+
+template <int AMODE, int BMODE, int OUT_F32>
+__global__ __launch_bounds__(SK_NT, 4) void nk_gemm_sk_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  // Work is assigned by blockIdx: workgroup b runs on XCD b % 8 (round-robin dispatch), so (b & 7, b >> 3) keeps an XCD's
+  // workgroups on one contiguous eighth of the tile list whatever order they start in.
+  const int w = blockIdx.x;
+  const int G = gridDim.x;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int nk = (p.K + BK - 1) / BK;
+  const int T = ntm * ntn * (p.nbatch ? p.nbatch : 1);
+
+  // logical position: (xcd, l) of nb workgroups on the tile range [t0, t1)
+  int xcd = 0, l = w, nb = G, t0 = 0, t1 = T;
+  if (p.sk_chunked) {
+    xcd = w & 7; l = w >> 3; nb = G >> 3;
+    t0 = (int)(((long)T * xcd) >> 3);
+    t1 = (int)(((long)T * (xcd + 1)) >> 3);
+  }
+  const int R = (t1 - t0) / nb;                  // full data-parallel rounds
+  const int rem = (t1 - t0) - R * nb;            // tiles left for the stream-K region (< nb)
+  const int sk_tile0 = t0 + R * nb;
+  const int Wsk = rem * nk;
+  const int max_split = max(1, min(16, nk >> 3));
+  const int P = min(nb, rem * max_split);        // workgroups taking part in the stream-K region
+  auto start_of = [&](int li) -> int { return (int)(((unsigned)Wsk * (unsigned)li) / (unsigned)P); };
+  SkCursor cons;
+  cons.r = 0;
+  cons.sk_s = l < P ? start_of(l) : 0;
+  cons.sk_end = l < P ? start_of(l + 1) : 0;
+  SkCursor prod = cons;
+
+  OperandDMA<AMODE, 2> opa;
+  OperandDMA<BMODE, 2> opb;
+  // ---- producer: one slab ahead of the consumer, across segment boundaries ----
+  int p_k = 0, p_k1 = 0;
+  bool p_live = false;
+  auto p_next = [&]() {
+    int t, ts_unused;
+    p_live = prod.next(nk, sk_tile0, t0, R, nb, l, t, p_k, p_k1, ts_unused);
+    if (!p_live) return;
+    int m0, n0, z;
+    sk_decode(p, t, ntm, ntn, m0, n0, z);
+    opa.init(p.nbatch ? p.Ab[z] : p.A, p.lda, p.M, m0, tid, p.ga);
+    opb.init(p.nbatch ? p.Bb[z] : p.B, p.ldb, p.N, n0, tid, p.gb);
+    opa.start(p_k * BK);
+    opb.start(p_k * BK);
+  };
+  auto p_issue = [&](char* stage) {
+    opa.issue_next(p.K, stage, p.ga, p.tw);
+    opb.issue_next(p.K, stage + V2_OPND_BYTES, p.gb, p.tw);
+    if (++p_k == p_k1) p_next();
+  };
+
+  p_next();
+  if (p_live) p_issue(smem);
+  int slab = 0;
+  int t, k0, k1, ts;
+  while (cons.next(nk, sk_tile0, t0, R, nb, l, t, k0, k1, ts)) {
+    float4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = k0; kt < k1; ++kt, ++slab) {
+      // vmcnt(0) + barrier: this slab has landed for every wave, and every wave is done reading the other stage
+      __syncthreads();
+      const char* cur = smem + (slab & 1) * V2_STAGE_BYTES;
+      bf16x8_t af[2][4], bfr[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[ks][i] = OperandDMA<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[ks][j] = OperandDMA<BMODE>::frag(cur + V2_OPND_BYTES, wn * 32 + j * 16, ks, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (p_live) p_issue(smem + ((slab + 1) & 1) * V2_STAGE_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)   // operands swapped: D = B.A^T, a lane holds 4 consecutive COLUMNS of one row
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    }
+
+    int m0, n0, z;
+    sk_decode(p, t, ntm, ntn, m0, n0, z);
+    void* C = p.nbatch ? p.Cb[z] : p.C;
+    if (k1 < nk) {
+      // not the end of the tile: publish the partial and raise this ticket's flag
+      sk_store_partial(p.sk_ws + (size_t)w * SK_TILE_FLOATS, acc, wave, lane);
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.sk_flags + w, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (k0 > 0) {
+        // last part of a shared tile: add the partials of the workgroups before us (lower tickets: they started earlier),
+        // nearest first, down to the one that holds the tile's first k-step
+        for (int li = l - 1; li >= 0; --li) {
+          const int ticket = p.sk_chunked ? xcd + 8 * li : li;
+          const int s_li = start_of(li);
+          if (s_li < start_of(li + 1)) {   // (an empty share has nothing to add)
+            // The workgroup waited for has a LOWER index on the same XCD: the dispatcher hands workgroups out in index
+            // order, so it is running or done.  The wait is bounded all the same (~0.2 s): on expiry the launch is marked
+            // failed (checked by nk_gemm_sk_status) instead of hanging the device.
+            int spins = 0;
+            while (__hip_atomic_load(p.sk_flags + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > (1 << 21)) {
+                if (tid == 0) __hip_atomic_store(p.sk_flags + SK_MAX_GRID + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            sk_add_partial(p.sk_ws + (size_t)ticket * SK_TILE_FLOATS, acc, wave, lane);
+          }
+          if (s_li <= ts) break;
+        }
+      }
+      if (!(p.sk_debug & 1) || acc[0][0][0] == 123.456f) sk_epilogue<OUT_F32>(p, C, acc, m0, n0, lane, wm, wn);
+    }
+  }
 }
 
 // =============================================================================================
@@ -763,7 +1107,7 @@ static bool use_big(const NkGemmParams& p, int amode, int bmode, int out_f32, in
   // the 256x256 variant planned next.
   static int dis = -1;
   if (dis < 0) { const char* e = getenv("NK_GEMM_BIG"); dis = (e && e[0] == '1') ? 0 : 1; }
-  if (dis || out_f32 || splitk != 1 || bmode != OP_KC || !(amode == OP_KC || amode == OP_KCG)) return false;
+  if (dis || p.nbatch || out_f32 || splitk != 1 || bmode != OP_KC || !(amode == OP_KC || amode == OP_KCG)) return false;
   long tiles = (long)((p.M + BIG_BM - 1) / BIG_BM) * ((p.N + BN - 1) / BN);
   return tiles >= 512 && p.K >= 4 * BK;
 }
@@ -800,7 +1144,7 @@ static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
     attr_set = true;
   }
   int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  dim3 grid(ntm * ntn, splitk, 1);
+  dim3 grid(ntm * ntn, splitk, p.nbatch ? p.nbatch : 1);
   // 8 waves per 128x128 tile by default: measured +4..14 % over 4 waves on every SDXL shape (A/B: NK_GEMM_NW=4)
   int nw = 8;
   if (const char* e = getenv("NK_GEMM_NW")) nw = atoi(e);
@@ -808,6 +1152,92 @@ static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
   else if (nw == 8) hipLaunchKernelGGL(kern8, grid, dim3(512), V2_SMEM_BYTES, stream, p);
   else hipLaunchKernelGGL(kern4, grid, dim3(NTHREADS), V2_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_kernel");
+}
+
+
+// ---- stream-K workspace: one per stream (launches on one stream are ordered; two streams run concurrently) ----
+#include <mutex>
+#include <unordered_map>
+struct SkWorkspace {
+  unsigned* counter = nullptr;
+  unsigned* flags = nullptr;
+  float* ws = nullptr;
+  unsigned base = 0, epoch = 0;
+};
+static std::mutex sk_mutex;
+static std::unordered_map<void*, SkWorkspace> sk_spaces;
+
+// NK_GEMM_SK: 0 = never, 1 = always, 2 = fp32 outputs (weight gradients) only, 3 = by shape, 4 (default) = by shape and
+// bf16 outputs only (weight gradients run on the side stream, where non-persistent grids back-fill the main stream's
+// kernels: measured 203.7 ms/step vs 206.3 without stream-K, 211 with it on every kernel).  By shape:
+// stream-K where the data-parallel grid fills the chip badly or would need split-K, the plain kernel for big grids
+// (measured 5-19 % faster there: its workgroups drift out of phase, the persistent ones load and store in lock-step).
+static bool use_sk(const NkGemmParams& p, int out_f32) {
+  int mode = 4;
+  if (const char* e = getenv("NK_GEMM_SK")) mode = atoi(e);   // read per call: tools/ab_step.py flips it in-process
+  if (mode == 0) return false;
+  if (mode == 1) return true;
+  if (mode == 2) return out_f32 != 0;
+  if (mode == 4 && out_f32) return false;     // by shape, bf16 outputs (main-stream forward / dgrad) only
+  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.nbatch ? p.nbatch : 1);
+  const long nk = (p.K + BK - 1) / BK;
+  const long rounds = (tiles + 511) / 512;
+  const double fill = (double)tiles / (double)(rounds * 512);
+  if (tiles >= 1024 && fill >= 0.8) return false;
+  if (tiles >= 512 && fill >= 0.95) return false;
+  return nk >= 24;    // a fix-up costs about as much as 6-8 k-steps
+}
+
+static int sk_prepare(NkGemmParams& p, int grid, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(sk_mutex);
+  SkWorkspace& w = sk_spaces[(void*)stream];
+  if (!w.ws) {
+    char* raw = nullptr;
+    const size_t ws_bytes = (size_t)SK_MAX_GRID * SK_TILE_FLOATS * sizeof(float);
+    if (hipMalloc((void**)&raw, ws_bytes + (SK_MAX_GRID + 64) * sizeof(unsigned)) != hipSuccess) {
+      nk_set_error(__FILE__, __LINE__, "hipMalloc of the stream-K workspace failed");
+      return NK_ERR_LAUNCH;
+    }
+    w.ws = (float*)raw;
+    w.flags = (unsigned*)(raw + ws_bytes);
+    w.counter = w.flags + SK_MAX_GRID;
+    if (hipMemset(w.flags, 0, (SK_MAX_GRID + 64) * sizeof(unsigned)) != hipSuccess) return NK_ERR_LAUNCH;
+  }
+  w.epoch += 1;
+  if (w.epoch == 0) w.epoch = 1;   // 0 is the flags' initial value
+  p.sk_counter = w.counter;
+  p.sk_flags = w.flags;
+  p.sk_ws = w.ws;
+  p.sk_base = w.base;
+  p.sk_epoch = w.epoch;
+  w.base += (unsigned)grid;
+  return NK_OK;
+}
+
+template <int AMODE, int BMODE, int OUT_F32>
+static int launch_sk(NkGemmParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = nk_gemm_sk_kernel<AMODE, BMODE, OUT_F32>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SK_SMEM_BYTES);
+    attr_set = true;
+  }
+  const long ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nk = (p.K + BK - 1) / BK;
+  const long T = ntm * ntn * (p.nbatch ? p.nbatch : 1), W = T * nk;
+  // persistent grid: two workgroups per CU, at least ~4 k-steps each
+  int max_grid = SK_MAX_GRID, min_iters = 4;
+  if (const char* e = getenv("NK_SK_GRID")) max_grid = atoi(e);
+  if (max_grid < 8 || max_grid > SK_MAX_GRID) max_grid = SK_MAX_GRID;
+  max_grid &= ~7;
+  if (const char* m = getenv("NK_SK_MIN_ITERS")) min_iters = atoi(m) > 0 ? atoi(m) : 4;
+  long grid = (W / min_iters) & ~7l;
+  if (grid > max_grid) grid = max_grid;
+  if (grid < 8) grid = 8;
+  p.sk_chunked = T >= 64;
+  { const char* d = getenv("NK_SK_DEBUG"); p.sk_debug = d ? atoi(d) : 0; }
+  if (int e = sk_prepare(p, (int)grid, stream)) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SK_NT), SK_SMEM_BYTES, stream, p);
+  return nk_check_launch("nk_gemm_sk_kernel");
 }
 
 static int pick_splitk(int M, int N, int K, int max_split) {
@@ -835,7 +1265,8 @@ static void set_split(NkGemmParams& p, int splitk) {
 int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int allow_splitk,
                      hipStream_t stream) {
   NK_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0);
-  NK_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && ((uintptr_t)p.C & 15) == 0);
+  if (!p.nbatch) NK_CHECK_ARG(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && ((uintptr_t)p.C & 15) == 0);
+  for (int z = 0; z < p.nbatch; ++z) NK_CHECK_ARG(((uintptr_t)p.Ab[z] & 15) == 0 && ((uintptr_t)p.Bb[z] & 15) == 0 && ((uintptr_t)p.Cb[z] & 15) == 0);
   // 16-byte chunk rules: k-contiguous operands need K % 8 == 0 and ld % 8 == 0; r-contiguous ones R % 8 == 0
   if (amode == OP_KC) NK_CHECK_ARG((p.K & 7) == 0 && (p.lda & 7) == 0);
   if (bmode == OP_KC) NK_CHECK_ARG((p.K & 7) == 0 && (p.ldb & 7) == 0);
@@ -848,15 +1279,32 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   if (!out_f32) NK_CHECK_ARG((p.ldc & 7) == 0 || (p.N & 7) != 0);
   if (p.fRowsPerBatch.d == 0) p.fRowsPerBatch = make_fastdiv(1);
 
+  if (!use_v1() && use_sk(p, out_f32)) {
+    const long ntm_ = (p.M + BM - 1) / BM, ntn_ = (p.N + BN - 1) / BN, nk_ = (p.K + BK - 1) / BK;
+    if (ntm_ * ntn_ * (p.nbatch ? p.nbatch : 1) * nk_ < (1l << 22)) {   // share arithmetic is 32-bit: W * grid < 2^31
+      if (p.accumulate == 2) p.accumulate = 0;     // "destination known zero" only matters to the atomic split-K path
+#define NK_SK_CASE(A_, B_)                                                        \
+      if (amode == A_ && bmode == B_) return out_f32 ? launch_sk<A_, B_, 1>(p, stream) : launch_sk<A_, B_, 0>(p, stream);
+      NK_SK_CASE(OP_KC, OP_KC)
+      NK_SK_CASE(OP_KC, OP_MC)
+      NK_SK_CASE(OP_MC, OP_MC)
+      NK_SK_CASE(OP_KCG, OP_KC)
+      NK_SK_CASE(OP_KCG, OP_MCT)
+      NK_SK_CASE(OP_MC, OP_MCG)
+#undef NK_SK_CASE
+    }
+  }
   int splitk = 1;
-  if (out_f32 && allow_splitk) splitk = pick_splitk(p.M, p.N, p.K, 32);
+  if (out_f32 && allow_splitk) splitk = pick_splitk(p.M * (p.nbatch ? p.nbatch : 1), p.N, p.K, 32);
+  if (p.nbatch) NK_CHECK_ARG(p.nbatch <= NK_MAX_BATCH && !use_v1());
   set_split(p, splitk);
   // accumulate: 0 = overwrite, 1 = add, 2 = the destination is known to be zero (flat gradient buffer right after
   // zero_grad): plain stores when there is a single K split, atomics otherwise -- and no memset either way
   if (out_f32 && splitk > 1 && p.accumulate == 0) {
     // split-K partials are summed with fp32 atomics, which need a zeroed destination
     NK_CHECK_ARG(p.ldc == p.N);
-    if (hipMemsetAsync(p.C, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess) return NK_ERR_LAUNCH;
+    for (int z = 0; z < (p.nbatch ? p.nbatch : 1); ++z)
+      if (hipMemsetAsync(p.nbatch ? p.Cb[z] : p.C, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess) return NK_ERR_LAUNCH;
     p.accumulate = 1;
   } else if (p.accumulate == 2) {
     p.accumulate = splitk > 1 ? 1 : 0;

@@ -40,7 +40,21 @@ struct NkGemmParams {
   FastDiv fRowsPerBatch;
   int ksplit_len;
   int accumulate;           // fp32 output: 0 = store, 1 = atomic add
+  // batched launch: blockIdx.z selects one of nbatch (<= NK_MAX_BATCH) problems of identical shape
+  int nbatch;
+  const bf16_t* Ab[8];
+  const bf16_t* Bb[8];
+  void* Cb[8];
+  // stream-K (nk_gemm_sk_kernel): per-stream workspace owned by the dispatcher
+  unsigned* sk_counter;     // ticket counter (monotonic across launches)
+  unsigned sk_base;         // its value before this launch
+  unsigned* sk_flags;       // [grid] flag[ticket] == sk_epoch once that workgroup's partial tile is in sk_ws
+  unsigned sk_epoch;
+  float* sk_ws;             // [grid][128*128] fp32 partial tiles in accumulator-register order
+  int sk_chunked;           // 1: each XCD owns a contiguous eighth of the tile list
+  int sk_debug;             // ablation switches (NK_SK_DEBUG): 1 = no epilogue stores, 2 = no fixup exchange
 };
+#define NK_MAX_BATCH 8
 
 enum { NK_OP_KC = 0, NK_OP_KCG = 1, NK_OP_MC = 2, NK_OP_MCT = 3, NK_OP_MCG = 4 };
 

@@ -53,6 +53,26 @@ extern "C" int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, 
   return nk_gemm_dispatch(p, NK_OP_MC, NK_OP_MC, 1, lddw == K, (hipStream_t)stream);
 }
 
+extern "C" int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, int count, int M,
+                                       int N, int K, long lddy, long ldx, long lddw, int accumulate, void* stream) {
+  // `count` weight gradients of IDENTICAL shape in one launch (blockIdx.z): dw[i][N,K] (+)= dy[i][M,N]^T @ x[i][M,K].
+  // Host pointer arrays; the device pointers are copied into the kernel arguments.
+  NK_CHECK_ARG(dy && x && dw && count >= 1 && count <= NK_MAX_BATCH);
+  NkGemmParams p = zero_params();
+  p.lda = lddy; p.ldb = ldx;
+  p.M = N; p.N = K; p.K = M;
+  p.ldc = lddw;
+  p.accumulate = accumulate;
+  p.nbatch = count;
+  for (int i = 0; i < count; ++i) {
+    p.Ab[i] = (const bf16_t*)dy[i];
+    p.Bb[i] = (const bf16_t*)x[i];
+    p.Cb[i] = dw[i];
+  }
+  p.A = p.Ab[0]; p.B = p.Bb[0]; p.C = p.Cb[0];
+  return nk_gemm_dispatch(p, NK_OP_MC, NK_OP_MC, 1, lddw == K, (hipStream_t)stream);
+}
+
 static int check_conv(const NkConvDesc* d) {
   NK_CHECK_ARG(d != nullptr);
   NK_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0);

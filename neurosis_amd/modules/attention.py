@@ -149,7 +149,10 @@ class CrossAttention(nn.Module):
                     ops.gemm_tn_f32(dv, ctx, ops.g2d(wv), acc())
 
                 ops.on_wgrad_stream(wg_kv, dk, dv, ctx)
-            ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dq, x, ops.g2d(wq), acc()), dq, x)
+            if ops._wgrad_queue is not None and dq.is_contiguous() and x.is_contiguous():
+                ops._wgrad_queue.add(dq, x, ops.g2d(wq))
+            else:
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dq, x, ops.g2d(wq), acc()), dq, x)
             dx = ops.gemm_nn(dq, ops.w2d(wq))
             dctx = None
             if self_attn or need_dctx:
@@ -222,11 +225,12 @@ class BasicTransformerBlock(nn.Module):
         y, b_ff = self.ff.fwd(n3, residual=a2)
 
         def bwd(dy: Tensor):
-            da2 = b_n3(b_ff(dy), dy)           # LN3 backward + the residual branch of x + ff(...)
-            dn2, dctx2 = b_a2(da2)
-            da1 = b_n2(dn2, da2)
-            dn1, dctx1 = b_a1(da1)
-            dx = b_n1(dn1, da1)
+            with ops.batched_wgrads():          # same-shape weight gradients of this block go out as one launch
+                da2 = b_n3(b_ff(dy), dy)       # LN3 backward + the residual branch of x + ff(...)
+                dn2, dctx2 = b_a2(da2)
+                da1 = b_n2(dn2, da2)
+                dn1, dctx1 = b_a1(da1)
+                dx = b_n1(dn1, da1)
             dctx = dctx2
             if dctx1 is not None:
                 dctx = dctx1 if dctx is None else ops.add(dctx, dctx1)

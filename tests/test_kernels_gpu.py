@@ -72,6 +72,23 @@ def test_linear_wgrad(ops, M, N, K):
     assert_close(dw, 2 * ref, TOL_F32, "linear_wgrad accumulate")
 
 
+@pytest.mark.parametrize("M,N,K,count", [(1024, 256, 384, 3), (64, 128, 128, 8), (4096, 1280, 1280, 3)])
+def test_linear_wgrad_batched(ops, M, N, K, count, monkeypatch):
+    """`count` same-shape weight gradients in one launch (blockIdx.z) == the launches one by one; also through the queue."""
+    monkeypatch.setattr(ops.state, "assume_zeroed", False)  # an engine built by an earlier test leaves "grads are zero" set
+    monkeypatch.setattr(ops.state, "grad_accumulate", False)
+    dys, xs = [rnd(M, N) for _ in range(count)], [rnd(M, K) for _ in range(count)]
+    q = ops.WgradQueue()
+    dws = [torch.full((N, K), 3.0, device="cuda") for _ in range(count)]
+    for dy, x, dw in zip(dys, xs, dws):
+        q.add(dev(dy), dev(x), dw)
+    q.add(dev(rnd(M, 2 * N)), dev(rnd(M, K)), torch.zeros(2 * N, K, device="cuda"))  # an odd shape rides along unbatched
+    q.flush()
+    ops.join_wgrad_stream()
+    for dy, x, dw in zip(dys, xs, dws):
+        assert_close(dw, dy.t() @ x, TOL_F32, "linear_wgrad_batched")
+
+
 def test_colsum(ops):
     dy = rnd(5000, 2560)
     out = torch.zeros(2560, device="cuda")

@@ -1,6 +1,6 @@
 """Per-shape time of the tile engine inside one real training step (serialized launches, HIP events)."""
 import sys, torch, collections
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from neurosis_amd import ops
 dev = torch.device("cuda", 0)
@@ -34,5 +34,7 @@ for key, (name, f, s, e) in zip(shapes, timer.records):
     a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += f; a[2] += s.elapsed_time(e)
 tot = sum(a[2] for a in agg.values())
 print(f"total {tot:.1f} ms over {len(timer.records)} launches")
+import json
+json.dump([[list(k), a] for k, a in agg.items()], open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'gemm_shapes.json'), 'w'))
 for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:40]:
     print(f"{key[0]:16s} M/N/K={key[1]:>8d} {key[2]:>6d} {key[3]:>6d}  x{a[0]:4d}  {a[2]:7.2f} ms  {a[1]/a[2]/1e9:7.0f} TF/s  ({a[2]/a[0]*1e3:7.1f} us each)")
