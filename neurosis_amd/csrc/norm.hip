@@ -34,7 +34,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
   const int chunk = tid % cpr, rsub = tid / cpr;
   if (rsub < rows_par) {
     const bf16_t* base = x + ((long)n * HW) * C + (ch0 + chunk) * 8;
-    for (int r = row_lo + rsub; r < row_hi; r += rows_par) {
+    int r = row_lo + rsub;
+    for (; r + 3 * rows_par < row_hi; r += 4 * rows_par) {   // four rows' loads in flight per thread
+      uint4_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const uint4_t*)(base + (long)(r + u * rows_par) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+      }
+    }
+    for (; r < row_hi; r += rows_par) {
       float f[8];
       unpack8(*(const uint4_t*)(base + (long)r * C), f);
 #pragma unroll
@@ -108,13 +121,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
   const int cpr = C >> 3;
   const int row_lo = blockIdx.x * rows_per;
   const int row_hi = min(HW, row_lo + rows_per);
-  const long total = (long)(row_hi - row_lo) * cpr;
+  const unsigned total = (unsigned)(row_hi - row_lo) * (unsigned)cpr;
   const bf16_t* xb = x + ((long)n * HW + row_lo) * C;
   bf16_t* yb = y + ((long)n * HW + row_lo) * C;
-  for (long i = tid; i < total; i += GN_THREADS) {
-    int chunk = (int)(i % cpr);
+  auto one = [&](unsigned i, const uint4_t& raw) {
+    const unsigned chunk = i % (unsigned)cpr;
     float f[8];
-    unpack8(*(const uint4_t*)(xb + i * 8), f);
+    unpack8(raw, f);
     const float4_t a0 = *(const float4_t*)(sc + chunk * 8), a1 = *(const float4_t*)(sc + chunk * 8 + 4);
     const float4_t b0 = *(const float4_t*)(sh + chunk * 8), b1 = *(const float4_t*)(sh + chunk * 8 + 4);
     f[0] = f[0] * a0[0] + b0[0]; f[1] = f[1] * a0[1] + b0[1]; f[2] = f[2] * a0[2] + b0[2]; f[3] = f[3] * a0[3] + b0[3];
@@ -123,8 +136,17 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
     }
-    *(uint4_t*)(yb + i * 8) = pack8(f);
+    *(uint4_t*)(yb + (size_t)i * 8) = pack8(f);
+  };
+  unsigned i = tid;
+  for (; i + 3 * GN_THREADS < total; i += 4 * GN_THREADS) {   // four 16-byte loads in flight per thread
+    uint4_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const uint4_t*)(xb + (size_t)(i + u * GN_THREADS) * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(i + u * GN_THREADS, v[u]);
   }
+  for (; i < total; i += GN_THREADS) one(i, *(const uint4_t*)(xb + (size_t)i * 8));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -162,10 +184,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_stats_kernel(const bf16_t* 
       ga[e] = gamma[c]; be[e] = beta[c];
     }
     const long base = ((long)n * HW) * C + (ch0 + chunk) * 8;
-    for (int r = row_lo + rsub; r < row_hi; r += rows_par) {
+    auto one = [&](const uint4_t& rx, const uint4_t& rd) {
       float fx[8], fd[8];
-      unpack8(*(const uint4_t*)(x + base + (long)r * C), fx);
-      unpack8(*(const uint4_t*)(dy + base + (long)r * C), fd);
+      unpack8(rx, fx);
+      unpack8(rd, fd);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float xh = (fx[e] - mu[e]) * rs[e];
@@ -174,7 +196,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_stats_kernel(const bf16_t* 
         a[e] += dz;
         b[e] += dz * xh;
       }
+    };
+    int r = row_lo + rsub;
+    for (; r + 3 * rows_par < row_hi; r += 4 * rows_par) {   // eight 16-byte loads in flight per thread
+      uint4_t vx[4], vd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        vx[u] = *(const uint4_t*)(x + base + (long)(r + u * rows_par) * C);
+        vd[u] = *(const uint4_t*)(dy + base + (long)(r + u * rows_par) * C);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(vx[u], vd[u]);
     }
+    for (; r < row_hi; r += rows_par) one(*(const uint4_t*)(x + base + (long)r * C), *(const uint4_t*)(dy + base + (long)r * C));
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       pa[(rsub * cpr + chunk) * 8 + e] = a[e];
@@ -214,6 +248,7 @@ __global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* __res
   const int c = blockIdx.x * 64 + tx;
   float a = 0.f, b = 0.f;
   if (c < C) {
+#pragma unroll 4
     for (int r = ty; r < nrows; r += 16) {
       a += part[(long)r * 2 * C + c];
       b += part[(long)r * 2 * C + C + c];
@@ -261,25 +296,41 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_apply_kernel(const bf16_t* 
   const int cpr = C >> 3;
   const int row_lo = blockIdx.x * rows_per;
   const int row_hi = min(HW, row_lo + rows_per);
-  const long total = (long)(row_hi - row_lo) * cpr;
+  const unsigned total = (unsigned)(row_hi - row_lo) * (unsigned)cpr;
   const long off0 = ((long)n * HW + row_lo) * C;
-  for (long i = tid; i < total; i += GN_THREADS) {
-    int c0 = (int)(i % cpr) * 8;
+  auto one = [&](unsigned i, const uint4_t& rx, const uint4_t& rd, const uint4_t& ra) {
+    const int c0 = (int)(i % (unsigned)cpr) * 8;
     float fx[8], fd[8], fa[8];
-    unpack8(*(const uint4_t*)(x + off0 + i * 8), fx);
-    unpack8(*(const uint4_t*)(dy + off0 + i * 8), fd);
-    if (dx_add) unpack8(*(const uint4_t*)(dx_add + off0 + i * 8), fa);
+    unpack8(rx, fx);
+    unpack8(rd, fd);
+    unpack8(ra, fa);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       int c = c0 + e;
       float xh = (fx[e] - p_mu[c]) * p_rs[c];
       float dz = fd[e];
       if (silu) dz *= dsilu_f(xh * p_ga[c] + p_be[c]);
-      float v = p_rs[c] * (dz * p_ga[c] - (p_s1[c] + xh * p_s2[c]));
-      if (dx_add) v += fa[e];
-      fx[e] = v;
+      fx[e] = p_rs[c] * (dz * p_ga[c] - (p_s1[c] + xh * p_s2[c])) + fa[e];
     }
-    *(uint4_t*)(dx + off0 + i * 8) = pack8(fx);
+    *(uint4_t*)(dx + off0 + (size_t)i * 8) = pack8(fx);
+  };
+  const uint4_t zero4 = {0u, 0u, 0u, 0u};
+  unsigned i = tid;
+  for (; i + GN_THREADS < total; i += 2 * GN_THREADS) {   // two chunks (4-6 loads of 16 bytes) in flight per thread
+    uint4_t vx[2], vd[2], va[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t o = off0 + (size_t)(i + u * GN_THREADS) * 8;
+      vx[u] = *(const uint4_t*)(x + o);
+      vd[u] = *(const uint4_t*)(dy + o);
+      va[u] = dx_add ? *(const uint4_t*)(dx_add + o) : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) one(i + u * GN_THREADS, vx[u], vd[u], va[u]);
+  }
+  for (; i < total; i += GN_THREADS) {
+    const size_t o = off0 + (size_t)i * 8;
+    one(i, *(const uint4_t*)(x + o), *(const uint4_t*)(dy + o), dx_add ? *(const uint4_t*)(dx_add + o) : zero4);
   }
 }
 
@@ -361,6 +412,9 @@ extern "C" int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamm
 // ------------------------------------------------------------------------------------------------
 #define LN_MAXCH 4   // 16-byte chunks per lane: C <= 64*8*4 = 2048
 
+// NCH = 16-byte chunks per lane actually needed (2: C <= 1024, 3: <= 1536, 4: <= 2048): the per-lane arrays are sized by
+// it, which is what decides the register count and with it how many rows a CU keeps in flight.
+template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
@@ -371,10 +425,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   const int cpr = C >> 3;
   const float invC = 1.0f / (float)C;
   for (int row = wave; row < M; row += nwaves) {
-    float f[LN_MAXCH][8];
+    float f[NCH][8];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       int ch = lane + 64 * j;
       if (ch < cpr) {
         unpack8(*(const uint4_t*)(x + (long)row * C + ch * 8), f[j]);
@@ -385,7 +439,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     const float mu = wave_sum(s) * invC;
     float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       int ch = lane + 64 * j;
       if (ch < cpr) {
 #pragma unroll
@@ -395,133 +449,182 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     const float rs = rsqrtf(wave_sum(v) * invC + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
-    for (int j = 0; j < LN_MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       int ch = lane + 64 * j;
       if (ch < cpr) {
+        const float4_t g0 = *(const float4_t*)(gamma + ch * 8), g1 = *(const float4_t*)(gamma + ch * 8 + 4);
+        const float4_t b0 = *(const float4_t*)(beta + ch * 8), b1 = *(const float4_t*)(beta + ch * 8 + 4);
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (f[j][e] - mu) * rs * gamma[ch * 8 + e] + beta[ch * 8 + e];
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (f[j][e] - mu) * rs * g0[e] + b0[e];
+          o[4 + e] = (f[j][4 + e] - mu) * rs * g1[e] + b1[e];
+        }
         *(uint4_t*)(y + (long)row * C + ch * 8) = pack8(o);
       }
     }
   }
 }
 
-// dx = rstd * (dy*gamma - mean_c(dy*gamma) - xhat * mean_c(dy*gamma*xhat)) (+ dx_add);
-// dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy   (per-lane register partials -> LDS -> atomics)
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
-                                                     bf16_t* __restrict__ dx, float* __restrict__ dgamma /* partial ws */,
-                                                     int M, int C) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* lg = (float*)smem_raw;   // [4 waves][C]
-  float* lb = lg + 4 * C;         // [4 waves][C]
+// LayerNorm backward, input gradient:
+// dx = rstd * (dy*gamma - mean_c(dy*gamma) - xhat * mean_c(dy*gamma*xhat)) (+ dx_add).  One wavefront per row; x and dy stay
+// in registers as packed bf16 between the statistics pass and the output pass.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
+                                                        bf16_t* __restrict__ dx, int M, int C) {
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int cpr = C >> 3;
   const float invC = 1.0f / (float)C;
-  float ag[LN_MAXCH][8], ab[LN_MAXCH][8], gm[LN_MAXCH][8];
+  float gm[NCH][8];
 #pragma unroll
-  for (int j = 0; j < LN_MAXCH; ++j) {
+  for (int j = 0; j < NCH; ++j) {
     int ch = lane + 64 * j;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      ag[j][e] = 0.f; ab[j][e] = 0.f;
-      gm[j][e] = ch < cpr ? gamma[ch * 8 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) gm[j][e] = 0.f;
+    if (ch < cpr) {
+      const float4_t g0 = *(const float4_t*)(gamma + ch * 8), g1 = *(const float4_t*)(gamma + ch * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gm[j][e] = g0[e]; gm[j][4 + e] = g1[e]; }
     }
   }
   for (int row = wave; row < M; row += nwaves) {
     const float mu = mean[row], rs = rstd[row];
-    float xh[LN_MAXCH][8], dg[LN_MAXCH][8];
+    uint4_t rx[NCH], rd[NCH], ra[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int ch = lane + 64 * j;
+      rx[j] = rd[j] = ra[j] = (uint4_t){0u, 0u, 0u, 0u};
+      if (ch < cpr) {
+        rx[j] = *(const uint4_t*)(x + (long)row * C + ch * 8);
+        rd[j] = *(const uint4_t*)(dy + (long)row * C + ch * 8);
+        if (dx_add) ra[j] = *(const uint4_t*)(dx_add + (long)row * C + ch * 8);
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXCH; ++j) {
-      int ch = lane + 64 * j;
-      if (ch < cpr) {
-        float fx[8], fd[8];
-        unpack8(*(const uint4_t*)(x + (long)row * C + ch * 8), fx);
-        unpack8(*(const uint4_t*)(dy + (long)row * C + ch * 8), fd);
+    for (int j = 0; j < NCH; ++j) {
+      float fx[8], fd[8];
+      unpack8(rx[j], fx);
+      unpack8(rd[j], fd);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float h = (fx[e] - mu) * rs;
-          xh[j][e] = h;
-          ab[j][e] += fd[e];
-          ag[j][e] += fd[e] * h;
-          float d = fd[e] * gm[j][e];
-          dg[j][e] = d;
-          s1 += d;
-          s2 += d * h;
-        }
+      for (int e = 0; e < 8; ++e) {   // lanes past the row hold zeros (dy = 0), so they add nothing
+        float d = fd[e] * gm[j][e];
+        s1 += d;
+        s2 += d * ((fx[e] - mu) * rs);
       }
     }
     s1 = wave_sum(s1) * invC;
     s2 = wave_sum(s2) * invC;
 #pragma unroll
-    for (int j = 0; j < LN_MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       int ch = lane + 64 * j;
       if (ch < cpr) {
-        float o[8];
-        if (dx_add) unpack8(*(const uint4_t*)(dx_add + (long)row * C + ch * 8), o);
-        else {
+        float fx[8], fd[8], o[8];
+        unpack8(rx[j], fx);
+        unpack8(rd[j], fd);
+        unpack8(ra[j], o);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += rs * (dg[j][e] - s1 - xh[j][e] * s2);
+        for (int e = 0; e < 8; ++e) o[e] += rs * (fd[e] * gm[j][e] - s1 - (fx[e] - mu) * rs * s2);
         *(uint4_t*)(dx + (long)row * C + ch * 8) = pack8(o);
       }
     }
   }
+}
+
+// LayerNorm backward, parameter gradients: part[split][0][c] = sum_rows dy*xhat, part[split][1][c] = sum_rows dy over the
+// split's 64 rows.  Block = 16 row lanes x 16 chunk lanes (256 contiguous bytes per row lane, four rows in flight per
+// thread); splits are combined by colpart_reduce_kernel (single writer per channel, deterministic).
+#define LNP_ROWS 64
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ part, int M, int C) {
+  __shared__ float pg[16][16 * 8 + 4], pb[16][16 * 8 + 4];
+  const int tid = threadIdx.x;
+  const int cx = tid & 15, ry = tid >> 4;
+  const int chunk = blockIdx.y * 16 + cx;
+  const bool cok = chunk < (C >> 3);
+  const int row_lo = blockIdx.x * LNP_ROWS;
+  float sg[8], sb[8];
 #pragma unroll
-  for (int j = 0; j < LN_MAXCH; ++j) {
-    int ch = lane + 64 * j;
-    if (ch < cpr) {
+  for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sb[e] = 0.f; }
+  if (cok) {
+    uint4_t vx[4], vd[4];
+    float mu[4], rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = row_lo + ry + 16 * i;
+      const bool ok = r < M;
+      vx[i] = ok ? *(const uint4_t*)(x + (long)r * C + chunk * 8) : (uint4_t){0u, 0u, 0u, 0u};
+      vd[i] = ok ? *(const uint4_t*)(dy + (long)r * C + chunk * 8) : (uint4_t){0u, 0u, 0u, 0u};
+      mu[i] = ok ? mean[r] : 0.f;
+      rs[i] = ok ? rstd[r] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float fx[8], fd[8];
+      unpack8(vx[i], fx);
+      unpack8(vd[i], fd);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        lg[wv * C + ch * 8 + e] = ag[j][e];
-        lb[wv * C + ch * 8 + e] = ab[j][e];
+        sb[e] += fd[e];
+        sg[e] += fd[e] * ((fx[e] - mu[i]) * rs[i]);
       }
     }
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { pg[ry][cx * 8 + e] = sg[e]; pb[ry][cx * 8 + e] = sb[e]; }
   __syncthreads();
-  // per-block partials part[blockIdx.x][2][C] (waves combined in a fixed order); reduced by colpart_reduce_kernel
-  float* part = dgamma + (long)blockIdx.x * 2 * C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    part[c] = (lg[c] + lg[C + c]) + (lg[2 * C + c] + lg[3 * C + c]);
-    part[C + c] = (lb[c] + lb[C + c]) + (lb[2 * C + c] + lb[3 * C + c]);
+  if (tid < 128) {
+    const int c = blockIdx.y * 128 + tid;
+    if (c < C) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { a += pg[r][tid]; b += pb[r][tid]; }
+      float* out = part + (long)blockIdx.x * 2 * C;
+      out[c] = a;
+      out[C + c] = b;
+    }
   }
 }
+
+static int ln_param_split(int M) { return (M + LNP_ROWS - 1) / LNP_ROWS; }
 
 extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                 float* rstd, int M, int C, float eps, void* stream) {
   NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
   NK_CHECK_ARG(x && gamma && beta && y && mean && rstd);
-  int blocks = min((M + 3) / 4, 2048);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
-                     (bf16_t*)y, mean, rstd, M, C, eps);
+  int blocks = min((M + 3) / 4, 4096);
+  const int nch = ((C >> 3) + 63) / 64;
+#define NK_LN_FWD(NCH_) hipLaunchKernelGGL(ln_fwd_kernel<NCH_>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps)
+  if (nch <= 2) NK_LN_FWD(2); else if (nch == 3) NK_LN_FWD(3); else NK_LN_FWD(4);
+#undef NK_LN_FWD
   return nk_check_launch("ln_fwd_kernel");
 }
 
-static int ln_bwd_blocks(int M) {
-  int b = (M + 7) / 8;   // 2 rows per wave: enough waves in flight to stream HBM, partials stay <= the tensor size
-  if (b > 1024) b = 1024;
-  if (b < 1) b = 1;
-  return b;
-}
-extern "C" long nk_layernorm_ws_floats(int M, int C) { return (long)ln_bwd_blocks(M) * 2 * C + 64; }
+extern "C" long nk_layernorm_ws_floats(int M, int C) { return (long)ln_param_split(M) * 2 * C + 64; }
 
 extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
-                                int M, int C, void* stream) {
+                                int M, int C, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
   NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws);
-  int blocks = ln_bwd_blocks(M);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 8 * C * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, ws, M, C);
-  if (int e = nk_check_launch("ln_bwd_kernel")) return e;
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, dgamma, dbeta, blocks, C);
+  // input gradient: one wavefront per row
+  const int blocks = min((M + 3) / 4, 4096);
+  const int nch = ((C >> 3) + 63) / 64;
+#define NK_LN_DX(NCH_) hipLaunchKernelGGL(ln_bwd_dx_kernel<NCH_>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, M, C)
+  if (nch <= 2) NK_LN_DX(2); else if (nch == 3) NK_LN_DX(3); else NK_LN_DX(4);
+#undef NK_LN_DX
+  if (int e = nk_check_launch("ln_bwd_dx_kernel")) return e;
+  // parameter gradients: column-parallel partial sums over row splits, then a single-writer reduce
+  const int nsplit = ln_param_split(M);
+  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(nsplit, (C + 127) / 128), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
+                     mean, rstd, ws, M, C);
+  if (int e = nk_check_launch("ln_bwd_param_kernel")) return e;
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, ws, dgamma, dbeta, nsplit, C);
   return nk_check_launch("colpart_reduce_kernel");
 }

@@ -1,6 +1,6 @@
 """In-process A/B of training-step variants (same device, interleaved rounds): prints ms/step per variant."""
 import os, sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from neurosis_amd import ops
 
@@ -23,7 +23,7 @@ def main():
     variants["sk_bf16_g256"] = b_256
     def b_noside(): os.environ["NK_GEMM_SK"] = "3"; ops.state.wgrad_stream = None
     variants["sk_heur_noside"] = b_noside
-    def restore(): ops.state.wgrad_stream = side; setenv(96, 192); os.environ["NK_GEMM_NW"] = "8"; os.environ["NK_GEMM_SK"] = "3"; os.environ["NK_SK_GRID"] = "512"
+    def restore(): ops.state.wgrad_stream = side; setenv(96, 192); os.environ["NK_GEMM_NW"] = "8"; os.environ["NK_GEMM_SK"] = "4"; os.environ["NK_SK_GRID"] = "512"
     for _ in range(2): step()
     res = {k: [] for k in variants}
     for rnd in range(3):

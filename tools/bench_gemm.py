@@ -1,6 +1,6 @@
 """Microbenchmark of the MFMA tile engine on the SDXL training-step shapes (run on the GPU box)."""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from neurosis_amd import ops
 
 def timeit(fn, iters=20):

@@ -1,6 +1,6 @@
 """HBM-bound kernels at the SDXL 1024^2 / batch-4 shapes: achieved GB/s against algorithmic bytes (read once, write once)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from neurosis_amd import ops
 
 def timeit(fn, iters=20):
