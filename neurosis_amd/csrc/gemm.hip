@@ -626,13 +626,9 @@ struct OperandDMA {
 // NW = 4: waves 2x2, 64x64 per wave, 2 waves per SIMD at two workgroups per CU.
 // NW = 8: waves 2x4, 64x32 per wave, 4 waves per SIMD: same tile, same LDS, twice the waves to cover each other's
 //         DMA waits and fragment-read latency (under-filled grids run one workgroup per CU, i.e. 1 vs 2 waves per SIMD).
-template <int AMODE, int BMODE, int OUT_F32, int NW, int PF = 0>
+template <int AMODE, int BMODE, int OUT_F32, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const bf16_t* pfa = p.nbatch ? p.Ab[blockIdx.z] : p.A;
-  const bf16_t* pfb = p.nbatch ? p.Bb[blockIdx.z] : p.B;
-  const int pfd = p.sk_debug >> 4;
-  unsigned pf_sink = 0;
   constexpr int NJ = NW == 4 ? 4 : 2;      // 16-column MFMA tiles per wave
   constexpr int NP = 16 / NW;              // DMA pieces per thread per operand tile
   const int tid = threadIdx.x;
@@ -679,12 +675,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
 #endif
   for (int kt = 0; kt < nk; ++kt) {
     // vmcnt(0) + barrier: tile kt has landed for every wave, and every wave is done reading the other buffer
-    if constexpr (PF) {
-      if (kt == 0) asm volatile("s_waitcnt vmcnt(0)\n s_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(1)\n s_barrier" ::: "memory");
-    } else {
-      __syncthreads();
-    }
+    __syncthreads();
     const char* cur = smem + (kt & 1) * V2_STAGE_BYTES;
     // fragment reads of BOTH k sub-steps first, THEN the next tile's DMA, then the MFMAs.  hipcc (ROCm 7.2) puts an
     // s_waitcnt vmcnt(0) in front of ds_read_b64_tr_b16 whenever an LDS-DMA is outstanding (it cannot prove the
@@ -704,23 +695,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
       opa.issue(kbeg + (kt + 1) * BK, kend, nxt, p.ga, p.tw);
       opb.issue(kbeg + (kt + 1) * BK, kend, nxt + V2_OPND_BYTES, p.gb, p.tw);
     }
-    if constexpr (PF) {
-      // L2 prefetch of a slab PFD k-steps ahead: one dword per 128-byte row segment into a register nobody reads.
-      // It is YOUNGER than the LDS-DMA above, so the counted wait at the top of the next k-step lets it fly.
-      const int kp = kbeg + (kt + 1 + pfd) * BK;
-      const bf16_t* src = (const bf16_t*)nk_zero_page;
-      if (kp < kend) {
-        const int r = tid & 127;
-        if (tid < 128) { if (m0 + r < p.M) src = pfa + (long)(m0 + r) * p.lda + kp; }
-        else if (tid < 256) { if (n0 + r < p.N) src = pfb + (long)(n0 + r) * p.ldb + kp; }
-        else if (kp + BK < kend) {
-          if (tid < 384) { if (m0 + r < p.M) src = pfa + (long)(m0 + r) * p.lda + kp + BK; }
-          else { if (n0 + r < p.N) src = pfb + (long)(n0 + r) * p.ldb + kp + BK; }
-        }
-      }
-      // (pf_sink stays allocated for the whole loop: the data lands in it long after this statement)
-      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(src) : "memory");
-    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -737,113 +711,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
     nk_clock_stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
   }
 #endif
-  if constexpr (PF) asm volatile("" :: "v"(pf_sink));
-  nk_gemm_epilogue<OUT_F32, BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
-}
-
-// ---------------------------------------------------------------------------------------------
-// software-pipelined variant of the loop above (experiment, NK_GEMM_PIPE=1): fragment reads of k sub-step 1 are issued
-// before the MFMAs of sub-step 0, and the next slab's sub-step 0 fragments before the MFMAs of sub-step 1, so a wave's
-// LDS latency is covered by its own MFMAs instead of being exposed after every barrier.
-// ---------------------------------------------------------------------------------------------
-template <int AMODE, int BMODE, int OUT_F32>
-__global__ __launch_bounds__(512, 4) void nk_gemm_pipe_kernel(const NkGemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = 8, NJ = 2, NP = 2;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ntn = (p.N + BN - 1) / BN;
-  const int ntm = (p.M + BM - 1) / BM;
-  const int per_group = GROUP_M * ntn;
-  const int group = wg / per_group;
-  const int first_m = group * GROUP_M;
-  const int gm = min(GROUP_M, ntm - first_m);
-  const int in_group = wg - group * per_group;
-  const int nt = in_group / gm;
-  const int mt = first_m + (in_group - nt * gm);
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int kbeg = blockIdx.y * p.ksplit_len;
-  const int kend = min(p.K, kbeg + p.ksplit_len);
-  const int nk = (kend - kbeg + BK - 1) / BK;
-
-  OperandDMA<AMODE, NP> opa;
-  OperandDMA<BMODE, NP> opb;
-  opa.init(p.nbatch ? p.Ab[blockIdx.z] : p.A, p.lda, p.M, m0, tid, p.ga);
-  opb.init(p.nbatch ? p.Bb[blockIdx.z] : p.B, p.ldb, p.N, n0, tid, p.gb);
-
-  float4_t acc[4][NJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-  bf16x8_t a0[4], b0[NJ], a1[4], b1[NJ];
-  if (nk > 0) {
-    opa.issue(kbeg, kend, smem, p.ga, p.tw);
-    opb.issue(kbeg, kend, smem + V2_OPND_BYTES, p.gb, p.tw);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a0[i] = OperandDMA<AMODE>::frag(smem, wm * 64 + i * 16, 0, lane);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) b0[j] = OperandDMA<BMODE>::frag(smem + V2_OPND_BYTES, wn * (NJ * 16) + j * 16, 0, lane);
-    if (nk > 1) {
-      opa.issue(kbeg + BK, kend, smem + V2_STAGE_BYTES, p.ga, p.tw);
-      opb.issue(kbeg + BK, kend, smem + V2_STAGE_BYTES + V2_OPND_BYTES, p.gb, p.tw);
-    }
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * V2_STAGE_BYTES;
-    // B (first MFMA) -- the wait for the sub-step 0 fragments sits here, with nothing else outstanding: hipcc waits for
-    // lgkmcnt(0), not a count, so the sub-step 1 reads are issued right AFTER this MFMA and land under the other seven
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], b0[0], acc[0][0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // A: sub-step 1 fragments of this slab
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a1[i] = OperandDMA<AMODE>::frag(cur, wm * 64 + i * 16, 1, lane);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) b1[j] = OperandDMA<BMODE>::frag(cur + V2_OPND_BYTES, wn * (NJ * 16) + j * 16, 1, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    // B: remaining MFMAs of sub-step 0
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        if (i | j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) {
-      // C: the next slab has landed for everyone, and everyone is done reading this one
-      __syncthreads();
-      const char* nxt = smem + ((kt + 1) & 1) * V2_STAGE_BYTES;
-      // E: sub-step 0 fragments of the next slab
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a0[i] = OperandDMA<AMODE>::frag(nxt, wm * 64 + i * 16, 0, lane);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b0[j] = OperandDMA<BMODE>::frag(nxt + V2_OPND_BYTES, wn * (NJ * 16) + j * 16, 0, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      // D: DMA of slab kt+2 into the stage just released
-      if (kt + 2 < nk) {
-        char* fre = smem + (kt & 1) * V2_STAGE_BYTES;
-        opa.issue(kbeg + (kt + 2) * BK, kend, fre, p.ga, p.tw);
-        opb.issue(kbeg + (kt + 2) * BK, kend, fre + V2_OPND_BYTES, p.gb, p.tw);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // F: MFMAs of sub-step 1
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __syncthreads();
   nk_gemm_epilogue<OUT_F32, BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
@@ -1300,27 +1167,6 @@ static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
   // 8 waves per 128x128 tile by default: measured +4..14 % over 4 waves on every SDXL shape (A/B: NK_GEMM_NW=4)
   int nw = 8;
   if (const char* e = getenv("NK_GEMM_NW")) nw = atoi(e);
-  static int pipe = -1, pf = -1;
-  if (pipe < 0) { const char* e = getenv("NK_GEMM_PIPE"); pipe = e ? atoi(e) : 0; }
-  if (pf < 0) { const char* e = getenv("NK_GEMM_PF"); pf = e ? atoi(e) : 0; }
-  if constexpr (AMODE == OP_KC && BMODE == OP_KC) {
-    if (pf > 0 && !use_v1() && nw == 8) {
-      auto kernf = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32, 8, 1>;
-      static bool fattr = false;
-      if (!fattr) { (void)hipFuncSetAttribute((const void*)kernf, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES); fattr = true; }
-      NkGemmParams q = p;
-      q.sk_debug = pf << 4;
-      hipLaunchKernelGGL(kernf, grid, dim3(512), V2_SMEM_BYTES, stream, q);
-      return nk_check_launch("nk_gemm_dma_kernel<pf>");
-    }
-  }
-  if (pipe && !use_v1() && nw == 8) {
-    auto kernp = nk_gemm_pipe_kernel<AMODE, BMODE, OUT_F32>;
-    static bool pattr = false;
-    if (!pattr) { (void)hipFuncSetAttribute((const void*)kernp, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES); pattr = true; }
-    hipLaunchKernelGGL(kernp, grid, dim3(512), V2_SMEM_BYTES, stream, p);
-    return nk_check_launch("nk_gemm_pipe_kernel");
-  }
   if (use_v1()) hipLaunchKernelGGL(kern1, grid, dim3(NTHREADS), SMEM_BYTES, stream, p);
   else if (nw == 8) hipLaunchKernelGGL(kern8, grid, dim3(512), V2_SMEM_BYTES, stream, p);
   else hipLaunchKernelGGL(kern4, grid, dim3(NTHREADS), V2_SMEM_BYTES, stream, p);

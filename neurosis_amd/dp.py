@@ -30,6 +30,10 @@ class FlatGradReducer:
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.pending = []
         self.reduced_elems = 0
+        # optional instrumentation (bench.py): events on the exchange stream around the first / last collective of a step
+        self.record_timing = False
+        self.ev_first = None
+        self.ev_last = None
 
     def reduce_range(self, lo: int, hi: int) -> None:
         if self.world == 1 or hi <= lo:
@@ -38,6 +42,9 @@ class FlatGradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
+            if self.record_timing and self.ev_first is None:
+                self.ev_first = torch.cuda.Event(enable_timing=True)
+                self.ev_first.record(self.stream)
         for a in range(lo, hi, self.max_chunk):
             b = min(hi, a + self.max_chunk)
             sl = self.flat[a:b]
@@ -59,10 +66,18 @@ class FlatGradReducer:
     def finish(self) -> None:
         """Make the compute stream wait for every outstanding reduction."""
         if self.cuda and self.world > 1:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.record_timing)
             ev.record(self.stream)
             torch.cuda.current_stream().wait_event(ev)
+            if self.record_timing:
+                self.ev_last = ev
         self.reduced_elems = 0
+
+    def take_timing(self):
+        """(first-collective-start, last-collective-end) events of the step just finished, then reset."""
+        pair = (self.ev_first, self.ev_last)
+        self.ev_first = self.ev_last = None
+        return pair
 
 
 class FlatDataParallel:
