@@ -250,6 +250,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--optimizer", default="adafactor", choices=["adafactor", "adamw"],
+                    help="adafactor = the reference example config's optimizer (scale_parameter, relative_step, warmup_init); adamw = fused flat AdamW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the multi-rank control flow)")
@@ -280,6 +282,8 @@ def main():
     lib.load()  # fail loudly if the HIP library is missing
     eng = build_engine(device, (args.res, args.res))
     unet = eng.model.diffusion_model
+    if args.optimizer == "adafactor":
+        eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)   # configs/sdxl/sdxl.example.yaml:158-164
     dp = FlatDataParallel(unet, eng.store) if world > 1 else None
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     gen_cpu = torch.Generator().manual_seed(42 + rank)
@@ -380,7 +384,7 @@ def main():
             "metric": "train images/sec (node) SDXL 1024^2", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"SDXL-base {args.res}^2 bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + AdamW step, frozen TE outputs synthetic",
+            "config": {"workload": f"SDXL-base {args.res}^2 bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, frozen TE outputs synthetic",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "activation_checkpointing": False, "accumulate_grad_batches": 1},
             "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "comm": comm,

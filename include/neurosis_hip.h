@@ -160,6 +160,26 @@ int nk_edm_loss(const void* net_out, const float* zt, const float* target, const
 int nk_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-tensor Adafactor on the flat buffers.  Replaces Adafactor.step,
+ * reference optimizers/adafactor.py:162-255 (_get_lr :133-147, _rms :150-151, _approx_sq_grad :154-159): the per-tensor
+ * Python loop becomes five launches per chunk of consecutive tensors.  `tensors` / `items` are device tables built by the
+ * host (layout: neurosis_amd/csrc/optim.hip NkAfTensor / NkAfItem; nk_adafactor_tensor_bytes() guards the mirror).
+ * nk_adafactor_init fills the per-item partial sums of p^2 once; nk_adafactor_chunk performs one step for tensors
+ * [tensor_lo, tensor_hi) = items [item_lo, item_hi).  beta2t = 1 - step^decay_rate and rel_step are host scalars. */
+typedef struct NkAdafactorArgs {
+  float* master; const float* grad; void* shadow; float* state; float* ws;
+  const void* tensors; const void* items;
+  float* u2_part; float* p2_part; float* mean_row; float* scale; float* lr_t;
+  int item_lo, item_hi, tensor_lo, tensor_hi;
+  float beta2t, eps1, eps2, clip_threshold, rel_step, weight_decay, grad_scale;
+  int scale_parameter;
+  const void* fin_items; int fin_lo, fin_hi;   /* finalize work list of the chunk's matrices (empty range: none) */
+} NkAdafactorArgs;
+long nk_adafactor_tensor_bytes(void);
+int nk_adafactor_init(const NkAdafactorArgs* args, void* stream);
+int nk_adafactor_chunk(const NkAdafactorArgs* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

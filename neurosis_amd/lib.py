@@ -65,6 +65,8 @@ SIGNATURES: dict[str, list] = {
     "nk_edm_prepare": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "nk_edm_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "nk_adamw_flat": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
+    "nk_adafactor_init": [vp, vp],
+    "nk_adafactor_chunk": [vp, vp],
 }
 
 # entry points that return a size (long) instead of a status
@@ -73,6 +75,7 @@ SIZE_QUERIES: dict[str, list] = {
     "nk_layernorm_ws_floats": [i32, i32],
     "nk_colsum_ws_floats": [i64, i32],
     "nk_attention_bwd_ws_floats": [adp],
+    "nk_adafactor_tensor_bytes": [],
 }
 
 _lib = None

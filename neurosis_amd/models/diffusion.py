@@ -104,10 +104,24 @@ class DiffusionEngine(nn.Module):
         self.last_log = {"train/loss": loss.detach().mean(), "train/loss_s0": loss.detach()[0]}
         return loss.mean()
 
-    def optimizer_step(self, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
-        """Fused flat AdamW (one kernel over masters, moments and bf16 shadows), then clears the gradients."""
+    def configure_adafactor(self, **kwargs):
+        """Use the fused multi-tensor Adafactor (reference optimizers/adafactor.py; the optimizer the example configs name,
+        configs/sdxl/sdxl.example.yaml:158-169) for optimizer_step().  kwargs as the reference class's; returns it."""
         if self.store is None:
             raise RuntimeError("call setup_flat_params() first")
-        self.store.adamw_step(lr, betas, eps, weight_decay, grad_scale)
+        from ..optim import FlatAdafactor
+
+        self.adafactor = FlatAdafactor(self.store, **kwargs)
+        return self.adafactor
+
+    def optimizer_step(self, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
+        """One parameter update on the flat buffers, then clears the gradients: the configured Adafactor if
+        configure_adafactor() was called (its own hyper-parameters; only grad_scale is used), else fused flat AdamW."""
+        if self.store is None:
+            raise RuntimeError("call setup_flat_params() first")
+        if getattr(self, "adafactor", None) is not None:
+            self.adafactor.step(grad_scale)
+        else:
+            self.store.adamw_step(lr, betas, eps, weight_decay, grad_scale)
         self.store.zero_grad()
         self.global_step += 1

@@ -1,0 +1,208 @@
+"""Optimizers over the flat parameter store.
+
+`FlatAdafactor` mirrors `neurosis.optimizers.Adafactor` (reference `optimizers/adafactor.py:104-255`: same constructor
+arguments and the same per-tensor rule -- factored second moments over the LAST TWO dims of every tensor with >= 2 dims,
+RMS-scaled relative step, update clipping) but runs as a handful of multi-tensor HIP launches on the flat fp32 master /
+gradient buffers (`csrc/optim.hip`), rewriting the bf16 shadows in the same pass.  `AdafactorScheduler` mirrors :258-291.
+
+Differences, all deliberate: `beta1` (first moment) is not implemented -- the example configs leave it `None`
+(`configs/sdxl/sdxl.example.yaml:158-164`) -- and asking for it raises; state lives in two flat buffers instead of a
+per-parameter dict (`state_dict()` exposes the reference's keys as views).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import ops
+from .lib import call, query
+
+AF_TENSOR_DTYPE = np.dtype([("off", "<i8"), ("row_off", "<i8"), ("col_off", "<i8"), ("ws_row", "<i8"), ("ws_col", "<i8"),
+                            ("kind", "<i4"), ("d0", "<i4"), ("d1", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("item0", "<i4"),
+                            ("nitems", "<i4"), ("mr0", "<i4")])
+AF_ITEM_DTYPE = np.dtype([("tensor", "<i4"), ("tr", "<i4"), ("tc", "<i4"), ("pad", "<i4")])
+AF_TR, AF_TC, AF_CONV_PAIRS, AF_VEC, AF_FIN = 256, 64, 1024, 1024, 1024
+
+
+class _Args(C.Structure):
+    _fields_ = [("master", C.c_void_p), ("grad", C.c_void_p), ("shadow", C.c_void_p), ("state", C.c_void_p), ("ws", C.c_void_p),
+                ("tensors", C.c_void_p), ("items", C.c_void_p), ("u2_part", C.c_void_p), ("p2_part", C.c_void_p),
+                ("mean_row", C.c_void_p), ("scale", C.c_void_p), ("lr_t", C.c_void_p),
+                ("item_lo", C.c_int), ("item_hi", C.c_int), ("tensor_lo", C.c_int), ("tensor_hi", C.c_int),
+                ("beta2t", C.c_float), ("eps1", C.c_float), ("eps2", C.c_float), ("clip_threshold", C.c_float),
+                ("rel_step", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float),
+                ("scale_parameter", C.c_int), ("fin_items", C.c_void_p), ("fin_lo", C.c_int), ("fin_hi", C.c_int)]
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class FlatAdafactor:
+    """Adafactor on a FlatParamStore.  Constructor arguments as the reference's (adafactor.py:104-131)."""
+
+    def __init__(self, store, lr: Optional[float] = None, eps: tuple[float, float] = (1e-30, 1e-3), clip_threshold: float = 1.0,
+                 decay_rate: float = -0.8, beta1: Optional[float] = None, weight_decay: float = 0.0, scale_parameter: bool = True,
+                 relative_step: bool = True, warmup_init: bool = False, chunk_bytes: Optional[int] = None):
+        if lr is not None and relative_step:
+            raise ValueError("Cannot combine manual `lr` and `relative_step=True` options")
+        if warmup_init and not relative_step:
+            raise ValueError("`warmup_init=True` requires `relative_step=True`")
+        if beta1 is not None:
+            raise NotImplementedError("FlatAdafactor: beta1 (first moment) is not implemented; the reference configs use beta1=None")
+        if query("nk_adafactor_tensor_bytes") != AF_TENSOR_DTYPE.itemsize:
+            raise RuntimeError("FlatAdafactor: tensor table layout differs from the HIP library's")
+        if chunk_bytes is None:
+            # gradient bytes per chunk of tensors (five launches each).  Measured on the SDXL UNet: 128 MB chunks (gradients
+            # re-read from the Infinity Cache) 19.2 images/s, 1-4 GB chunks 19.9-20.0: the dependent small launches cost more
+            # than the second and third gradient read from HBM, so chunks are large.
+            import os
+
+            chunk_bytes = int(os.environ.get("NK_AF_CHUNK_MB", "2048")) << 20
+        self.store = store
+        self.lr, self.eps, self.clip_threshold, self.decay_rate = lr, eps, clip_threshold, decay_rate
+        self.weight_decay, self.scale_parameter, self.relative_step, self.warmup_init = weight_decay, scale_parameter, relative_step, warmup_init
+        self.step_count = 0
+        dev = store.master.device
+
+        tens = np.zeros(len(store.params), dtype=AF_TENSOR_DTYPE)
+        items, fin = [], []
+        self.chunks = []   # (tensor_lo, tensor_hi, item_lo, item_hi, fin_lo, fin_hi)
+        state_off = 0
+        ws_max = 0
+        mr_slots = 0
+        c_t0, c_i0, c_f0, c_bytes, c_ws = 0, 0, 0, 0, 0
+        for ti, (p, off) in enumerate(zip(store.params, store.offsets)):
+            t = tens[ti]
+            t["off"] = off
+            if p.dim() >= 2 and p.dim() not in (2, 4):
+                raise NotImplementedError(f"FlatAdafactor: {p.dim()}-d parameters are not supported")
+            nbytes = p.numel() * 4
+            if c_bytes and c_bytes + nbytes > chunk_bytes:   # close the current chunk before this tensor
+                self.chunks.append((c_t0, ti, c_i0, len(items), c_f0, len(fin)))
+                ws_max = max(ws_max, c_ws)
+                c_t0, c_i0, c_f0, c_bytes, c_ws = ti, len(items), len(fin), 0, 0
+            t["item0"] = len(items)
+            if p.dim() == 2:
+                d0, d1 = p.shape
+                if d1 % 4:
+                    raise NotImplementedError("FlatAdafactor: matrix rows must be a multiple of 4 elements")
+                ntr, ntc = -(-d0 // AF_TR), -(-d1 // AF_TC)
+                t["kind"], t["d0"], t["d1"], t["kh"], t["kw"] = 1, d0, d1, 1, 1
+                t["row_off"], t["col_off"] = state_off, state_off + _align(d0)
+                state_off += _align(d0) + _align(d1)
+                t["ws_row"], t["ws_col"] = c_ws, c_ws + ntc * d0
+                c_ws += _align(ntc * d0 + ntr * d1)
+                items += [(ti, r, c, 0) for r in range(ntr) for c in range(ntc)]
+                t["mr0"] = mr_slots
+                mr_slots += -(-d0 // AF_FIN)
+                fin += [(ti, r, 0, 0) for r in range(-(-d0 // AF_FIN))] + [(ti, c, 1, 0) for c in range(-(-d1 // AF_FIN))]
+            elif p.dim() == 4:
+                O, I, KH, KW = p.shape
+                if KH > 3 or KW > 3:
+                    raise NotImplementedError("FlatAdafactor: conv kernels larger than 3x3 are not supported")
+                t["kind"], t["d0"], t["d1"], t["kh"], t["kw"] = 2, O, I, KH, KW
+                t["row_off"], t["col_off"] = state_off, state_off + _align(O * KH * I)
+                state_off += _align(O * KH * I) + _align(O * KW * I)
+                items += [(ti, r, 0, 0) for r in range(-(-(O * I) // AF_CONV_PAIRS))]
+            else:
+                n = p.numel()
+                t["kind"], t["d0"], t["d1"], t["kh"], t["kw"] = 0, n, 1, 1, 1
+                t["row_off"] = state_off
+                state_off += _align(n)
+                items += [(ti, r, 0, 0) for r in range(-(-n // AF_VEC))]
+            t["nitems"] = len(items) - int(t["item0"])
+            c_bytes += nbytes
+        self.chunks.append((c_t0, len(store.params), c_i0, len(items), c_f0, len(fin)))
+        ws_max = max(ws_max, c_ws)
+
+        items_np = np.array(items, dtype=np.int32).view(AF_ITEM_DTYPE).reshape(-1)
+        self._tens_np = tens
+        self.tensors = torch.from_numpy(tens.view(np.uint8).copy()).to(dev)
+        self.items = torch.from_numpy(items_np.view(np.uint8).copy()).to(dev)
+        fin_np = np.array(fin if fin else [(0, 0, 0, 0)], dtype=np.int32).view(AF_ITEM_DTYPE).reshape(-1)
+        self.fin_items = torch.from_numpy(fin_np.view(np.uint8).copy()).to(dev)
+        self.nitems, self.ntensors = len(items), len(store.params)
+        self.state = torch.zeros(max(state_off, 1), dtype=torch.float32, device=dev)
+        self.ws = torch.empty(max(ws_max, 1), dtype=torch.float32, device=dev)
+        self.u2_part = torch.zeros(self.nitems, dtype=torch.float32, device=dev)
+        self.p2_part = torch.zeros(self.nitems, dtype=torch.float32, device=dev)
+        self.mean_row = torch.zeros(max(mr_slots, 1), dtype=torch.float32, device=dev)
+        self.scale = torch.zeros(self.ntensors, dtype=torch.float32, device=dev)
+        self.lr_t = torch.zeros(self.ntensors, dtype=torch.float32, device=dev)
+        self._p2_valid = False
+
+    # -- the update -------------------------------------------------------------------------------
+    def _args(self, chunk, beta2t: float, rel_step: float, grad_scale: float) -> _Args:
+        t0, t1, i0, i1, f0, f1 = chunk
+        s = self.store
+        return _Args(s.master.data_ptr(), s.grad.data_ptr(), s.shadow.data_ptr(), self.state.data_ptr(), self.ws.data_ptr(),
+                     self.tensors.data_ptr(), self.items.data_ptr(), self.u2_part.data_ptr(), self.p2_part.data_ptr(),
+                     self.mean_row.data_ptr(), self.scale.data_ptr(), self.lr_t.data_ptr(), i0, i1, t0, t1,
+                     beta2t, self.eps[0], self.eps[1], self.clip_threshold, rel_step, self.weight_decay, grad_scale,
+                     int(self.scale_parameter), self.fin_items.data_ptr(), f0, f1)
+
+    def rel_step(self, step: int) -> float:
+        """adafactor.py:133-139"""
+        if not self.relative_step:
+            return float(self.lr)
+        min_step = 1e-6 * step if self.warmup_init else 1e-2
+        return min(min_step, 1.0 / math.sqrt(step))
+
+    def refresh_param_norms(self) -> None:
+        """Recompute the per-tile sums of p^2 (needed once, and again whenever the masters are changed from outside)."""
+        a = self._args((0, self.ntensors, 0, self.nitems, 0, 0), 0.0, 0.0, 1.0)
+        call("nk_adafactor_init", C.byref(a), ops._stream())
+        self._p2_valid = True
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        """One Adafactor update of every parameter (adafactor.py:162-255); also rewrites the bf16 shadows."""
+        if not self._p2_valid:
+            self.refresh_param_norms()
+        self.step_count += 1
+        beta2t = 1.0 - math.pow(self.step_count, self.decay_rate)
+        rel = self.rel_step(self.step_count)
+        stream = ops._stream()
+        for chunk in self.chunks:
+            a = self._args(chunk, beta2t, rel, grad_scale)
+            call("nk_adafactor_chunk", C.byref(a), stream)
+        self.store._mark_fresh()
+
+    # -- introspection mirroring the reference's per-parameter state --------------------------------
+    def current_lrs(self) -> Tensor:
+        """Per-tensor lr of the last step (what `_get_lr` returned for each parameter)."""
+        return self.lr_t
+
+    def param_state(self, index: int) -> dict:
+        t = self._tens_np[index]
+        p = self.store.params[index]
+        if t["kind"] == 1:
+            return {"step": self.step_count, "exp_avg_sq_row": self.state[int(t["row_off"]):int(t["row_off"]) + int(t["d0"])],
+                    "exp_avg_sq_col": self.state[int(t["col_off"]):int(t["col_off"]) + int(t["d1"])]}
+        if t["kind"] == 2:
+            O, I, KH, KW = p.shape
+            row = self.state[int(t["row_off"]):int(t["row_off"]) + O * KH * I].view(O, KH, I).permute(0, 2, 1)
+            col = self.state[int(t["col_off"]):int(t["col_off"]) + O * KW * I].view(O, KW, I).permute(0, 2, 1)
+            return {"step": self.step_count, "exp_avg_sq_row": row, "exp_avg_sq_col": col}
+        return {"step": self.step_count, "exp_avg_sq": self.state[int(t["row_off"]):int(t["row_off"]) + p.numel()].view(p.shape)}
+
+
+class AdafactorScheduler:
+    """Proxy scheduler (adafactor.py:258-291): reports `initial_lr` before the first step, then the optimizer's own lr of
+    the first parameter."""
+
+    def __init__(self, optimizer: FlatAdafactor, initial_lr: float = 0.0):
+        self.optimizer, self.initial_lr = optimizer, initial_lr
+
+    def get_lr(self) -> list[float]:
+        if self.optimizer.step_count == 0:
+            return [self.initial_lr]
+        return [float(self.optimizer.lr_t[0])]
+
+    def step(self) -> None:
+        pass

@@ -194,10 +194,47 @@ def op_cases(nd):
     print("glue: table", table.shape, float(table[0]), float(table[-2]), float(table[-1]))
 
 
+def adafactor_case():
+    """Three steps of the reference's Adafactor (optimizers/adafactor.py) on a small mixed parameter set:
+    matrices, 3x3 and 1x1 conv weights (OIHW), vectors.  Inputs: initial values and per-step gradients; outputs: the
+    parameters after every step and the factored states after the last one."""
+    from neurosis.optimizers.adafactor import Adafactor
+
+    g = torch.Generator().manual_seed(1234)
+    shapes = [(48, 32), (40, 64), (300, 8), (16, 8, 3, 3), (8, 16, 1, 1), (32,), (7,), (1200,)]
+    out = {}
+    for tag, kw in [("relative", dict(scale_parameter=True, relative_step=True, warmup_init=True)),
+                    ("manual", dict(lr=1e-3, scale_parameter=False, relative_step=False, weight_decay=0.01))]:
+        params = [torch.nn.Parameter(torch.randn(*s, generator=g) * (0.5 if len(s) > 1 else 1.0)) for s in shapes]
+        init = [p.detach().clone() for p in params]
+        opt = Adafactor(params, **kw)
+        grads, after = [], []
+        for step in range(3):
+            gs = [torch.randn(*s, generator=g) * (10.0 ** (step - 1)) for s in shapes]   # small, unit, large: clipping kicks in
+            for p, gr in zip(params, gs):
+                p.grad = gr.clone()
+            opt.step()
+            grads.append(gs)
+            after.append([p.detach().clone() for p in params])
+        states = []
+        for p in params:
+            st = opt.state[p]
+            states.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()})
+        out[tag] = dict(kwargs=kw, shapes=shapes, init=init, grads=grads, after=after, states=states)
+        print("adafactor", tag, "lr of p0 after 3 steps:", opt._get_lr(opt.param_groups[0], opt.state[params[0]]))
+    torch.save(out, HERE / "adafactor_steps.pt")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor"}
     nd, nmodel = import_reference()
-    unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
-    unet_case(nd, UNET_SD15_TINY, "unet_sd15_tiny", B=2, HW=16, with_y=False)
-    vae_case(nmodel)
-    op_cases(nd)
+    if "unet" in which:
+        unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
+        unet_case(nd, UNET_SD15_TINY, "unet_sd15_tiny", B=2, HW=16, with_y=False)
+    if "vae" in which:
+        vae_case(nmodel)
+    if "glue" in which:
+        op_cases(nd)
+    if "adafactor" in which:
+        adafactor_case()
