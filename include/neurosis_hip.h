@@ -41,6 +41,11 @@ int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add, void* dx,
 int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy, long ldx,
                     long lddw, int accumulate, void* stream);
 
+/* Health of the persistent stream-K tile kernel (gemm.hip): a workgroup that finishes a K-split tile waits -- bounded --
+ * for the partial tiles of lower-indexed workgroups.  Returns 0 if no launch ever gave up that wait, 1 otherwise
+ * (that launch's output is wrong), -1 on a device error.  Synchronises the device; meant for tests and end-of-run checks. */
+int nk_gemm_sk_status(void);
+
 /* `count` (<= 8) weight gradients of identical shape in ONE launch: the three 1280x1280 projections of a transformer
  * block are 100 tiles each, far below one workgroup per CU on their own.  dy / x / dw are HOST arrays of device pointers. */
 int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, int count, int M, int N, int K,

@@ -1233,6 +1233,19 @@ static int sk_prepare(NkGemmParams& p, int grid, hipStream_t stream) {
   return NK_OK;
 }
 
+// 0 = every stream-K launch so far completed its fix-ups; 1 = some launch gave up waiting for a partial tile (its output
+// is wrong).  Synchronises the device.
+extern "C" int nk_gemm_sk_status(void) {
+  std::lock_guard<std::mutex> lock(sk_mutex);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  int bad = 0;
+  for (auto& kv : sk_spaces) {
+    unsigned v = 0;
+    if (kv.second.flags && hipMemcpy(&v, kv.second.flags + SK_MAX_GRID + 1, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess && v) bad = 1;
+  }
+  return bad;
+}
+
 template <int AMODE, int BMODE, int OUT_F32>
 static int launch_sk(NkGemmParams& p, hipStream_t stream) {
   static bool attr_set = false;

@@ -76,6 +76,7 @@ SIZE_QUERIES: dict[str, list] = {
     "nk_colsum_ws_floats": [i64, i32],
     "nk_attention_bwd_ws_floats": [adp],
     "nk_adafactor_tensor_bytes": [],
+    "nk_gemm_sk_status": [],
 }
 
 _lib = None

@@ -308,3 +308,28 @@ def test_layout_and_timestep(ops):
     args = ts[:, None] * freqs[None]
     ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
     assert float((got.float().cpu() - ref).abs().max()) < 1e-2
+
+
+def test_stream_k_under_contention(ops, monkeypatch):
+    """The persistent stream-K kernel splits tiles across workgroups and joins them through flags.  Run it while another
+    stream keeps the CUs busy with ordinary tile-engine kernels (so its 512 workgroups are NOT all resident at once):
+    results stay exact w.r.t. the uncontended run and no fix-up wait ever expires."""
+    from neurosis_amd import lib
+
+    monkeypatch.setenv("NK_GEMM_SK", "1")
+    M, N, K = 4096, 1280, 5120          # 320 tiles x 80 k-steps: every tile is shared by two workgroups
+    x, w = dev(rnd(M, K)), dev(rnd(N, K, scale=K ** -0.5))
+    want = ops.gemm_nt(x, w).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a, b = dev(rnd(8192, 2048)), dev(rnd(4096, 2048, scale=0.02))
+    monkeypatch.setenv("NK_GEMM_SK", "0")
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            ops.gemm_nt(a, b)           # data-parallel kernels, 2 workgroups per CU, on the other stream
+    monkeypatch.setenv("NK_GEMM_SK", "1")
+    outs = [ops.gemm_nt(x, w) for _ in range(20)]
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)     # deterministic fix-up order: bitwise equal
+    assert lib.query("nk_gemm_sk_status") == 0
