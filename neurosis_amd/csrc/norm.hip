@@ -607,19 +607,25 @@ extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* 
 
 extern "C" long nk_layernorm_ws_floats(int M, int C) { return (long)ln_param_split(M) * 2 * C + 64; }
 
-extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
-                                int M, int C, void* stream_) {
+extern "C" int nk_layernorm_bwd_dx(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                   const void* dx_add, void* dx, int M, int C, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
-  NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws);
+  NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx);
   // input gradient: one wavefront per row
   const int blocks = min((M + 3) / 4, 4096);
   const int nch = ((C >> 3) + 63) / 64;
 #define NK_LN_DX(NCH_) hipLaunchKernelGGL(ln_bwd_dx_kernel<NCH_>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, M, C)
   if (nch <= 2) NK_LN_DX(2); else if (nch == 3) NK_LN_DX(3); else NK_LN_DX(4);
 #undef NK_LN_DX
-  if (int e = nk_check_launch("ln_bwd_dx_kernel")) return e;
+  return nk_check_launch("ln_bwd_dx_kernel");
+}
+
+extern "C" int nk_layernorm_bwd_params(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma,
+                                       float* dbeta, float* ws, int M, int C, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0);
+  NK_CHECK_ARG(dy && x && mean && rstd && dgamma && dbeta && ws);
   // parameter gradients: column-parallel partial sums over row splits, then a single-writer reduce
   const int nsplit = ln_param_split(M);
   hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(nsplit, (C + 127) / 128), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
@@ -627,4 +633,11 @@ extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamm
   if (int e = nk_check_launch("ln_bwd_param_kernel")) return e;
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, ws, dgamma, dbeta, nsplit, C);
   return nk_check_launch("colpart_reduce_kernel");
+}
+
+extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
+                                int M, int C, void* stream) {
+  if (int e = nk_layernorm_bwd_dx(dy, x, gamma, mean, rstd, dx_add, dx, M, C, stream)) return e;
+  return nk_layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, ws, M, C, stream);
 }

@@ -48,6 +48,8 @@ SIGNATURES: dict[str, list] = {
     "nk_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "nk_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "nk_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "nk_layernorm_bwd_dx": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "nk_layernorm_bwd_params": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "nk_geglu_fwd": [vp, vp, i64, i32, vp],
     "nk_geglu_bwd": [vp, vp, vp, i64, i32, vp],
     "nk_silu_fwd": [vp, vp, i64, vp],

@@ -34,6 +34,9 @@ class _State:
     # 215 vs 210 ms/step: on the side stream the under-filled grids already overlap the dgrad chain, and deferring them to the
     # end of the block only delays that overlap -- so off by default.
     batch_wgrads = False
+    # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):
+    # 210 more cross-stream waits per step delay the weight-gradient GEMMs queued behind them.  Off.
+    norm_params_on_side_stream = False
 
 
 state = _State()
@@ -465,9 +468,18 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
         dx = torch.empty_like(x)
+        call("nk_layernorm_bwd_dx", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
+             dx.data_ptr(), M, Cc, _stream())
         ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
-        call("nk_layernorm_bwd", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add), dx.data_ptr(),
-             grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, _stream())
+
+        def params():   # gamma / beta gradients: off the critical path -> weight-gradient stream
+            call("nk_layernorm_bwd_params", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                 grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, _stream())
+
+        if state.norm_params_on_side_stream:
+            on_wgrad_stream(params, dy, x, mean, rstd, ws)
+        else:
+            params()
         return dx
 
     return y, bwd

@@ -17,13 +17,9 @@ def main():
     variants["base"] = lambda: None
     def setenv(lo, hi):
         os.environ["NK_SPLIT_LO"] = str(lo); os.environ["NK_SPLIT_HI"] = str(hi)
+    variants["ln_side"] = lambda: setattr(ops.state, "norm_params_on_side_stream", True)
     variants["no_sk"] = lambda: os.environ.__setitem__("NK_GEMM_SK", "0")
-    variants["sk_bf16"] = lambda: os.environ.__setitem__("NK_GEMM_SK", "4")
-    def b_256(): os.environ["NK_GEMM_SK"] = "4"; os.environ["NK_SK_GRID"] = "256"
-    variants["sk_bf16_g256"] = b_256
-    def b_noside(): os.environ["NK_GEMM_SK"] = "3"; ops.state.wgrad_stream = None
-    variants["sk_heur_noside"] = b_noside
-    def restore(): ops.state.wgrad_stream = side; setenv(96, 192); os.environ["NK_GEMM_NW"] = "8"; os.environ["NK_GEMM_SK"] = "4"; os.environ["NK_SK_GRID"] = "512"
+    def restore(): ops.state.wgrad_stream = side; setenv(96, 192); os.environ["NK_GEMM_NW"] = "8"; os.environ["NK_GEMM_SK"] = "4"; os.environ["NK_SK_GRID"] = "512"; ops.state.norm_params_on_side_stream = False
     for _ in range(2): step()
     res = {k: [] for k in variants}
     for rnd in range(3):
