@@ -70,6 +70,9 @@ def build_engine(device, image_hw=(1024, 1024)):
     return eng
 
 
+MIXED_BUCKETS = [(1216, 832), (832, 1216), (1024, 1024), (1152, 896), (896, 1152)]   # (H, W)
+
+
 def synthetic_batch(device, batch, hw, gen):
     H, W = hw
     return {
@@ -250,6 +253,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--mixed-res", action="store_true",
+                    help="BASELINE config 4: every step each rank draws one aspect bucket (W,H) from the SDXL bucket list "
+                         "{832x1216, 1216x832, 1024x1024, 896x1152, 1152x896}; not the metric's configuration")
     ap.add_argument("--optimizer", default="adafactor", choices=["adafactor", "adamw"],
                     help="adafactor = the reference example config's optimizer (scale_parameter, relative_step, warmup_init); adamw = fused flat AdamW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -296,7 +302,10 @@ def main():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             step_marks.append(ev)
-        batch = synthetic_batch(device, args.batch, (args.res, args.res), gen)
+        hw = (args.res, args.res)
+        if args.mixed_res:   # (H, W) of this rank's bucket for this step (N/dataset/aspect/lists.py:14-56)
+            hw = MIXED_BUCKETS[int(torch.randint(len(MIXED_BUCKETS), (1,), generator=gen_cpu))]
+        batch = synthetic_batch(device, args.batch, hw, gen)
         sig = draw_sigmas(args.batch, gen_cpu, device)
         loss = eng.training_step(batch, 0, sigmas=sig)
         loss.backward()
@@ -384,7 +393,7 @@ def main():
             "metric": "train images/sec (node) SDXL 1024^2", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"SDXL-base {args.res}^2 bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, frozen TE outputs synthetic",
+            "config": {"workload": f"SDXL-base {'mixed-res buckets (~1024^2 pixels)' if args.mixed_res else str(args.res) + '^2'} bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, frozen TE outputs synthetic",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "activation_checkpointing": False, "accumulate_grad_batches": 1},
             "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "comm": comm,
