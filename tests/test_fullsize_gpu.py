@@ -162,3 +162,61 @@ def test_full_size_sdxl_step_is_finite_and_forward_reproducible():
     assert float(eng.store.grad.abs().max()) == 0.0
     del eng
     torch.cuda.empty_cache()
+
+
+def test_config1_sd15_512_training_step_vs_cpu_oracle():
+    """BASELINE configs[0] at FULL size: one SD1.5 512x512 batch-1 training step (frozen VAE encode -> noised latents ->
+    UNet -> eps loss -> backward), HIP path vs the CPU oracle on identical inputs and weights (the oracle needs ~5-10 s for
+    it).  Tolerances: latents 3e-2 of max magnitude (bf16 VAE), per-sample loss 1e-2 relative, gradient cosine >= 0.99."""
+    import bench
+    import neurosis_amd.modules.diffusion as D
+    from neurosis_amd.models.autoencoder import AutoencoderKL
+    from neurosis_amd.models.diffusion import DiffusionEngine
+    from oracle import sdxl_oracle as O
+    from tests.golden.make_golden import synth_state_dict
+    from tests.util import cosine, rel_err
+
+    dev = torch.device("cuda", 0)
+    with torch.device(dev):
+        unet = D.UNetModel(**bench.SD15_UNET)
+        vae = AutoencoderKL(embed_dim=4, ddconfig=bench.SDXL_VAE_DD)
+        den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization())
+    den = den.to(dev)
+    usd = synth_state_dict({k: list(v.shape) for k, v in unet.state_dict().items()})
+    enc_sd = synth_state_dict({k: list(v.shape) for k, v in vae.encoder.state_dict().items()})
+    q_sd = synth_state_dict({f"quant_conv.{k}": list(v.shape) for k, v in vae.quant_conv.state_dict().items()})
+    unet.load_state_dict(usd)
+    vae.encoder.load_state_dict(enc_sd)
+    vae.quant_conv.load_state_dict({k.split(".", 1)[1]: v for k, v in q_sd.items()})
+    loss_fn = D.StandardDiffusionLoss(sigma_generator=D.InjectedSigmaGenerator(), loss_weighting=D.EpsWeighting())
+    eng = DiffusionEngine(model=unet, denoiser=den, first_stage_model=vae, loss_fn=loss_fn, scale_factor=0.18215, input_key="image")
+    eng.setup_flat_params()
+
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    ctx = torch.randn(1, 77, 768, generator=g)
+    sigma = torch.tensor([1.7])
+    noise = torch.randn(1, 4, 64, 64, generator=g)
+
+    # CPU oracle: same weights, same inputs
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    osd = {k: v.clone().requires_grad_(True) for k, v in usd.items()}
+    vsd = {**enc_sd, **q_sd}
+    ref_mean, ref_loss, ref_lat = O.training_step_loss(osd, dict(bench.SD15_UNET), vsd, bench.SDXL_VAE_DD, 0.18215, img, sigma, noise, ctx, None)
+    ref_mean.backward()
+
+    lat = eng.encode_first_stage(img.to(dev))
+    assert lat.shape == (1, 4, 64, 64)
+    assert rel_err(lat.float().cpu(), ref_lat) <= 3e-2
+    batch = {"image": img.to(dev), "crossattn": ctx.to(dev)}
+    loss = eng(ref_lat.to(dev), batch, sigmas=sigma.to(dev), noise=noise.to(dev))     # same latents on both sides
+    loss.mean().backward()
+    torch.cuda.synchronize()
+    assert rel_err(loss.detach().float().cpu(), ref_loss) <= 1e-2, (loss.tolist(), ref_loss.tolist())
+    grads = dict(unet.named_parameters())
+    for k in ["input_blocks.0.0.weight", "input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight", "input_blocks.3.0.op.weight",
+              "middle_block.1.proj_in.weight", "output_blocks.5.2.conv.weight", "output_blocks.11.1.transformer_blocks.0.ff.net.0.proj.weight",
+              "time_embed.0.weight", "out.2.weight"]:
+        assert cosine(grads[k].grad.float().cpu(), osd[k].grad) >= 0.99, k
+    del eng
+    torch.cuda.empty_cache()
