@@ -108,20 +108,20 @@ int nk_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void*
                      float* ws, int N, int HW, int C, int G, float eps, int silu, void* stream);
 int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                      const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
-                     int N, int HW, int C, int G, int silu, void* stream);
+                     int N, int HW, int C, int G, int silu, int accumulate, void* stream);
 
 /* nn.LayerNorm(C) over rows of [M][C] (attention.py:468-470).  mean/rstd: [M] fp32. */
 int nk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      int M, int C, float eps, void* stream);
 long nk_layernorm_ws_floats(int M, int C);
 int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                     const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C, void* stream);
+                     const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C, int accumulate, void* stream);
 /* The same in two parts, so the caller can run the parameter gradients (off the critical path of backward) on another
  * stream: _dx needs no workspace; _params reads dy, x and the saved statistics only. */
 int nk_layernorm_bwd_dx(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* dx_add, void* dx, int M, int C, void* stream);
 int nk_layernorm_bwd_params(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma,
-                            float* dbeta, float* ws, int M, int C, void* stream);
+                            float* dbeta, float* ws, int M, int C, int accumulate, void* stream);
 
 /* GEGLU (attention.py:55-57): y[M][I] = u[:, :I] * gelu_erf(u[:, I:]) */
 int nk_geglu_fwd(const void* u, void* y, long M, int I, void* stream);

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_stats_kernel(const bf16_t* 
 // dgamma[c] += sum_rows part[row][0][c] ; dbeta[c] += sum_rows part[row][1][c]
 // block = 64 channels x 16 row groups (1024 threads); single writer per channel, so no atomics
 __global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int nrows, int C) {
+                                                              float* __restrict__ dbeta, int nrows, int C, int accumulate) {
   __shared__ float sa[16][64], sb[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* __res
   if (ty == 0 && c < C) {
 #pragma unroll
     for (int j = 1; j < 16; ++j) { a += sa[j][tx]; b += sb[j][tx]; }
-    dgamma[c] += a;
-    dbeta[c] += b;
+    dgamma[c] = accumulate ? dgamma[c] + a : a;
+    dbeta[c] = accumulate ? dbeta[c] + b : b;
   }
 }
 
@@ -383,7 +383,7 @@ extern "C" int nk_groupnorm_fwd(const void* x, const float* gamma, const float* 
 
 extern "C" int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                                 const float* mean, const float* rstd, const void* dx_add, void* dx, float* dgamma,
-                                float* dbeta, float* ws, int N, int HW, int C, int G, int silu, void* stream_) {
+                                float* dbeta, float* ws, int N, int HW, int C, int G, int silu, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(N > 0 && HW > 0 && C > 0 && G > 0 && G <= 64);
   NK_CHECK_ARG((C & 7) == 0 && C % G == 0 && C <= GN_MAXC);
@@ -399,7 +399,7 @@ extern "C" int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamm
   if (int e = nk_check_launch("gn_bwd_stats_kernel")) return e;
   hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(1024), 0, stream, part, gsum, nsplit * nz, 2 * G);
   if (int e = nk_check_launch("gn_reduce_partials_kernel")) return e;
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, chan, dgamma, dbeta, N * nsplit, C);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, chan, dgamma, dbeta, N * nsplit, C, accumulate);
   if (int e = nk_check_launch("colpart_reduce_kernel")) return e;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nsplit, N), dim3(GN_THREADS), 6 * C * sizeof(float), stream,
                      (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, gsum, (const bf16_t*)dx_add,
@@ -622,7 +622,7 @@ extern "C" int nk_layernorm_bwd_dx(const void* dy, const void* x, const float* g
 }
 
 extern "C" int nk_layernorm_bwd_params(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma,
-                                       float* dbeta, float* ws, int M, int C, void* stream_) {
+                                       float* dbeta, float* ws, int M, int C, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0);
   NK_CHECK_ARG(dy && x && mean && rstd && dgamma && dbeta && ws);
@@ -631,13 +631,13 @@ extern "C" int nk_layernorm_bwd_params(const void* dy, const void* x, const floa
   hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(nsplit, (C + 127) / 128), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
                      mean, rstd, ws, M, C);
   if (int e = nk_check_launch("ln_bwd_param_kernel")) return e;
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, ws, dgamma, dbeta, nsplit, C);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, ws, dgamma, dbeta, nsplit, C, accumulate);
   return nk_check_launch("colpart_reduce_kernel");
 }
 
 extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
-                                int M, int C, void* stream) {
+                                int M, int C, int accumulate, void* stream) {
   if (int e = nk_layernorm_bwd_dx(dy, x, gamma, mean, rstd, dx_add, dx, M, C, stream)) return e;
-  return nk_layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, ws, M, C, stream);
+  return nk_layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, ws, M, C, accumulate, stream);
 }

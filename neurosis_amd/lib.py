@@ -45,11 +45,11 @@ SIGNATURES: dict[str, list] = {
     "nk_attention_bwd": [adp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nk_softmax_rows": [vp, i64, i32, vp],
     "nk_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
-    "nk_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "nk_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "nk_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
-    "nk_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "nk_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "nk_layernorm_bwd_dx": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
-    "nk_layernorm_bwd_params": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "nk_layernorm_bwd_params": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "nk_geglu_fwd": [vp, vp, i64, i32, vp],
     "nk_geglu_bwd": [vp, vp, vp, i64, i32, vp],
     "nk_silu_fwd": [vp, vp, i64, vp],

@@ -70,9 +70,9 @@ class DiffusionEngine(nn.Module):
     def setup_flat_params(self) -> FlatParamStore:
         """Re-home the trainable UNet parameters into the flat fp32/bf16/grad buffers (call after .cuda())."""
         self.store = FlatParamStore([p for p in self.model.diffusion_model.parameters() if p.requires_grad])
-        # contract: the flat gradient buffer is all-zero before the first micro-batch of every optimizer step (it is born
-        # zeroed and optimizer_step() re-zeroes it), so weight-gradient kernels may store instead of memset+atomic-add
-        ops.state.assume_zeroed = True
+        # contract: every parameter gradient is OVERWRITTEN by its producer on the first micro-batch of a step
+        # (ops.state.grad_accumulate False) and added to on later ones, so the 10 GB buffer is never zero-filled between steps
+        ops.state.assume_zeroed = False
         if ops.state.wgrad_stream is None:
             ops.state.wgrad_stream = torch.cuda.Stream()
         return self.store
@@ -115,7 +115,7 @@ class DiffusionEngine(nn.Module):
         return self.adafactor
 
     def optimizer_step(self, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
-        """One parameter update on the flat buffers, then clears the gradients: the configured Adafactor if
+        """One parameter update on the flat buffers (gradients are not cleared: the next backward overwrites them): the configured Adafactor if
         configure_adafactor() was called (its own hyper-parameters; only grad_scale is used), else fused flat AdamW."""
         if self.store is None:
             raise RuntimeError("call setup_flat_params() first")
@@ -123,5 +123,4 @@ class DiffusionEngine(nn.Module):
             self.adafactor.step(grad_scale)
         else:
             self.store.adamw_step(lr, betas, eps, weight_decay, grad_scale)
-        self.store.zero_grad()
         self.global_step += 1

@@ -144,10 +144,15 @@ class Conv2d(nn.Module):
             with torch.no_grad():  # fold the padded gradient back (a few thousand elements)
                 g = wp.grad[: self.out_channels, : self.in_channels]
                 ops.grad_flat(self.weight)
-                self.weight.grad.add_(g)
-                if self.bias is not None:
-                    ops.grad_flat(self.bias)
-                    self.bias.grad.add_(bp.grad[: self.out_channels])
+                ops.grad_flat(self.bias) if self.bias is not None else None
+                if acc:
+                    self.weight.grad.add_(g)
+                    if self.bias is not None:
+                        self.bias.grad.add_(bp.grad[: self.out_channels])
+                else:   # like every other parameter gradient: overwritten by its producer unless accumulating
+                    self.weight.grad.copy_(g)
+                    if self.bias is not None:
+                        self.bias.grad.copy_(bp.grad[: self.out_channels])
             return res
 
         return out, bwd
@@ -239,6 +244,8 @@ class FlatParamStore:
             p._nk_shadow_epoch = ops.state.param_epoch
 
     def zero_grad(self) -> None:
+        """Not needed between steps: every parameter gradient is overwritten by its producer on the first micro-batch
+        (ops.state.grad_accumulate False) and added to on the following ones.  Kept for callers that skip parameters."""
         self.grad.zero_()
 
     def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, grad_scale: float = 1.0) -> None:

@@ -27,7 +27,7 @@ BF16 = torch.bfloat16
 
 class _State:
     grad_accumulate = False  # False: weight-grad kernels overwrite; True: they add (micro-batch accumulation)
-    assume_zeroed = False  # True: .grad buffers are all-zero before the first micro-batch (engine zeroes after each step)
+    assume_zeroed = False  # True: a caller guarantees .grad buffers are all-zero before the first micro-batch (split-K skips its memset)
     param_epoch = 0  # bumped whenever fp32 masters change (optimizer step / load_state_dict)
     wgrad_stream = None  # optional side HIP stream: weight-gradient GEMMs run there, concurrently with the dgrad chain
     # same-shape weight gradients of one transformer block as ONE batched launch (nk_linear_wgrad_batched).  Measured
@@ -349,11 +349,13 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
         if queued:
             _wgrad_queue.add(dy, x, g2d(weight))
 
+        acc = state.grad_accumulate   # every parameter gradient is OVERWRITTEN by its (single) producer unless accumulating
+
         def wg():
             if not queued:
                 gemm_tn_f32(dy, x, g2d(weight), wgrad_mode())
             if bias is not None:
-                colsum(dy, grad_flat(bias), True)
+                colsum(dy, grad_flat(bias), acc)
 
         if not queued or bias is not None:
             on_wgrad_stream(wg, dy, x)
@@ -402,10 +404,12 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
         _check2d(dy, "dy")
         if not dy.is_contiguous():
             raise ValueError("conv2d bwd: dy must be dense")
+        acc = state.grad_accumulate
+
         def wg():
             call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(), _stream())
             if bias is not None:
-                colsum(dy, grad_flat(bias), True)
+                colsum(dy, grad_flat(bias), acc)
 
         on_wgrad_stream(wg, dy, x.t)
         drow = None
@@ -449,7 +453,7 @@ def groupnorm_fwd(x: Img, weight: Tensor, bias: Tensor, groups: int, eps: float,
         ws2 = _ws(nws, dy.device)
         call("nk_groupnorm_bwd", dy.data_ptr(), x.t.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
              _p(dx_add), dx.data_ptr(), grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws2.data_ptr(), N, HW, Cc, groups,
-             int(silu), _stream())
+             int(silu), int(state.grad_accumulate), _stream())
         return dx
 
     return Img(y, x.N, x.H, x.W), bwd
@@ -472,9 +476,11 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
              dx.data_ptr(), M, Cc, _stream())
         ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
 
-        def params():   # gamma / beta gradients: off the critical path -> weight-gradient stream
+        acc = state.grad_accumulate
+
+        def params():   # gamma / beta gradients
             call("nk_layernorm_bwd_params", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                 grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, _stream())
+                 grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, int(acc), _stream())
 
         if state.norm_params_on_side_stream:
             on_wgrad_stream(params, dy, x, mean, rstd, ws)

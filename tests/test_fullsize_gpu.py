@@ -158,8 +158,15 @@ def test_full_size_sdxl_step_is_finite_and_forward_reproducible():
     # every parameter tensor received a gradient (zero-initialised modules were re-initialised for the bench)
     dead = [n for n, p in eng.model.diffusion_model.named_parameters() if float(p.grad.abs().max()) == 0.0]
     assert not dead, dead[:5]
+    # gradients are not zero-filled between steps: a second backward OVERWRITES every one of them (same inputs, same
+    # weights -> the same gradient, not twice it; the tiny-grid split-K atomics make it equal only to rounding)
+    g_before = eng.store.grad.clone()
+    loss2 = eng(latents, batch, sigmas=sig, noise=noise)
+    loss2.mean().backward()
+    torch.cuda.synchronize()
+    assert float((eng.store.grad - g_before).norm() / g_before.norm()) < 1e-2
     eng.optimizer_step(lr=1e-6)
-    assert float(eng.store.grad.abs().max()) == 0.0
+    assert bool(torch.isfinite(eng.store.master).all())
     del eng
     torch.cuda.empty_cache()
 
