@@ -191,6 +191,10 @@ long nk_adafactor_tensor_bytes(void);
 int nk_adafactor_init(const NkAdafactorArgs* args, void* stream);
 int nk_adafactor_chunk(const NkAdafactorArgs* args, void* stream);
 
+/* LitEma.forward (reference modules/ema.py:40-59) as one pass over the flat fp32 buffers (n % 4 == 0):
+ * ema[i] -= one_minus_decay * (ema[i] - p[i]).  The decay schedule min(decay, (1+n)/(10+n)) is the host's. */
+int nk_ema_flat(float* ema, const float* p, long n, float one_minus_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

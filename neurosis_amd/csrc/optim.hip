@@ -521,3 +521,21 @@ extern "C" int nk_adafactor_chunk(const NkAdafactorArgs* h, void* stream_) {
   hipLaunchKernelGGL(af_apply_kernel, dim3(nitems), dim3(256), 0, stream, a);
   return nk_check_launch("af_apply_kernel");
 }
+
+// ---- LitEma.forward (modules/ema.py:40-59) over the flat buffer: shadow -= (1 - decay) * (shadow - p) -------------------
+__global__ __launch_bounds__(256) void ema_flat_kernel(float* __restrict__ ema, const float* __restrict__ p, long n4, float omd) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4_t e = ((const float4_t*)ema)[i];
+    const float4_t q = ((const float4_t*)p)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] -= omd * (e[k] - q[k]);
+    ((float4_t*)ema)[i] = e;
+  }
+}
+extern "C" int nk_ema_flat(float* ema, const float* p, long n, float one_minus_decay, void* stream) {
+  NK_CHECK_ARG(ema && p && n > 0 && (n & 3) == 0);
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(ema_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ema, p, n / 4, one_minus_decay);
+  return nk_check_launch("ema_flat_kernel");
+}

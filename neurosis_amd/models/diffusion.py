@@ -114,6 +114,16 @@ class DiffusionEngine(nn.Module):
         self.adafactor = FlatAdafactor(self.store, **kwargs)
         return self.adafactor
 
+    def configure_ema(self, decay: float = 0.9999, use_num_updates: bool = True):
+        """`use_ema` / `ema_decay_rate` of the reference engine (models/diffusion.py:47-48,93-99): a flat fp32 average of the
+        trainable parameters, updated after every optimizer step (reference: on_train_batch_end, :243-244)."""
+        if self.store is None:
+            raise RuntimeError("call setup_flat_params() first")
+        from ..optim import FlatEma
+
+        self.model_ema = FlatEma(self.store, decay, use_num_updates)
+        return self.model_ema
+
     def optimizer_step(self, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
         """One parameter update on the flat buffers (gradients are not cleared: the next backward overwrites them): the configured Adafactor if
         configure_adafactor() was called (its own hyper-parameters; only grad_scale is used), else fused flat AdamW."""
@@ -123,4 +133,6 @@ class DiffusionEngine(nn.Module):
             self.adafactor.step(grad_scale)
         else:
             self.store.adamw_step(lr, betas, eps, weight_decay, grad_scale)
+        if getattr(self, "model_ema", None) is not None:
+            self.model_ema.update()
         self.global_step += 1

@@ -206,3 +206,46 @@ class AdafactorScheduler:
 
     def step(self) -> None:
         pass
+
+
+class FlatEma:
+    """`LitEma` (reference modules/ema.py:11-93) for a FlatParamStore: ONE flat fp32 shadow of every trainable parameter,
+    updated by one kernel per step.  Same constructor arguments, decay warm-up `min(decay, (1+n)/(10+n))`, and the
+    `store` / `copy_to` / `restore` protocol `DiffusionEngine.ema_scope` uses (models/diffusion.py:247-257)."""
+
+    def __init__(self, store, decay: float = 0.9999, use_num_updates: bool = True):
+        if decay < 0.0 or decay > 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        self.param_store = store
+        self.decay = float(decay)
+        self.num_updates = 0 if use_num_updates else -1
+        self.shadow = store.master.detach().clone()
+        self.collected: Optional[Tensor] = None
+
+    def reset_num_updates(self) -> None:
+        self.num_updates = 0
+
+    def update(self) -> None:
+        """ema.py:40-59"""
+        decay = self.decay
+        if self.num_updates >= 0:
+            self.num_updates += 1
+            decay = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+        call("nk_ema_flat", self.shadow.data_ptr(), self.param_store.master.data_ptr(), self.shadow.numel(), float(1.0 - decay), ops._stream())
+
+    __call__ = update
+
+    def copy_to(self) -> None:
+        """ema.py:61-68: the averaged weights become the model's (masters and bf16 shadows)."""
+        self.param_store.master.copy_(self.shadow)
+        self.param_store.refresh()
+
+    def store(self) -> None:
+        self.collected = self.param_store.master.detach().clone()
+
+    def restore(self) -> None:
+        if self.collected is None:
+            raise RuntimeError("FlatEma.restore() without store()")
+        self.param_store.master.copy_(self.collected)
+        self.param_store.refresh()
+        self.collected = None

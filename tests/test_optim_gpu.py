@@ -98,3 +98,31 @@ def test_flat_adafactor_argument_errors():
         FlatAdafactor(store, lr=1e-3, relative_step=False, warmup_init=True)
     with pytest.raises(NotImplementedError):
         FlatAdafactor(store, beta1=0.9)
+
+
+def test_flat_ema_matches_lit_ema_rule():
+    """modules/ema.py:40-59: shadow -= (1 - d) * (shadow - p), d = min(decay, (1+n)/(10+n)); store / copy_to / restore."""
+    from neurosis_amd.optim import FlatEma
+
+    g = torch.Generator().manual_seed(3)
+    init = [torch.randn(40, 24, generator=g), torch.randn(8, 8, 3, 3, generator=g), torch.randn(17, generator=g)]
+    store, params = make_store(init)
+    ema = FlatEma(store, decay=0.999)
+    ref = [t.clone() for t in init]
+    cur = [t.clone() for t in init]
+    for n in range(1, 4):
+        cur = [c + 0.1 * torch.randn(c.shape, generator=g) for c in cur]
+        with torch.no_grad():
+            for p, c in zip(params, cur):
+                p.copy_(c.cuda())
+        ema.update()
+        d = min(0.999, (1 + n) / (10 + n))
+        ref = [r - (1.0 - d) * (r - c) for r, c in zip(ref, cur)]
+    torch.cuda.synchronize()
+    ema.store()
+    ema.copy_to()
+    for p, want in zip(params, ref):
+        assert rel_err(p.detach().cpu(), want) <= 1e-6
+    ema.restore()
+    for p, want in zip(params, cur):
+        assert rel_err(p.detach().cpu(), want) <= 1e-6
