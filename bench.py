@@ -397,6 +397,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "activation_checkpointing": False, "accumulate_grad_batches": 1},
             "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "comm": comm,
+            "stream_k_fixup_timeouts": lib.query("nk_gemm_sk_status"),   # 0: every K-split tile was joined (gemm.hip)
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
