@@ -17,6 +17,7 @@
 //           dQ kernel (queries on lanes, loops over key tiles, no atomics).  P is recomputed from LSE.
 #include "../../include/neurosis_hip.h"
 #include "nk_common.h"
+#include <stdlib.h>
 
 struct AttnParams {
   const bf16_t *Q, *K, *V, *dO;
@@ -67,16 +68,16 @@ __device__ __forceinline__ bf16x8_t pack_frag(const float16_t& x, int s) {
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // cooperative load of a [ROWS][DP] tile (rows >= nrows or cols >= D read as zero) into registers / LDS
-template <int ROWS, int DP>
+template <int ROWS, int DP, int NT = 256>
 struct TileLoader {
   static constexpr int CPR = DP / 8;
-  static constexpr int PER = (ROWS * CPR + 255) / 256;
+  static constexpr int PER = (ROWS * CPR + NT - 1) / NT;
   static constexpr int RS = DP * 2 + 16;
   uint4_t v[PER];
   __device__ __forceinline__ void load(const bf16_t* base, long stride, int row0, int nrows, int D, int tid) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      int c = tid + 256 * i;
+      int c = tid + NT * i;
       int row = c / CPR, ch = c - row * CPR;
       uint4_t z = {0u, 0u, 0u, 0u};
       if (c < ROWS * CPR && row0 + row < nrows && ch * 8 < D)
@@ -87,7 +88,7 @@ struct TileLoader {
   __device__ __forceinline__ void store(char* tile, int tid) const {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      int c = tid + 256 * i;
+      int c = tid + NT * i;
       int row = c / CPR, ch = c - row * CPR;
       if (c < ROWS * CPR) *(uint4_t*)(tile + row * RS + ch * 16) = v[i];
     }
@@ -97,14 +98,14 @@ struct TileLoader {
 // ================================================================================================
 // forward
 // ================================================================================================
-template <int DP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+template <int DP, int NW = 4>   // NW waves x 32 rows per workgroup (2: twice the workgroups for short sequences)
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 64 * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K,V][64][RS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, ql = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
   const float c = p.scale * LOG2E;
 
   const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * p.D;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   float m = NEG_BIG, l = 0.f;
 
   const int nt = (p.Lk + 63) / 64;
-  TileLoader<64, DP> lk, lv;
+  TileLoader<64, DP, NW * 64> lk, lv;
   lk.load(Kb, p.sk, 0, p.Lk, p.D, tid);
   lv.load(Vb, p.sv, 0, p.Lk, p.D, tid);
   lk.store(smem, tid);
@@ -260,8 +261,8 @@ __global__ void attn_delta_kernel(const AttnParams p) {
 // ================================================================================================
 // backward: dK, dV.  Workgroup = 128 keys (4 waves x 32 keys on lanes), loops over 32-query tiles.
 // ================================================================================================
-template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) {
+template <int DP, int NW = 4>   // NW waves x 32 rows per workgroup (2: twice the workgroups for short sequences)
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(const AttnParams p) {
   constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 32 * RS;
   constexpr int STAGE = 2 * TILE + 256;  // Q tile, dO tile, lse2[32], delta[32]
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
   const int h5 = lane >> 5, kl = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
   const int kb = blockIdx.x / p.qsplit, qs = blockIdx.x - kb * p.qsplit;
-  const int k0 = kb * 128 + wave * 32;
+  const int k0 = kb * (NW * 32) + wave * 32;
   const float c = p.scale * LOG2E;
 
   const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * p.D;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
   const int nt = max(t_hi - t_lo, 0);
-  TileLoader<32, DP> lq, ld_;
+  TileLoader<32, DP, NW * 64> lq, ld_;
   float st_lse = 0.f, st_dl = 0.f;
   auto load_stats = [&](int q0) {
     if (tid < 32) {
@@ -439,14 +440,14 @@ __global__ void attn_dkv_reduce_kernel(const AttnParams p) {
 // ================================================================================================
 // backward: dQ.  Workgroup = 128 queries (on lanes), loops over 64-key tiles.
 // ================================================================================================
-template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+template <int DP, int NW = 4>   // NW waves x 32 rows per workgroup (2: twice the workgroups for short sequences)
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p) {
   constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 64 * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, ql = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
   const int q = q0 + ql;
   const float c = p.scale * LOG2E;
 
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
   const int nt = (p.Lk + 63) / 64;
-  TileLoader<64, DP> lk, lv;
+  TileLoader<64, DP, NW * 64> lk, lv;
   lk.load(Kb, p.sk, 0, p.Lk, p.D, tid);
   lv.load(Vb, p.sv, 0, p.Lk, p.D, tid);
   lk.store(smem, tid);
@@ -558,6 +559,14 @@ static int attn_check(const NkAttnDesc* d) {
   return NK_OK;
 }
 static int attn_dp(int D) { return D <= 64 ? 64 : (D <= 96 ? 96 : 160); }
+// waves per workgroup: 4 x 32 rows.  A 2-wave variant (twice the workgroups for SDXL's L = 1024 layers, which give only
+// 640) is compiled but measured SLOWER (forward 72 vs 65 us, backward 200 vs 181 us: twice the K/V tile loads per query row
+// and half the waves sharing a tile); NK_ATTN_NW=2 selects it for experiments.
+static int attn_waves(int L, int heads_x_batch) {
+  (void)L; (void)heads_x_batch;
+  if (const char* e = getenv("NK_ATTN_NW")) return atoi(e) == 2 ? 2 : 4;
+  return 4;
+}
 
 template <typename K>
 static void set_smem(K kern, int bytes) {
@@ -575,13 +584,17 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
   p.sq = d->sq; p.sk = d->sk; p.sv = d->sv; p.so = d->so;
   p.bq = d->bq; p.bk = d->bk; p.bv = d->bv; p.bo = d->bo;
   p.scale = d->scale;
-  dim3 grid((d->Lq + 127) / 128, d->H, d->B);
+  const int nw = attn_waves(d->Lq, d->H * d->B);
+  dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
   const int dp = attn_dp(d->D);
   const int smem = 2 * 2 * 64 * (dp * 2 + 16);
 #define FWD_CASE(DP_)                                                                          \
-  if (dp == DP_) {                                                                             \
-    set_smem(attn_fwd_kernel<DP_>, smem);                                                      \
-    hipLaunchKernelGGL(attn_fwd_kernel<DP_>, grid, dim3(256), smem, stream, p);                \
+  if (dp == DP_ && nw == 4) {                                                                  \
+    set_smem(attn_fwd_kernel<DP_, 4>, smem);                                                   \
+    hipLaunchKernelGGL((attn_fwd_kernel<DP_, 4>), grid, dim3(256), smem, stream, p);           \
+  } else if (dp == DP_) {                                                                      \
+    set_smem(attn_fwd_kernel<DP_, 2>, smem);                                                   \
+    hipLaunchKernelGGL((attn_fwd_kernel<DP_, 2>), grid, dim3(128), smem, stream, p);           \
   }
   FWD_CASE(64) FWD_CASE(96) FWD_CASE(160)
 #undef FWD_CASE
@@ -633,12 +646,16 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   p.qsplit = attn_qsplit(d);
   p.dkv_part = p.qsplit > 1 ? delta_ws + (((long)d->B * d->H * d->Lq + 3) & ~3l) : nullptr;
   {
-    dim3 grid(((d->Lk + 127) / 128) * p.qsplit, d->H, d->B);
+    const int nw = attn_waves(d->Lk, d->H * d->B * p.qsplit);
+    dim3 grid(((d->Lk + nw * 32 - 1) / (nw * 32)) * p.qsplit, d->H, d->B);
     const int smem = 2 * (2 * 32 * (dp * 2 + 16) + 256);
 #define KV_CASE(DP_)                                                                           \
-  if (dp == DP_) {                                                                             \
-    set_smem(attn_bwd_dkdv_kernel<DP_>, smem);                                                 \
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DP_>, grid, dim3(256), smem, stream, p);           \
+  if (dp == DP_ && nw == 4) {                                                                  \
+    set_smem(attn_bwd_dkdv_kernel<DP_, 4>, smem);                                              \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DP_, 4>), grid, dim3(256), smem, stream, p);      \
+  } else if (dp == DP_) {                                                                      \
+    set_smem(attn_bwd_dkdv_kernel<DP_, 2>, smem);                                              \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DP_, 2>), grid, dim3(128), smem, stream, p);      \
   }
     KV_CASE(64) KV_CASE(96) KV_CASE(160)
 #undef KV_CASE
@@ -652,12 +669,16 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
     }
   }
   {
-    dim3 grid((d->Lq + 127) / 128, d->H, d->B);
+    const int nw = attn_waves(d->Lq, d->H * d->B);
+    dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
     const int smem = 2 * 2 * 64 * (dp * 2 + 16);
 #define Q_CASE(DP_)                                                                            \
-  if (dp == DP_) {                                                                             \
-    set_smem(attn_bwd_dq_kernel<DP_>, smem);                                                   \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<DP_>, grid, dim3(256), smem, stream, p);             \
+  if (dp == DP_ && nw == 4) {                                                                  \
+    set_smem(attn_bwd_dq_kernel<DP_, 4>, smem);                                                \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP_, 4>), grid, dim3(256), smem, stream, p);        \
+  } else if (dp == DP_) {                                                                      \
+    set_smem(attn_bwd_dq_kernel<DP_, 2>, smem);                                                \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP_, 2>), grid, dim3(128), smem, stream, p);        \
   }
     Q_CASE(64) Q_CASE(96) Q_CASE(160)
 #undef Q_CASE
