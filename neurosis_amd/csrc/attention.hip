@@ -98,8 +98,11 @@ struct TileLoader {
 // ================================================================================================
 // forward
 // ================================================================================================
+// Occupancy target 3 waves per SIMD (<= 168 VGPRs): left alone hipcc takes 192 registers (2 waves per SIMD) and these
+// VALU-heavy loops stall half their cycles with nobody to cover -- measured forward 314 -> 247 us at L = 4096 (696 TFLOP/s),
+// 66 -> 48 us at L = 1024; 4 waves per SIMD spills and is slower again (308 us).
 template <int DP, int NW = 4>   // NW waves x 32 rows per workgroup (2: twice the workgroups for short sequences)
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p) {
   constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 64 * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K,V][64][RS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -262,7 +265,7 @@ __global__ void attn_delta_kernel(const AttnParams p) {
 // backward: dK, dV.  Workgroup = 128 keys (4 waves x 32 keys on lanes), loops over 32-query tiles.
 // ================================================================================================
 template <int DP, int NW = 4>   // NW waves x 32 rows per workgroup (2: twice the workgroups for short sequences)
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dkdv_kernel(const AttnParams p) {
   constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 32 * RS;
   constexpr int STAGE = 2 * TILE + 256;  // Q tile, dO tile, lse2[32], delta[32]
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -441,7 +444,7 @@ __global__ void attn_dkv_reduce_kernel(const AttnParams p) {
 // backward: dQ.  Workgroup = 128 queries (on lanes), loops over 64-key tiles.
 // ================================================================================================
 template <int DP, int NW = 4>   // NW waves x 32 rows per workgroup (2: twice the workgroups for short sequences)
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParams p) {
   constexpr int RS = DP * 2 + 16, KS = DP / 16, DT = DP / 32, TILE = 64 * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
