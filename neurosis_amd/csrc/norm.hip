@@ -155,7 +155,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 //   per channel: a_c = sum dz, b_c = sum dz*xhat           -> dbeta += a, dgamma += b
 //   per (n,g):   s1 = sum_c gamma_c a_c, s2 = sum_c gamma_c b_c -> gsum[n][g][2]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GN_THREADS) void gn_bwd_stats_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(GN_THREADS, 4) void gn_bwd_stats_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   float* __restrict__ gsum, float* __restrict__ chan_part,
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 // dx = rstd * (dy*gamma - mean_c(dy*gamma) - xhat * mean_c(dy*gamma*xhat)) (+ dx_add).  One wavefront per row; x and dy stay
 // in registers as packed bf16 between the statistics pass and the output pass.
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, 4) void ln_bwd_dx_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
                                                         bf16_t* __restrict__ dx, int M, int C) {
