@@ -451,7 +451,8 @@ struct OperandDMA {
   long ld;
   int R, r0, wave, lane;
   int pn[NP], pbh[NP], pbw[NP];   // KCG: pixel decode of this thread's rows
-  int tkh[2], tkw[2], tc[2];   // MCG: tap / channel of this thread's r-chunk (two swizzle variants)
+  int tkh0, tkh1, tkw0, tkw1, tc0, tc1;   // MCG: tap / channel of this thread's r-chunk (two swizzle variants; scalars, not
+                                          // arrays: hipcc put the arrays in scratch and re-read them every k-step)
   bool rvalid[NP < 2 ? 2 : NP];  // KC*: row valid ; MC*: [0],[1] r-chunk variant valid
 
   __device__ __forceinline__ int kc_row(int i) const { return wave * (NP * 8) + i * 8 + (lane >> 3); }
@@ -460,7 +461,7 @@ struct OperandDMA {
   __device__ __forceinline__ int mc_var(int i) const { return (((wave * NP + i) * 4) >> 3) & 1; }   // (k >> 3) & 1 of that piece
   // two-way selects instead of runtime-indexed arrays (hipcc puts those in scratch)
   __device__ __forceinline__ bool mc_valid(int v) const { return v ? rvalid[1] : rvalid[0]; }
-  __device__ __forceinline__ int sel(const int (&a)[2], int v) const { return v ? a[1] : a[0]; }
+  __device__ __forceinline__ int sel(int a0, int a1, int v) const { return v ? a1 : a0; }
   __device__ __forceinline__ int mc_chunk(int v) const { return (lane & 15) ^ (((lane >> 4) | (v << 2)) << 1); }
 
   __device__ __forceinline__ void init(const bf16_t* p, long ld_, int R_, int r0_, int tid, const NkGather& g) {
@@ -489,10 +490,11 @@ struct OperandDMA {
         if constexpr (MODE == OP_MCG) {
           unsigned rr = rvalid[v] ? (unsigned)r : 0u;
           unsigned tap = fdiv(rr, g.fC);
-          tc[v] = (int)(rr - tap * g.fC.d);
+          const int c_ = (int)(rr - tap * g.fC.d);
           unsigned kh = fdiv(tap, g.fKW);
-          tkh[v] = (int)kh;
-          tkw[v] = (int)(tap - kh * g.fKW.d);
+          const int kw_ = (int)(tap - kh * g.fKW.d);
+          if (v == 0) { tc0 = c_; tkh0 = (int)kh; tkw0 = kw_; }
+          else { tc1 = c_; tkh1 = (int)kh; tkw1 = kw_; }
         }
       }
     }
@@ -550,7 +552,7 @@ struct OperandDMA {
         unsigned rem = p_ - n * g.fHoWo.d;
         unsigned ph = fdiv(rem, g.fWo);
         unsigned pw = rem - ph * g.fWo.d;
-        long off = gather_offset(g, (int)n, (int)ph * g.rs + g.off_h, (int)pw * g.rs + g.off_w, sel(tkh, v), sel(tkw, v), sel(tc, v), ok);
+        long off = gather_offset(g, (int)n, (int)ph * g.rs + g.off_h, (int)pw * g.rs + g.off_w, sel(tkh0, tkh1, v), sel(tkw0, tkw1, v), sel(tc0, tc1, v), ok);
         src[i] = ok ? P + off : zp;
       }
     }
@@ -564,17 +566,14 @@ struct OperandDMA {
   // inside the k loop there, which keeps hipcc from hoisting the row * ld products the way it does for issue()) ----
   int kcur;
   const bf16_t* rp[NP];
-  long rstep;
   __device__ __forceinline__ void start(int k_begin) {
     kcur = k_begin;
     if constexpr (MODE == OP_KC) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) rp[i] = P + (long)(r0 + kc_row(i)) * ld + (k_begin + kc_chunk() * 8);
-      rstep = BK;
     } else if constexpr (MODE == OP_MC) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) rp[i] = P + (long)(k_begin + mc_k(i)) * ld + r0 + mc_chunk(mc_var(i)) * 8;
-      rstep = (long)BK * ld;
     }
   }
   __device__ __forceinline__ void issue_next(int kend, char* img, const NkGather& g, const NkTapW& tw) {
@@ -587,7 +586,7 @@ struct OperandDMA {
         if constexpr (MODE == OP_KC) ok = (kcur + kc_chunk() * 8 < kend) && rvalid[i];
         else ok = (kcur + mc_k(i) < kend) && mc_valid(mc_var(i));
         src[i] = ok ? rp[i] : zp;
-        rp[i] += rstep;
+        rp[i] += MODE == OP_KC ? (long)BK : (long)BK * ld;   // (ld is wave-uniform: a scalar multiply)
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i)
