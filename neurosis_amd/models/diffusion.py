@@ -40,8 +40,8 @@ class DiffusionEngine(nn.Module):
                  scale_factor: float = 1.0, disable_first_stage_autocast: bool = False, input_key: str = "jpg", vae_batch_size: Optional[int] = None,
                  log_sigmas: bool = False, **kwargs):
         super().__init__()
-        if use_ema:
-            raise NotImplementedError("EMA is outside the hot path (use_ema: false in the reference configs)")
+        self.use_ema = use_ema                                    # models/diffusion.py:93-99; created in setup_flat_params()
+        self.ema_decay_rate = kwargs.pop("ema_decay_rate", 0.9999)
         self.input_key = input_key
         self.model = OpenAIWrapper(model)
         self.denoiser = denoiser
@@ -75,6 +75,8 @@ class DiffusionEngine(nn.Module):
         ops.state.assume_zeroed = False
         if ops.state.wgrad_stream is None:
             ops.state.wgrad_stream = torch.cuda.Stream()
+        if self.use_ema:
+            self.configure_ema(self.ema_decay_rate)
         return self.store
 
     def get_input(self, batch: dict) -> Tensor:

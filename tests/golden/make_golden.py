@@ -225,9 +225,42 @@ def adafactor_case():
     torch.save(out, HERE / "adafactor_steps.pt")
 
 
+def conditioner_case():
+    """GeneralConditioner with the SDXL cond_stage layout (modules/encoders/embedding.py:59-149, metadata.py:14-36): two
+    pass-through embedders standing in for the frozen text encoders' outputs (token features -> "crossattn", pooled ->
+    "vector") and three ConcatTimestepEmbedderND(256) for original size / crop / target size (lists of tuples, as the
+    dataset provides them)."""
+    from neurosis.modules.encoders.embedding import AbstractEmbModel, GeneralConditioner
+    from neurosis.modules.encoders.metadata import ConcatTimestepEmbedderND
+
+    class Passthrough(AbstractEmbModel):
+        def forward(self, x):
+            return x
+
+    g = torch.Generator().manual_seed(99)
+    batch = {
+        "image": torch.zeros(3, 3, 8, 8),
+        "tokens_l": torch.randn(3, 77, 48, generator=g),
+        "tokens_g": torch.randn(3, 77, 80, generator=g),
+        "pooled_g": torch.randn(3, 80, generator=g),
+        "original_size_as_tuple": [(1024, 1024), (832, 1216), (1536, 640)],
+        "crop_coords_top_left": [(0, 0), (64, 32), (7, 511)],
+        "target_size_as_tuple": [(1024, 1024), (832, 1216), (1344, 768)],
+    }
+    cond = GeneralConditioner([
+        Passthrough(input_key="tokens_l"), Passthrough(input_key="tokens_g"), Passthrough(input_key="pooled_g"),
+        ConcatTimestepEmbedderND(256, input_key="original_size_as_tuple"), ConcatTimestepEmbedderND(256, input_key="crop_coords_top_left"),
+        ConcatTimestepEmbedderND(256, input_key="target_size_as_tuple"),
+    ])
+    out = cond(batch)
+    zero = cond(batch, force_zero_embeddings=["pooled_g", "crop_coords_top_left"])
+    torch.save(dict(batch=batch, out=out, zero=zero), HERE / "conditioner_sdxl.pt")
+    print("conditioner:", {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -238,3 +271,5 @@ if __name__ == "__main__":
         op_cases(nd)
     if "adafactor" in which:
         adafactor_case()
+    if "conditioner" in which:
+        conditioner_case()

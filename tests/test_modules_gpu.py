@@ -214,3 +214,26 @@ def test_unet_non_square_latents_vs_oracle(hw):
     for k in ["input_blocks.0.0.weight", "input_blocks.3.0.op.weight", "output_blocks.2.2.conv.weight", "middle_block.1.transformer_blocks.0.attn1.to_q.weight",
               "output_blocks.8.0.skip_connection.weight", "out.2.weight"]:
         assert cosine(grads[k].grad, sd[k].grad) >= 0.99, k
+
+
+def test_general_conditioner_against_reference_golden():
+    """SURVEY 8(f) N3 glue: key routing, concatenation order, ConcatTimestepEmbedderND (sinusoidal embedding kernel, bf16) and
+    force_zero_embeddings, against the reference's GeneralConditioner (fixture from make_golden.py::conditioner_case)."""
+    from neurosis_amd.modules.encoders import ConcatTimestepEmbedderND, GeneralConditioner, PrecomputedEmbedder
+
+    fx = torch.load(G / "conditioner_sdxl.pt", weights_only=False)
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in fx["batch"].items()}
+    cond = GeneralConditioner([
+        PrecomputedEmbedder(input_key="tokens_l"), PrecomputedEmbedder(input_key="tokens_g"), PrecomputedEmbedder(input_key="pooled_g"),
+        ConcatTimestepEmbedderND(256, input_key="original_size_as_tuple"), ConcatTimestepEmbedderND(256, input_key="crop_coords_top_left"),
+        ConcatTimestepEmbedderND(256, input_key="target_size_as_tuple"),
+    ])
+    for got, want in ((cond(batch), fx["out"]), (cond(batch, force_zero_embeddings=["pooled_g", "crop_coords_top_left"]), fx["zero"])):
+        assert set(got) == set(want)
+        for k in want:
+            assert got[k].shape == want[k].shape
+            assert rel_err(got[k].float().cpu(), want[k]) <= 1e-2, k      # the embedding kernel writes bf16
+    with pytest.raises(ValueError):
+        GeneralConditioner([])
+    with pytest.raises(ValueError):
+        GeneralConditioner([torch.nn.Linear(2, 2)])
