@@ -383,8 +383,9 @@ class UNetModel(nn.Module):
 
         self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
         self.input_blocks[0]._nk_input_block = True
-        # called as hook(module) right after each top-level block's parameter gradients are final (backward order);
-        # the data-parallel wrapper uses it to start reducing that slice of the flat gradient buffer
+        # called as hook(module) right after each top-level block's parameter gradients have been ENQUEUED (backward order),
+        # on the current stream and on ops.state.wgrad_stream: a consumer must order itself after both streams.  The
+        # data-parallel wrapper uses it to start reducing that slice of the flat gradient buffer
         self.grad_ready_hook: Optional[Callable[[nn.Module], None]] = None
 
     # -- the network as an explicit forward / backward chain over HIP kernels --------------------
@@ -424,7 +425,8 @@ class UNetModel(nn.Module):
         def bwd(dout: Tensor):
             if hook_raw is not None:
                 def hook(m):
-                    ops.join_wgrad_stream()   # the block's weight gradients may still be in flight on the side stream
+                    # the block's weight gradients may still be in flight on the side stream: the hook's owner waits for that
+                    # stream itself (FlatDataParallel does, on its exchange stream), so backward is not stalled here
                     hook_raw(m)
             else:
                 hook = None
