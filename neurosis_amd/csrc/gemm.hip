@@ -713,6 +713,127 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
   nk_gemm_epilogue<OUT_F32, BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deep-ring variant for UNDER-FILLED grids (<= one workgroup per CU, e.g. the 100-tile 1280x1280 weight gradients): a lone
+// 8-wave workgroup cannot hide a loaded global-memory latency behind one k-step of its own MFMAs, and the LDS the second
+// workgroup would have used is idle -- so the ring gets FOUR stages (three slabs in flight), with counted s_waitcnt vmcnt
+// and raw barriers.  r-contiguous operands are read with ds_read_b64_tr_b16 through inline asm: hipcc would drain vmcnt(0)
+// in front of the builtin whenever an LDS-DMA is outstanding, which here is always.
+// ---------------------------------------------------------------------------------------------
+#define RING_NS 4
+#define RING_SMEM_BYTES (RING_NS * V2_STAGE_BYTES)    // 131072 >= 67584 (epilogue staging)
+
+template <int MODE>
+__device__ __forceinline__ bf16x8_t ring_frag(const char* img, int sub, int ks, int lane) {
+  if constexpr (MODE == OP_KC || MODE == OP_KCG) {
+    return OperandDMA<MODE>::frag(img, sub, ks, lane);
+  } else {
+    int g = lane >> 4, i = lane & 15;
+    int q = i >> 2, p = i & 3;
+    int k = ks * 32 + 8 * g + q;
+    int col = sub + 4 * p;
+    int byte_lo = k * 256 + (((col >> 3) ^ mc_swz(k)) << 4) + (col & 7) * 2;
+    int k2 = k + 4;
+    int byte_hi = k2 * 256 + (((col >> 3) ^ mc_swz(k2)) << 4) + (col & 7) * 2;
+    typedef __attribute__((address_space(3))) const char* lds_c;
+    const unsigned a_lo = (unsigned)(size_t)(lds_c)(img + byte_lo), a_hi = (unsigned)(size_t)(lds_c)(img + byte_hi);
+    short4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a_lo));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a_hi));
+    short8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, r);
+  }
+}
+
+template <int AMODE, int BMODE, int OUT_F32>
+__global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NJ = 2, NP = 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int per_group = GROUP_M * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(GROUP_M, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int mt = first_m + (in_group - nt * gm);
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int kbeg = blockIdx.y * p.ksplit_len;
+  const int kend = min(p.K, kbeg + p.ksplit_len);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  OperandDMA<AMODE, NP> opa;
+  OperandDMA<BMODE, NP> opb;
+  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+
+  float4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < RING_NS - 1; ++t)
+    if (t < nk) {
+      opa.issue(kbeg + t * BK, kend, smem + t * V2_STAGE_BYTES, p.ga, p.tw);
+      opb.issue(kbeg + t * BK, kend, smem + t * V2_STAGE_BYTES + V2_OPND_BYTES, p.gb, p.tw);
+    }
+  int cur_stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // every wave issued 4 pieces per slab, in order: slab kt has landed once at most the pieces of the later slabs remain
+    const int later = min(nk - 1 - kt, RING_NS - 2);
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // slab kt is in LDS for every wave; every wave is done reading stage (kt - 1) % NS
+    const char* cur = smem + cur_stage * V2_STAGE_BYTES;
+    bf16x8_t af[2][4], bfr[2][NJ];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[ks][i] = ring_frag<AMODE>(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[ks][j] = ring_frag<BMODE>(cur + V2_OPND_BYTES, wn * (NJ * 16) + j * 16, ks, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + RING_NS - 1 < nk) {
+      int ns = cur_stage + RING_NS - 1; if (ns >= RING_NS) ns -= RING_NS;
+      opa.issue(kbeg + (kt + RING_NS - 1) * BK, kend, smem + ns * V2_STAGE_BYTES, p.ga, p.tw);
+      opb.issue(kbeg + (kt + RING_NS - 1) * BK, kend, smem + ns * V2_STAGE_BYTES + V2_OPND_BYTES, p.gb, p.tw);
+    }
+    // the asm reads are invisible to hipcc's wait insertion: wait here, with the fragments as operands so the MFMAs below
+    // cannot be scheduled above it
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]),
+                   "+v"(af[1][3]), "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[1][0]), "+v"(bfr[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    if (++cur_stage == RING_NS) cur_stage = 0;
+  }
+  __syncthreads();
+  nk_gemm_epilogue<OUT_F32, BM, 512, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
+}
+
 // =============================================================================================
 // stream-K main kernel (default).  Measured on the 128x128 data-parallel kernel above: a k-step costs 0.94 us per
 // round of 512 tiles, but every round also pays ~4.5 us of fixed cost (first loads from a cold pipeline, LDS-staged
@@ -1166,6 +1287,15 @@ static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
   // 8 waves per 128x128 tile by default: measured +4..14 % over 4 waves on every SDXL shape (A/B: NK_GEMM_NW=4)
   int nw = 8;
   if (const char* e = getenv("NK_GEMM_NW")) nw = atoi(e);
+  int ring = 1;
+  if (const char* e = getenv("NK_GEMM_RING")) ring = atoi(e);
+  if (ring && !use_v1() && nw == 8 && !p.nbatch && (long)ntm * ntn * splitk <= 256) {
+    auto kernr = nk_gemm_ring_kernel<AMODE, BMODE, OUT_F32>;
+    static bool rattr = false;
+    if (!rattr) { (void)hipFuncSetAttribute((const void*)kernr, hipFuncAttributeMaxDynamicSharedMemorySize, RING_SMEM_BYTES); rattr = true; }
+    hipLaunchKernelGGL(kernr, grid, dim3(512), RING_SMEM_BYTES, stream, p);
+    return nk_check_launch("nk_gemm_ring_kernel");
+  }
   if (use_v1()) hipLaunchKernelGGL(kern1, grid, dim3(NTHREADS), SMEM_BYTES, stream, p);
   else if (nw == 8) hipLaunchKernelGGL(kern8, grid, dim3(512), V2_SMEM_BYTES, stream, p);
   else hipLaunchKernelGGL(kern4, grid, dim3(NTHREADS), V2_SMEM_BYTES, stream, p);
