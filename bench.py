@@ -253,6 +253,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--accumulate", type=int, default=1,
+                    help="micro-batches per optimizer step (the reference example config uses accumulate_grad_batches: 4); "
+                         "a 'step' then is one optimizer step = ACCUMULATE micro-batches of --batch images; not the metric's configuration")
     ap.add_argument("--mixed-res", action="store_true",
                     help="BASELINE config 4: every step each rank draws one aspect bucket (W,H) from the SDXL bucket list "
                          "{832x1216, 1216x832, 1024x1024, 896x1152, 1152x896}; not the metric's configuration")
@@ -302,13 +305,15 @@ def main():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             step_marks.append(ev)
-        hw = (args.res, args.res)
-        if args.mixed_res:   # (H, W) of this rank's bucket for this step (N/dataset/aspect/lists.py:14-56)
-            hw = MIXED_BUCKETS[int(torch.randint(len(MIXED_BUCKETS), (1,), generator=gen_cpu))]
-        batch = synthetic_batch(device, args.batch, hw, gen)
-        sig = draw_sigmas(args.batch, gen_cpu, device)
-        loss = eng.training_step(batch, 0, sigmas=sig)
-        loss.backward()
+        for mb in range(args.accumulate):
+            hw = (args.res, args.res)
+            if args.mixed_res:   # (H, W) of this rank's bucket for this step (N/dataset/aspect/lists.py:14-56)
+                hw = MIXED_BUCKETS[int(torch.randint(len(MIXED_BUCKETS), (1,), generator=gen_cpu))]
+            batch = synthetic_batch(device, args.batch, hw, gen)
+            sig = draw_sigmas(args.batch, gen_cpu, device)
+            eng.accumulate(mb, dp, last=mb == args.accumulate - 1)
+            loss = eng.training_step(batch, 0, sigmas=sig)
+            (loss / args.accumulate).backward()
         gs = 1.0
         if dp is not None:
             if mark:
@@ -359,7 +364,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss_val = float(last.detach())
-    images = args.steps * args.batch * world
+    images = args.steps * args.batch * world * args.accumulate
     value = images / dt
     ms_per_step = dt / args.steps * 1e3
 
@@ -394,7 +399,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SDXL-base {'mixed-res buckets (~1024^2 pixels)' if args.mixed_res else str(args.res) + '^2'} bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, frozen TE outputs synthetic",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "activation_checkpointing": False, "accumulate_grad_batches": 1},
+                       "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}", "activation_checkpointing": False, "accumulate_grad_batches": args.accumulate},
             "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "comm": comm,
             "stream_k_fixup_timeouts": lib.query("nk_gemm_sk_status"),   # 0: every K-split tile was joined (gemm.hip)

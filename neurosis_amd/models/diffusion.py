@@ -106,6 +106,14 @@ class DiffusionEngine(nn.Module):
         self.last_log = {"train/loss": loss.detach().mean(), "train/loss_s0": loss.detach()[0]}
         return loss.mean()
 
+    def accumulate(self, micro_batch_index: int, dp=None, last: bool = True):
+        """Gradient accumulation (Lightning's `accumulate_grad_batches`, configs/sdxl/sdxl.example.yaml): call before the
+        backward of micro-batch `micro_batch_index` of an optimizer step.  The first micro-batch overwrites the gradients,
+        later ones add; with a FlatDataParallel `dp`, only the last micro-batch exchanges them (DDP's no_sync)."""
+        ops.state.grad_accumulate = micro_batch_index > 0
+        if dp is not None:
+            dp.no_sync(not last)
+
     def configure_adafactor(self, **kwargs):
         """Use the fused multi-tensor Adafactor (reference optimizers/adafactor.py; the optimizer the example configs name,
         configs/sdxl/sdxl.example.yaml:158-169) for optimizer_step().  kwargs as the reference class's; returns it."""
@@ -137,4 +145,5 @@ class DiffusionEngine(nn.Module):
             self.store.adamw_step(lr, betas, eps, weight_decay, grad_scale)
         if getattr(self, "model_ema", None) is not None:
             self.model_ema.update()
+        ops.state.grad_accumulate = False
         self.global_step += 1

@@ -75,3 +75,28 @@ def test_flat_data_parallel_two_ranks_one_gpu():
     assert out["scale"] == 0.5
     # bf16 activations: per-rank batches of 1 vs one batch of 2 round differently; same bound as the golden-vector test
     assert out["cos"] >= 0.999 and out["err"] <= 5e-2, dict(out)
+
+
+def test_engine_accumulate_helper_overwrites_then_adds():
+    """DiffusionEngine.accumulate(i): micro-batch 0 overwrites the flat gradient buffer (no zero-fill between steps), later
+    ones add; optimizer_step() resets the mode."""
+    from neurosis_amd import ops
+
+    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
+    eng = _build(fx, shapes)
+    sel = slice(0, 2)
+    eng.accumulate(0)
+    _loss(eng, fx, sel).mean().backward()
+    torch.cuda.synchronize()
+    g1 = eng.store.grad.clone()
+    eng.accumulate(0)                       # a new "step" without any zero-fill: overwritten, not doubled
+    _loss(eng, fx, sel).mean().backward()
+    torch.cuda.synchronize()
+    assert float((eng.store.grad - g1).norm() / g1.norm()) < 1e-2
+    eng.accumulate(1)
+    _loss(eng, fx, sel).mean().backward()
+    torch.cuda.synchronize()
+    assert float((eng.store.grad - 2 * g1).norm() / (2 * g1).norm()) < 1e-2
+    eng.optimizer_step(lr=1e-6)
+    assert ops.state.grad_accumulate is False
