@@ -1,8 +1,8 @@
-"""Denoiser / DiscreteDenoiser: mirror of neurosis.modules.diffusion.denoiser (denoiser.py:17-97).
+"""Denoiser / DiscreteDenoiser with the reference's class surface (`neurosis.modules.diffusion.denoiser`, :17-97).
 
-`forward` is the reference's generic path (works with any network module; a handful of [B]- and latent-sized
-elementwise ops).  `coefficients` exposes the same per-sample scalars to the fused HIP training path
-(StandardDiffusionLoss), where the scaling is folded into the nk_edm_prepare / nk_edm_loss kernels.
+Two consumers: the generic `forward` (any network module; a handful of [B]- and latent-sized elementwise ops) and the
+fused HIP training path (`StandardDiffusionLoss`), which asks `coefficients()` for the same per-sample scalars and folds
+them into the nk_edm_prepare / nk_edm_loss kernels.
 """
 from __future__ import annotations
 
@@ -13,7 +13,6 @@ from torch import Tensor, nn
 
 from .denoiser_preconditioning import DenoiserPreconditioning
 from .discretization import Discretization
-from .util import append_dims
 
 
 class Denoiser(nn.Module):
@@ -21,6 +20,7 @@ class Denoiser(nn.Module):
         super().__init__()
         self.preconditioning = preconditioning
 
+    # hooks the discrete variant overrides -------------------------------------------------------
     def possibly_quantize_sigma(self, sigma: Tensor) -> Tensor:
         return sigma
 
@@ -28,47 +28,49 @@ class Denoiser(nn.Module):
         return c_noise
 
     def coefficients(self, sigma: Tensor):
-        """(c_skip, c_out, c_in, c_noise) as [B] tensors, exactly as forward computes them (denoiser.py:37-47)."""
-        sigma = self.possibly_quantize_sigma(sigma)
-        c_skip, c_out, c_in, c_noise = self.preconditioning(sigma)
-        return c_skip, c_out, c_in, self.possibly_quantize_c_noise(c_noise.reshape(sigma.shape))
+        """(c_skip, c_out, c_in, c_noise), each shaped like `sigma`, c_noise already quantised."""
+        snapped = self.possibly_quantize_sigma(sigma)
+        skip, out, cin, noise = self.preconditioning(snapped)
+        return skip, out, cin, self.possibly_quantize_c_noise(noise.reshape(snapped.shape))
 
     def forward(self, network: nn.Module, inputs: Tensor, sigma: Tensor, cond: dict, output_mode: str = "D", **additional_model_inputs) -> Tensor:
-        sigma = self.possibly_quantize_sigma(sigma)
-        sigma_shape = sigma.shape
-        sigma = append_dims(sigma, inputs.ndim)
-        c_skip, c_out, c_in, c_noise = self.preconditioning(sigma)
-        c_noise = self.possibly_quantize_c_noise(c_noise.reshape(sigma_shape))
-        c_in, c_out, c_skip = c_in.to(inputs.dtype), c_out.to(inputs.dtype), c_skip.to(inputs.dtype)
-        net_outputs = network(inputs * c_in, c_noise, cond, **additional_model_inputs)
-        if output_mode == "F":
-            return net_outputs
-        return net_outputs * c_out + inputs * c_skip
+        if output_mode not in ("D", "F"):
+            raise ValueError(f"output_mode must be 'D' (denoised) or 'F' (raw network output), got {output_mode!r}")
+        if sigma.ndim != 1 or sigma.shape[0] != inputs.shape[0]:
+            raise ValueError(f"sigma must hold one value per sample: got {tuple(sigma.shape)} for a batch of {inputs.shape[0]}")
+        skip, out, cin, noise = self.coefficients(sigma)
+        bshape = (-1,) + (1,) * (inputs.ndim - 1)          # broadcast the [B] scalars over the latent dims
+        prediction = network(inputs * cin.reshape(bshape).to(inputs.dtype), noise, cond, **additional_model_inputs)
+        if output_mode == "F":                              # raw network output
+            return prediction
+        return prediction * out.reshape(bshape).to(inputs.dtype) + inputs * skip.reshape(bshape).to(inputs.dtype)
 
 
 class DiscreteDenoiser(Denoiser):
-    """denoiser.py:60-97: sigma and c_noise snapped to the nearest entry of the discretisation's table."""
+    """sigma and c_noise are snapped to the nearest entry of the discretisation's table (reference :60-97)."""
 
     def __init__(self, preconditioning: DenoiserPreconditioning, num_idx: int, discretization: Discretization, do_append_zero: bool = False,
                  quantize_c_noise: bool = True, flip: bool = False):
         super().__init__(preconditioning)
-        self.num_idx = num_idx
-        self.quantize_c_noise = quantize_c_noise
-        self.do_append_zero = do_append_zero
-        self.flip = flip
-        sigmas = discretization(self.num_idx, do_append_zero=self.do_append_zero, flip=self.flip).detach()
-        self.register_buffer("sigmas", sigmas, persistent=False)
-        self.register_buffer("log_sigmas", sigmas.log(), persistent=False)
+        self.num_idx, self.quantize_c_noise, self.do_append_zero, self.flip = num_idx, quantize_c_noise, do_append_zero, flip
+        table = discretization(num_idx, do_append_zero=do_append_zero, flip=flip).detach()
+        self.register_buffer("sigmas", table, persistent=False)
+        self.register_buffer("log_sigmas", table.log(), persistent=False)
 
     def sigma_to_idx(self, sigma: Tensor) -> Tensor:
-        dists = sigma - self.sigmas[:, None]
-        return dists.abs().argmin(dim=0).view(sigma.shape)
+        """index of the nearest table entry (first one on ties), same shape as `sigma`"""
+        distance = (self.sigmas.unsqueeze(1) - sigma.reshape(1, -1)).abs()
+        return distance.argmin(dim=0).reshape(sigma.shape)
+
+    def extra_repr(self) -> str:
+        lo, hi = float(self.sigmas.min()), float(self.sigmas.max())
+        return f"num_idx={self.num_idx}, sigma=[{lo:.4g}, {hi:.4g}], quantize_c_noise={self.quantize_c_noise}, flip={self.flip}"
 
     def idx_to_sigma(self, idx: Union[Tensor, int]) -> Tensor:
         return self.sigmas[idx]
 
     def possibly_quantize_sigma(self, sigma: Tensor) -> Tensor:
-        return self.idx_to_sigma(self.sigma_to_idx(sigma))
+        return self.sigmas[self.sigma_to_idx(sigma)]
 
     def possibly_quantize_c_noise(self, c_noise: Tensor) -> Tensor:
         return self.sigma_to_idx(c_noise) if self.quantize_c_noise else c_noise

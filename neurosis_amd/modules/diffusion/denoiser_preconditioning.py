@@ -1,75 +1,71 @@
-"""c_skip / c_out / c_in / c_noise (host-side, [B] scalars): mirror of neurosis.modules.diffusion.denoiser_preconditioning."""
+"""Input / output scalings of the denoiser (host side, [B]-sized tensors).
+
+API of `neurosis.modules.diffusion.denoiser_preconditioning` (reference :8-105): an object called with sigma returns
+`(c_skip, c_out, c_in, c_noise)`; the `get_c_*` accessors exist because the reference exposes them.  Here every variant
+is ONE `scalings(sigma)` method and the accessors are derived from it.
+
+    D(x; sigma) = c_skip * x + c_out * F(c_in * x; c_noise)
+"""
 from __future__ import annotations
 
-from abc import ABC, abstractmethod
 from typing import Tuple
 
 import torch
 from torch import Tensor
 
+Scalings = Tuple[Tensor, Tensor, Tensor, Tensor]
 
-class DenoiserPreconditioning(ABC):
-    """denoiser_preconditioning.py:8-31."""
 
-    def __call__(self, sigma: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-        return self.get_c_skip(sigma), self.get_c_out(sigma), self.get_c_in(sigma), self.get_c_noise(sigma)
+class DenoiserPreconditioning:
+    def scalings(self, sigma: Tensor) -> Scalings:
+        raise NotImplementedError(f"{type(self).__name__} does not define scalings()")
 
-    @abstractmethod
-    def get_c_skip(self, sigma: Tensor) -> Tensor: ...
+    def __call__(self, sigma: Tensor) -> Scalings:
+        return self.scalings(sigma)
 
-    @abstractmethod
-    def get_c_out(self, sigma: Tensor) -> Tensor: ...
+    def get_c_skip(self, sigma: Tensor) -> Tensor:
+        return self.scalings(sigma)[0]
 
-    @abstractmethod
-    def get_c_in(self, sigma: Tensor) -> Tensor: ...
+    def get_c_out(self, sigma: Tensor) -> Tensor:
+        return self.scalings(sigma)[1]
 
-    @abstractmethod
-    def get_c_noise(self, sigma: Tensor) -> Tensor: ...
+    def get_c_in(self, sigma: Tensor) -> Tensor:
+        return self.scalings(sigma)[2]
+
+    def get_c_noise(self, sigma: Tensor) -> Tensor:
+        return self.scalings(sigma)[3]
 
     def get_snr(self, sigma: Tensor) -> Tensor:
-        return 1 / sigma**2.0
+        return sigma.square().reciprocal()
+
+
+def _inv_norm(sigma: Tensor, offset: float) -> Tensor:
+    """1 / sqrt(sigma^2 + offset)"""
+    return (sigma.square() + offset).sqrt().reciprocal()
 
 
 class EpsPreconditioning(DenoiserPreconditioning):
-    """denoiser_preconditioning.py:33-44."""
+    """The network predicts the noise: x0 = x - sigma * eps(x / sqrt(sigma^2 + 1); sigma)   (reference :33-44)."""
 
-    def get_c_skip(self, sigma: Tensor) -> Tensor:
-        return torch.ones_like(sigma, device=sigma.device)
-
-    def get_c_out(self, sigma: Tensor) -> Tensor:
-        return -sigma
-
-    def get_c_in(self, sigma: Tensor) -> Tensor:
-        return 1.0 / (sigma**2.0 + 1.0) ** 0.5
-
-    def get_c_noise(self, sigma: Tensor) -> Tensor:
-        return sigma.clone()
+    def scalings(self, sigma: Tensor) -> Scalings:
+        return torch.ones_like(sigma), sigma.neg(), _inv_norm(sigma, 1.0), sigma.clone()
 
 
-class VPreconditioning(EpsPreconditioning):
-    """denoiser_preconditioning.py:47-52."""
+class VPreconditioning(DenoiserPreconditioning):
+    """v-prediction (reference :47-52)."""
 
-    def get_c_skip(self, sigma: Tensor) -> Tensor:
-        return 1.0 / (sigma**2 + 1.0)
-
-    def get_c_out(self, sigma: Tensor) -> Tensor:
-        return -sigma / (sigma**2 + 1.0) ** 0.5
+    def scalings(self, sigma: Tensor) -> Scalings:
+        inv = _inv_norm(sigma, 1.0)
+        return (sigma.square() + 1.0).reciprocal(), sigma.neg() * inv, inv, sigma.clone()
 
 
 class EDMPreconditioning(DenoiserPreconditioning):
-    """denoiser_preconditioning.py:60-77."""
+    """Karras et al. 2022, table 1 (reference :60-77)."""
 
     def __init__(self, sigma_data: float = 0.5):
         self.sigma_data = sigma_data
 
-    def get_c_skip(self, sigma: Tensor) -> Tensor:
-        return self.sigma_data**2 / (sigma**2 + self.sigma_data**2)
-
-    def get_c_out(self, sigma: Tensor) -> Tensor:
-        return sigma * self.sigma_data / (sigma**2 + self.sigma_data**2) ** 0.5
-
-    def get_c_in(self, sigma: Tensor) -> Tensor:
-        return 1 / (sigma**2 + self.sigma_data**2) ** 0.5
-
-    def get_c_noise(self, sigma: Tensor) -> Tensor:
-        return 0.25 * sigma.log()
+    def scalings(self, sigma: Tensor) -> Scalings:
+        var = self.sigma_data ** 2
+        inv = _inv_norm(sigma, var)
+        return var / (sigma.square() + var), sigma * self.sigma_data * inv, inv, sigma.log() * 0.25

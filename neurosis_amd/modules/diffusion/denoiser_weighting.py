@@ -1,34 +1,36 @@
-"""Loss weights w(sigma) (host side): mirror of neurosis.modules.diffusion.denoiser_weighting."""
+"""Per-sample loss weights w(sigma) (host side).  Class names and call signature of
+`neurosis.modules.diffusion.denoiser_weighting` (reference :16-101, the variants the diffusion configs use)."""
 from __future__ import annotations
-
-from abc import ABC, abstractmethod
 
 import torch
 from torch import Tensor
 
 
-class DenoiserWeighting(ABC):
-    @abstractmethod
-    def __call__(self, sigma: Tensor) -> Tensor: ...
+class DenoiserWeighting:
+    def __call__(self, sigma: Tensor) -> Tensor:
+        raise NotImplementedError(f"{type(self).__name__} does not define a weight")
 
 
 class UnitWeighting(DenoiserWeighting):
+    """w = 1"""
+
     def __call__(self, sigma: Tensor) -> Tensor:
-        return torch.ones_like(sigma, device=sigma.device)
+        return torch.ones_like(sigma)
 
 
 class EpsWeighting(DenoiserWeighting):
-    """denoiser_weighting.py:22-25."""
+    """w = sigma^-2: an MSE on x0 becomes an MSE on the predicted noise (reference :22-25)."""
 
     def __call__(self, sigma: Tensor) -> Tensor:
-        return sigma**-2.0
+        return sigma.pow(-2.0)
 
 
 class EDMWeighting(DenoiserWeighting):
-    """denoiser_weighting.py:28-35."""
+    """w = (sigma^2 + sigma_data^2) / (sigma * sigma_data)^2   (Karras et al. 2022; reference :28-35)."""
 
     def __init__(self, sigma_data: float = 1.0):
         self.sigma_data = sigma_data
 
     def __call__(self, sigma: Tensor) -> Tensor:
-        return (sigma**2 + self.sigma_data**2) / (sigma * self.sigma_data) ** 2
+        sd = self.sigma_data
+        return (sigma.square() + sd * sd) / (sigma * sd).square()

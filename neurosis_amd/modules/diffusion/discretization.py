@@ -1,56 +1,53 @@
-"""Sigma tables (host side, fp32/fp64 scalars): mirror of neurosis.modules.diffusion.discretization."""
+"""Sigma tables (host side, fp32).  Class names / call signature of `neurosis.modules.diffusion.discretization`.
+
+Two reference behaviours are kept on purpose: the call's `do_append_zero` ARGUMENT is ignored in favour of
+the constructor attribute (Q1: the SDXL table therefore has 1 001 entries), and the legacy DDPM table holds the same
+values as the reference's but without its autograd graph (Q5)."""
 from __future__ import annotations
 
-from abc import ABC, abstractmethod
-from math import log
+import math
 
 import numpy as np
 import torch
 from torch import Tensor
 
-from .util import append_zero, make_beta_schedule
+from .util import make_beta_schedule
 
 
 def generate_roughly_equally_spaced_steps(num_substeps: int, max_step: int) -> np.ndarray:
-    return np.linspace(max_step - 1, 0, num_substeps, endpoint=False).astype(int)[::-1]
+    """`num_substeps` ascending step indices ending at max_step - 1 (reference discretization.py:13-14)."""
+    descending = np.linspace(max_step - 1, 0, num_substeps, endpoint=False).astype(int)
+    return descending[::-1]
 
 
-class Discretization(ABC):
-    """discretization.py:17-40.  NOTE: __call__ ignores its do_append_zero argument and uses the
-    instance attribute (default True); reproduced so the sigma table has the reference's 1001 entries."""
-
+class Discretization:
     def __init__(self, do_append_zero: bool = True):
-        super().__init__()
         self.do_append_zero = do_append_zero
 
-    def __call__(self, n: int, do_append_zero: bool = True, device="cpu", flip: bool = False) -> Tensor:
-        sigmas = self.get_sigmas(n, device=device)
-        if self.do_append_zero:
-            sigmas = append_zero(sigmas)
-        if flip:
-            sigmas = sigmas.flip((0,))
-        return sigmas
-
-    @abstractmethod
     def get_sigmas(self, n: int, device) -> Tensor:
-        raise NotImplementedError("Abstract base class was called ;_;")
+        raise NotImplementedError(f"{type(self).__name__} does not define a sigma table")
+
+    def __call__(self, n: int, do_append_zero: bool = True, device="cpu", flip: bool = False) -> Tensor:
+        table = self.get_sigmas(n, device=device)
+        if self.do_append_zero:                      # (the argument of the same name is deliberately unused: Q1)
+            table = torch.cat([table, table.new_zeros(1)])
+        return table.flip(0) if flip else table
 
 
 class EDMcDiscretization(Discretization):
-    """discretization.py:43-57."""
+    """log-uniform between sigma_min and sigma_max, descending (reference :43-57)."""
 
     def __init__(self, sigma_min: float = 0.001, sigma_max: float = 1000.0):
         super().__init__()
         self.sigma_min, self.sigma_max = sigma_min, sigma_max
 
     def get_sigmas(self, n: int, device="cpu") -> Tensor:
-        sigmas = torch.linspace(log(self.sigma_min), log(self.sigma_max), n, dtype=torch.float32).exp()
-        return sigmas.flip(0).to(device)
+        log_sigmas = torch.linspace(math.log(self.sigma_min), math.log(self.sigma_max), n, dtype=torch.float32)
+        return log_sigmas.exp().flip(0).to(device)
 
 
 class LegacyDDPMDiscretization(Discretization):
-    """discretization.py:149-171.  The table is detached (the reference's carries an autograd graph that breaks a
-    second backward; the values are identical)."""
+    """sigma_t = sqrt((1 - abar_t) / abar_t) of the linear-beta DDPM schedule, descending (reference :149-171)."""
 
     def __init__(self, linear_start: float = 0.00085, linear_end: float = 0.0120, num_timesteps: int = 1000):
         super().__init__()
@@ -59,12 +56,10 @@ class LegacyDDPMDiscretization(Discretization):
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0, dtype=torch.float32)
 
     def get_sigmas(self, n: int, device="cpu") -> Tensor:
-        if n < self.num_timesteps:
-            timesteps = generate_roughly_equally_spaced_steps(n, self.num_timesteps)
-            alphas_cumprod = self.alphas_cumprod[timesteps.copy()].clone()
-        elif n == self.num_timesteps:
-            alphas_cumprod = self.alphas_cumprod.clone()
-        else:
+        if n > self.num_timesteps:
             raise ValueError(f"n ({n}) must be less than or equal to num_timesteps ({self.num_timesteps})")
-        sigmas = ((1 - alphas_cumprod) / alphas_cumprod) ** 0.5
-        return sigmas.flip(0).to(device, dtype=torch.float32)
+        abar = self.alphas_cumprod
+        if n < self.num_timesteps:
+            abar = abar[generate_roughly_equally_spaced_steps(n, self.num_timesteps).copy()]
+        table = ((1 - abar) / abar) ** 0.5
+        return table.flip(0).to(device, dtype=torch.float32)

@@ -116,9 +116,8 @@ class StandardDiffusionLoss(DiffusionLoss):
         if noise is None:
             noise = torch.randn_like(inputs)
         noise = self.apply_noise_offset(noise, inputs)
-        unet = getattr(network, "diffusion_model", None)
-        fusable = isinstance(network, OpenAIWrapper) and isinstance(unet, UNetModel) and inputs.is_cuda and not extra_inputs and cond.get("concat", None) is None
-        if fusable:
+        unet = network.fused_unet(inputs, cond, extra_inputs) if isinstance(network, OpenAIWrapper) else None
+        if unet is not None:
             loss = self.fused_edm(unet, denoiser, self.loss_weighting, inputs, sigmas, noise, cond)
         else:
             sigmas_bc = append_dims(sigmas, inputs.ndim)

@@ -1,6 +1,6 @@
-"""`ConcatTimestepEmbedderND` (reference `modules/encoders/metadata.py:14-36`): the SDXL size / crop / target-size
-conditioning -- every scalar gets its own sinusoidal embedding (`Timestep(outdim)` -> nk_timestep_embedding) and the
-embeddings of one sample are concatenated: (B, dims) -> (B, dims * outdim)."""
+"""`ConcatTimestepEmbedderND` (name and behaviour of reference `modules/encoders/metadata.py:14-36`): SDXL's original-size /
+crop / target-size conditioning.  Every scalar of a sample gets its own sinusoidal embedding (the nk_timestep_embedding
+kernel via `Timestep`), and a sample's embeddings are laid side by side: (B, n) -> (B, n * outdim)."""
 from __future__ import annotations
 
 import torch
@@ -13,16 +13,14 @@ from .embedding import AbstractEmbModel
 class ConcatTimestepEmbedderND(AbstractEmbModel):
     def __init__(self, outdim, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.timestep = Timestep(outdim)
         self.outdim = outdim
+        self.timestep = Timestep(outdim)
 
     def forward(self, x):
-        if isinstance(x, list):
-            x = torch.stack(x, dim=-1)
-        if x.ndim == 1:
-            x = x[:, None]
-        if x.ndim != 2:
-            raise ValueError(f"Expected 2D input, got {x.ndim}D")
-        b, dims = x.shape[0], x.shape[1]
-        emb = self.timestep(x.reshape(b * dims))
-        return emb.reshape(b, dims * self.outdim)
+        values = torch.stack(x, dim=-1) if isinstance(x, list) else x
+        if values.ndim == 1:
+            values = values.unsqueeze(1)
+        if values.ndim != 2:
+            raise ValueError(f"Expected 2D input, got {values.ndim}D")
+        batch, count = values.shape
+        return self.timestep(values.flatten()).reshape(batch, count * self.outdim)
