@@ -166,6 +166,23 @@ int nk_edm_prepare(const float* x, const float* eps, const float* sigma, const f
 int nk_edm_loss(const void* net_out, const float* zt, const float* target, const float* c_out, const float* c_skip,
                 const float* w, float* loss, void* dnet, int B, int C, int HW, int Cpad, float upstream, void* stream);
 
+/* Sampler-side latent kernels.  x / denoised / x_next: fp32 NCHW [B][C][HW]; net_in / net_out: bf16
+ * channels-last tokens [rep*B][HW][Cpad], rep = 2 for classifier-free guidance laid out [uncond | cond]
+ * (VanillaCFG.prepare_inputs, modules/guidance.py:26-37).
+ * prepare:    net_in[r*B+b] = bf16(c_in[b] * x[b]) for r < rep        (Denoiser.forward input scaling, denoiser.py:41-49,
+ *             + the guider's torch.cat([x] * 2))
+ * denoise:    D = c_skip[b]*x + c_out[b]*(F_u + scale*(F_c - F_u))    (denoiser.py:49-53 + VanillaCFG.__call__ guidance.py:21-24;
+ *             rep == 1: F = net_out, scale ignored)
+ * euler_step: d = (x - D)/sigma_hat[b]; x_next = x + (sigma_next[b] - sigma_hat[b])*d   (EDMSampler.sampler_step with the
+ *             Euler correction, sampling/sampling.py:166-181,313-316, to_d sampling/utils.py:49-51).  x_next may alias x;
+ *             `denoised` is optional (NULL to skip). */
+int nk_sample_prepare(const float* x, const float* c_in, void* net_in, int B, int C, int HW, int Cpad, int rep, void* stream);
+int nk_sample_denoise(const void* net_out, const float* x, const float* c_skip, const float* c_out, float scale,
+                      float* denoised, int B, int C, int HW, int Cpad, int rep, void* stream);
+int nk_sample_euler_step(const void* net_out, const float* x, const float* c_skip, const float* c_out, const float* sigma_hat,
+                         const float* sigma_next, float scale, float* x_next, float* denoised, int B, int C, int HW, int Cpad,
+                         int rep, void* stream);
+
 /* Fused AdamW over the flat fp32 parameter buffer; also rewrites the bf16 shadow the kernels read.
  * (The optimizer itself is outside SURVEY section 8(a); bench.py needs a real parameter update in the timed step.) */
 int nk_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1,

@@ -66,6 +66,9 @@ SIGNATURES: dict[str, list] = {
     "nk_timestep_embedding": [vp, vp, i32, i32, f32, vp],
     "nk_edm_prepare": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "nk_edm_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "nk_sample_prepare": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "nk_sample_denoise": [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, i32, vp],
+    "nk_sample_euler_step": [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp],
     "nk_adamw_flat": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
     "nk_ema_flat": [vp, vp, i64, f32, vp],
     "nk_adafactor_init": [vp, vp],

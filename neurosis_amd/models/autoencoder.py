@@ -1,7 +1,8 @@
-"""AutoencoderKL holder: the slice of neurosis.models.autoencoder (autoencoder.py:429-522) the SDXL training
-step touches -- construction, weight layout (encoder.*, quant_conv.*), freeze()/eval().  The hot path only
-runs the ENCODER forward (DiffusionEngine.encode_first_stage, models/diffusion.py:186-197); the decoder and
-the VAE's own training step are outside SURVEY section 8(a) (row N2 of 8(f)) and are not built.
+"""AutoencoderKL holder: the slice of neurosis.models.autoencoder (autoencoder.py:429-522) the diffusion engine
+touches -- construction, weight layout (encoder.*, decoder.*, quant_conv.*, post_quant_conv.*), freeze()/eval(),
+encode() and decode().  The training step only runs the ENCODER forward (DiffusionEngine.encode_first_stage,
+models/diffusion.py:186-197); the decoder forward serves sampling / log_images.  The VAE's own
+training step (row N2) is not built.
 """
 from __future__ import annotations
 
@@ -10,7 +11,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from ..modules.diffusion.model import Encoder
+from ..modules.diffusion.model import Decoder, Encoder
 from ..nn import Conv2d
 
 
@@ -21,11 +22,11 @@ class AutoencoderKL(nn.Module):
         dd.pop("standalone", None)
         self.embed_dim = embed_dim
         self.encoder = Encoder(**dd, embed_dim=embed_dim, standalone=False)
-        self.decoder = None  # out of scope (inference / VAE training only)
+        self.decoder = Decoder(**dd, embed_dim=embed_dim, standalone=False)
         z = dd["z_channels"]
         double_z = dd.get("double_z", True)
         self.quant_conv = Conv2d((1 + double_z) * z, (1 + double_z) * embed_dim, 1)
-        self.post_quant_conv = None
+        self.post_quant_conv = Conv2d(embed_dim, z, 1)
         self.monitor = monitor
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path)
@@ -52,3 +53,14 @@ class AutoencoderKL(nn.Module):
             return enc(x, regularize=True)
         finally:
             enc.standalone, enc.quant_conv = prev
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
+        """post_quant_conv + decoder (autoencoder.py:505-508), fp32 NCHW."""
+        dec = self.decoder
+        prev = (dec.standalone, dec.post_quant_conv)
+        dec.standalone, dec.post_quant_conv = True, self.post_quant_conv
+        try:
+            return dec(z, **kwargs)
+        finally:
+            dec.standalone, dec.post_quant_conv = prev

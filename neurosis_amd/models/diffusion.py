@@ -1,15 +1,17 @@
-"""DiffusionEngine: the training-step slice of neurosis.models.diffusion.DiffusionEngine
-(/root/reference/src/neurosis/models/diffusion.py:35-233) without Lightning.
+"""DiffusionEngine: the training-step and sampling slices of neurosis.models.diffusion.DiffusionEngine
+(/root/reference/src/neurosis/models/diffusion.py:35-233 and :172-184,298-420) without Lightning.
 
 What is mirrored: the constructor's model wiring (OpenAIWrapper around the UNet, the VAE dismantled into
 `vae_encoder` with its quant_conv, models/diffusion.py:73,146-164), get_input, encode_first_stage, forward and
 training_step, and the `model.diffusion_model.*` / `vae_encoder.*` state_dict prefixes.  What replaces
 Lightning: `training_step` returns loss.mean() exactly as the reference does; `optimizer_step` and the
 data-parallel exchange are explicit methods because there is no Trainer (bench.py and the tests drive them).
-Hooks, EMA, samplers, logging and checkpoint IO are outside SURVEY section 8(a).
+Sampling: `sample`, `decode_first_stage`, `ema_scope` and `log_images` (tensors only: the text-as-image
+panels of `log_conditionings` are logging, not compute).  Hooks, loggers and checkpoint IO are outside section 8.
 """
 from __future__ import annotations
 
+from contextlib import contextmanager
 from math import ceil
 from typing import Callable, Optional
 
@@ -26,11 +28,12 @@ class PrecomputedConditioner(nn.Module):
     """Stand-in for GeneralConditioner (modules/encoders/embedding.py:90-149, frozen text encoders: out of scope):
     returns the conditioning tensors the batch already carries."""
 
-    def forward(self, batch: dict) -> dict:
+    def forward(self, batch: dict, force_zero_embeddings=None) -> dict:
+        zeroed = set(force_zero_embeddings or ())
         out = {}
         for k in ("crossattn", "vector", "concat"):
             if k in batch and batch[k] is not None:
-                out[k] = batch[k]
+                out[k] = torch.zeros_like(batch[k]) if k in zeroed else batch[k]
         return out
 
 
@@ -50,7 +53,9 @@ class DiffusionEngine(nn.Module):
         self.scale_factor = scale_factor
         self.vae_batch_size = vae_batch_size
         self.log_sigmas = log_sigmas
+        self.sampler = sampler
         self.vae_encoder = None
+        self.vae_decoder = None
         if first_stage_model is not None:
             self._init_first_stage(first_stage_model)
         self.global_step = 0
@@ -66,6 +71,11 @@ class DiffusionEngine(nn.Module):
         enc.quant_conv = model.quant_conv
         enc.standalone = True
         self.vae_encoder = enc
+        dec = getattr(model, "decoder", None)
+        if dec is not None:
+            dec.post_quant_conv = model.post_quant_conv
+            dec.standalone = True
+            self.vae_decoder = dec
 
     def setup_flat_params(self) -> FlatParamStore:
         """Re-home the trainable UNet parameters into the flat fp32/bf16/grad buffers (call after .cuda())."""
@@ -92,6 +102,14 @@ class DiffusionEngine(nn.Module):
         outs = [self.vae_encoder(x[n * n_samples:(n + 1) * n_samples], regularize=True) for n in range(ceil(x.shape[0] / n_samples))]
         z = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         return self.scale_factor * z
+
+    @torch.no_grad()
+    def decode_first_stage(self, z: Tensor) -> Tensor:
+        """models/diffusion.py:172-184: latents -> images (fp32 NCHW), in chunks of vae_batch_size."""
+        z = 1.0 / self.scale_factor * z
+        n_samples = self.vae_batch_size or z.shape[0]
+        outs = [self.vae_decoder(z[n * n_samples:(n + 1) * n_samples], cat_zero=True) for n in range(ceil(z.shape[0] / n_samples))]
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     def forward(self, x: Tensor, batch: dict, return_dict: bool = False, **inject):
         cond = self.conditioner(batch)
@@ -147,3 +165,70 @@ class DiffusionEngine(nn.Module):
             self.model_ema.update()
         ops.state.grad_accumulate = False
         self.global_step += 1
+
+    # -- sampling -------------------------------------------------------------------
+    @contextmanager
+    def ema_scope(self, context: Optional[str] = None):
+        """models/diffusion.py:280-292: run the body with the EMA weights swapped in (no-op without EMA)."""
+        ema = getattr(self, "model_ema", None) if self.use_ema else None
+        if ema is not None:
+            ema.store()
+            ema.copy_to()
+        try:
+            yield None
+        finally:
+            if ema is not None:
+                ema.restore()
+
+    @torch.no_grad()
+    def sample(self, cond: dict, uc: Optional[dict] = None, batch_size: int = 4, shape=None, noise: Optional[Tensor] = None, **model_kwargs) -> Tensor:
+        """models/diffusion.py:298-313.  `noise` may be injected (parity tests); otherwise unit gaussian of `shape`."""
+        if self.sampler is None:
+            raise RuntimeError("no sampler configured")
+        from ..modules.diffusion.sampling import FusedDenoiser
+
+        device = next(self.model.parameters()).device
+        randn = torch.randn(batch_size, *shape, device=device) if noise is None else noise.to(device=device, dtype=torch.float32).clone()
+        return self.sampler(FusedDenoiser(self.model, self.denoiser, **model_kwargs), randn, cond, uc=uc)
+
+    @torch.no_grad()
+    def log_images(self, batch: dict, num_img: int = 4, split: str = "train", sample: bool = True, ucg_keys=None, **kwargs) -> dict:
+        """models/diffusion.py:369-420: inputs, VAE reconstructions and (CFG) samples for the batch's conditioning."""
+        inputs = self.get_input(batch)[:num_img]
+        num_img = len(inputs)
+        input_keys = list({e.input_key for e in getattr(self.conditioner, "embedders", ()) if hasattr(e, "input_key")})
+        if ucg_keys and any(k not in input_keys for k in ucg_keys):
+            raise ValueError("Each defined ucg key for sampling must be in the provided conditioner input keys!"
+                             f"\nRequested UCG keys: {ucg_keys}\nAvailable input keys: {input_keys}")
+        latents = self.encode_first_stage(inputs)
+        images = {f"{split}/inputs": inputs.cpu(), f"{split}/recons": self.decode_first_stage(latents).cpu()}
+        cond, uncond = get_unconditional_conditioning(self.conditioner, batch)
+        device = latents.device
+        for key, value in cond.items():
+            if isinstance(value, Tensor):
+                cond[key], uncond[key] = value[:num_img].to(device), uncond[key][:num_img].to(device)
+        if sample:
+            with self.ema_scope("Plotting"):
+                samples = self.sample(cond=cond, shape=latents.shape[1:], uc=uncond, batch_size=num_img, **kwargs)
+            images["samples"] = self.decode_first_stage(samples).cpu()
+        return images
+
+
+def get_unconditional_conditioning(conditioner, batch_c: dict, batch_uc: Optional[dict] = None, force_uc_zero_embeddings=None,
+                                   force_cond_zero_embeddings=None):
+    """models/diffusion.py:423-447: (cond, uncond) with every embedder's ucg dropout switched off for the two calls; the
+    unconditional batch defaults to the same batch with empty captions."""
+    embedders = list(getattr(conditioner, "embedders", ()))
+    rates = [e.ucg_rate for e in embedders]
+    for e in embedders:
+        e.ucg_rate = 0.0
+    try:
+        c = conditioner(batch_c, force_zero_embeddings=force_cond_zero_embeddings)
+        if batch_uc is None:
+            batch_uc = dict(batch_c)
+            batch_uc["caption"] = [""] * len(batch_c["caption"]) if "caption" in batch_c else [""]
+        uc = conditioner(batch_uc, force_zero_embeddings=force_uc_zero_embeddings or [])
+    finally:
+        for e, rate in zip(embedders, rates):
+            e.ucg_rate = rate
+    return c, uc

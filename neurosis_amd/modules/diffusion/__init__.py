@@ -4,13 +4,13 @@ from .denoiser_preconditioning import DenoiserPreconditioning, EDMPreconditionin
 from .denoiser_weighting import DenoiserWeighting, EDMWeighting, EpsWeighting, UnitWeighting
 from .discretization import Discretization, EDMcDiscretization, LegacyDDPMDiscretization
 from .loss import DiffusionLoss, StandardDiffusionLoss
-from .model import AttnBlock, Encoder, MemoryEfficientAttnBlock, ResnetBlock
+from .model import AttnBlock, Decoder, Encoder, MemoryEfficientAttnBlock, ResnetBlock
 from .openaimodel import Timestep, UNetModel
 from .sampling import DiscreteSigmaGenerator, EDMSigmaGenerator, InjectedSigmaGenerator, SigmaGenerator
 from .wrappers import IdentityWrapper, OpenAIWrapper
 
 __all__ = [
-    "AttnBlock", "Denoiser", "DenoiserPreconditioning", "DenoiserWeighting", "DiffusionLoss", "DiscreteDenoiser", "DiscreteSigmaGenerator",
+    "AttnBlock", "Decoder", "Denoiser", "DenoiserPreconditioning", "DenoiserWeighting", "DiffusionLoss", "DiscreteDenoiser", "DiscreteSigmaGenerator",
     "Discretization", "EDMcDiscretization", "EDMPreconditioning", "EDMSigmaGenerator", "EDMWeighting", "Encoder", "EpsPreconditioning",
     "EpsWeighting", "IdentityWrapper", "InjectedSigmaGenerator", "LegacyDDPMDiscretization", "MemoryEfficientAttnBlock", "OpenAIWrapper",
     "ResnetBlock", "SigmaGenerator", "StandardDiffusionLoss", "Timestep", "UnitWeighting", "UNetModel", "VPreconditioning",

@@ -1,10 +1,11 @@
-"""VAE Encoder on MI355X: the class surface of neurosis.modules.diffusion.model.Encoder
-(/root/reference/src/neurosis/modules/diffusion/model.py:456-606) over the HIP kernels.
+"""VAE Encoder and Decoder on MI355X: the class surface of neurosis.modules.diffusion.model.{Encoder,Decoder}
+(/root/reference/src/neurosis/modules/diffusion/model.py:456-606 and :609-765) over the HIP kernels.
 
-The hot path only ever runs the encoder forward under no_grad (DiffusionEngine.encode_first_stage,
-models/diffusion.py:186-197), so this mirror is forward-only: same constructor arguments, module tree and
+The diffusion engine only ever runs these under no_grad (DiffusionEngine.encode_first_stage / decode_first_stage,
+models/diffusion.py:172-197), so both mirrors are forward-only: same constructor arguments, module tree and
 state_dict keys (conv_in, down.{l}.block.{i}.{norm1,conv1,norm2,conv2,nin_shortcut}, down.{l}.downsample.conv,
-mid.{block_1,attn_1,block_2}, norm_out, conv_out, quant_conv).
+up.{l}.block.{i}.*, up.{l}.upsample.conv, mid.{block_1,attn_1,block_2}, norm_out, conv_out, quant_conv /
+post_quant_conv).  Training the VAE itself is not built.
 """
 from __future__ import annotations
 
@@ -40,6 +41,21 @@ class Downsample(nn.Module):
 
     def fwd(self, x: Img) -> Img:
         return self.conv.fwd(x, need_dx=False)[0]
+
+
+class Upsample(nn.Module):
+    """model.py:44-62: nearest-neighbour x2 followed by a 3x3 conv.  The conv's implicit-GEMM gather reads the
+    low-resolution tensor at (y >> 1, x >> 1), so the upsampled image never exists in HBM."""
+
+    def __init__(self, in_channels: int, with_conv: bool):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("resamp_with_conv=False is not used by the SD/SDXL VAE")
+        self.with_conv = with_conv
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+
+    def fwd(self, x: Img) -> Img:
+        return self.conv.fwd(x, upsample=True, need_dx=False)[0]
 
 
 class ResnetBlock(nn.Module):
@@ -205,3 +221,90 @@ class Encoder(nn.Module):
             keep = zc_real // 2 if (regularize and self.double_z) else zc_real
             outs.append(ops.tokens_to_nchw(h.t, n, keep, h.H, h.W, dtype=torch.float32))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+class Decoder(nn.Module):
+    """model.py:609-765.  Latents in, image out; levels are built coarse to fine but stored fine-first (`up[0]` is the
+    full-resolution level), which is what the checkpoint keys expect."""
+
+    def __init__(self, *, ch: int, out_ch: int, ch_mult: Sequence[int] = (1, 2, 4, 8), num_res_blocks: int, attn_resolutions: Sequence[int],
+                 dropout: float = 0.0, resamp_with_conv: bool = True, in_channels: int, resolution: int, z_channels: int, give_pre_end: bool = False,
+                 tanh_out: bool = False, use_linear_attn: bool = False, attn_type: str = "vanilla", embed_dim: int = 256, standalone: bool = False,
+                 **kwargs):
+        super().__init__()
+        if use_linear_attn:
+            raise ValueError("linear attention is outside the SD/SDXL path")
+        levels = len(ch_mult)
+        self.ch, self.temb_ch, self.num_resolutions, self.num_res_blocks = ch, 0, levels, num_res_blocks
+        self.resolution, self.in_channels, self.out_ch = resolution, in_channels, out_ch
+        self.give_pre_end, self.tanh_out = give_pre_end, tanh_out
+        width = ch * ch_mult[-1]
+        res = resolution // 2 ** (levels - 1)
+        self.z_shape = (1, z_channels, res, res)
+        self.conv_in = Conv2d(z_channels, width, kernel_size=3, stride=1, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=width, out_channels=width, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(width, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=width, out_channels=width, temb_channels=0, dropout=dropout)
+        stages = []
+        for level in range(levels - 1, -1, -1):
+            stage = nn.Module()
+            stage.block, stage.attn = nn.ModuleList(), nn.ModuleList()
+            for _ in range(num_res_blocks + 1):
+                stage.block.append(ResnetBlock(in_channels=width, out_channels=ch * ch_mult[level], temb_channels=0, dropout=dropout))
+                width = ch * ch_mult[level]
+                if res in attn_resolutions:
+                    stage.attn.append(make_attn(width, attn_type=attn_type))
+            if level > 0:
+                stage.upsample = Upsample(width, resamp_with_conv)
+                res *= 2
+            stages.append(stage)
+        self.up = nn.ModuleList(reversed(stages))
+        self.norm_out = Normalize(width)
+        self.conv_out = Conv2d(width, out_ch, kernel_size=3, stride=1, padding=1)
+        self.max_batch_size = None
+        self.standalone = standalone
+        self.post_quant_conv = Conv2d(embed_dim, z_channels, 1) if standalone else nn.Identity()
+
+    def get_last_layer(self, **kwargs):
+        return self.conv_out.weight
+
+    def fwd(self, z: Img) -> Img:
+        """post_quant_conv (when standalone) + decode on an Img whose channels are padded to a multiple of 8"""
+        if self.standalone:
+            z = self.post_quant_conv.fwd(z, need_dx=False)[0]
+        h = self.conv_in.fwd(z, need_dx=False)[0]
+        h = self.mid.block_1.fwd(h)
+        if not isinstance(self.mid.attn_1, nn.Identity):
+            h = self.mid.attn_1.fwd(h)
+        h = self.mid.block_2.fwd(h)
+        for level in range(self.num_resolutions - 1, -1, -1):
+            stage = self.up[level]
+            for i, block in enumerate(stage.block):
+                h = block.fwd(h)
+                if len(stage.attn) > 0:
+                    h = stage.attn[i].fwd(h)
+            if level > 0:
+                h = stage.upsample.fwd(h)
+        if self.give_pre_end:
+            return h
+        return self.conv_out.fwd(_gn(h, self.norm_out, True), need_dx=False)[0]
+
+    @torch.no_grad()
+    def forward(self, z: Tensor, cat_zero: bool = False, **kwargs):
+        """model.py:746-765.  fp32 NCHW out.  With `max_batch_size` set the reference returns a python list of chunk outputs
+        unless cat_zero=True; that is kept."""
+        N, Cz, H, W = z.shape
+        bs = self.max_batch_size or N
+        outs = []
+        for i in range(0, N, bs):
+            zb = z[i:i + bs]
+            n = zb.shape[0]
+            img = Img(ops.nchw_to_tokens(zb.float() if zb.dtype not in (torch.float32, BF16) else zb, (Cz + 7) // 8 * 8), n, H, W)
+            h = self.fwd(img)
+            keep = h.C if self.give_pre_end else self.out_ch
+            o = ops.tokens_to_nchw(h.t, n, keep, h.H, h.W, dtype=torch.float32)
+            outs.append(torch.tanh(o) if self.tanh_out and not self.give_pre_end else o)
+        if self.max_batch_size is None:
+            return outs[0]
+        return torch.cat(outs, 0) if cat_zero else outs

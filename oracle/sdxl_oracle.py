@@ -253,6 +253,26 @@ def vae_encode(sd: SD, dd: dict, x: Tensor) -> Tensor:
     return mean
 
 
+def vae_decode(sd: SD, dd: dict, z: Tensor) -> Tensor:
+    """Decoder.forward, modules/diffusion/model.py:707-765: post_quant_conv (standalone, :700-704) -> conv_in -> mid ->
+    for level = L-1 .. 0: (num_res_blocks + 1) resnets (+ attn) then Upsample (nearest x2 + 3x3 conv, :44-62) except at
+    level 0 -> GroupNorm, SiLU, conv_out (tanh_out / give_pre_end are off in the SD/SDXL configs)."""
+    levels = len(dd["ch_mult"])
+    h = conv(sd, "post_quant_conv", z, padding=0) if "post_quant_conv.weight" in sd else z
+    h = conv(sd, "conv_in", h)
+    h = vae_resnet(sd, "mid.block_1", h)
+    h = vae_attn(sd, "mid.attn_1", h)
+    h = vae_resnet(sd, "mid.block_2", h)
+    for lvl in reversed(range(levels)):
+        for ib in range(dd["num_res_blocks"] + 1):
+            h = vae_resnet(sd, f"up.{lvl}.block.{ib}", h)
+            if f"up.{lvl}.attn.{ib}.norm.weight" in sd:
+                h = vae_attn(sd, f"up.{lvl}.attn.{ib}", h)
+        if lvl != 0:
+            h = conv(sd, f"up.{lvl}.upsample.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
+    return conv(sd, "conv_out", F.silu(group_norm(sd, "norm_out", h, 1e-6)))
+
+
 # ------------------------------------------------------------------------------------------------
 # diffusion glue
 # ------------------------------------------------------------------------------------------------
@@ -265,6 +285,20 @@ def legacy_ddpm_sigmas(num_idx: int = 1000, linear_start: float = 0.00085, linea
     alphas_cumprod = torch.cumprod(1.0 - betas, dim=0, dtype=torch.float32)  # fp32 cumprod, discretization.py:159
     sigmas = ((1 - alphas_cumprod) / alphas_cumprod) ** 0.5
     sigmas = torch.flip(sigmas, (0,)).to(torch.float32)
+    return torch.cat([sigmas, sigmas.new_zeros([1])])
+
+
+def legacy_ddpm_sampling_sigmas(n: int, num_idx: int = 1000, linear_start: float = 0.00085, linear_end: float = 0.0120) -> Tensor:
+    """The sampler's table, LegacyDDPMDiscretization.get_sigmas for n < num_timesteps (discretization.py:13-14,161-171):
+    n roughly equally spaced timesteps ending at num_idx - 1, descending sigmas, final 0 appended."""
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, num_idx, dtype=torch.float64) ** 2
+    alphas_cumprod = torch.cumprod(1.0 - betas, dim=0, dtype=torch.float32)
+    if n < num_idx:
+        import numpy as np
+
+        steps = np.linspace(num_idx - 1, 0, n, endpoint=False).astype(int)[::-1]
+        alphas_cumprod = alphas_cumprod[torch.from_numpy(np.ascontiguousarray(steps))]
+    sigmas = torch.flip(((1 - alphas_cumprod) / alphas_cumprod) ** 0.5, (0,)).to(torch.float32)
     return torch.cat([sigmas, sigmas.new_zeros([1])])
 
 

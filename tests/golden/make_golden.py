@@ -258,9 +258,116 @@ def conditioner_case():
     print("conditioner:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def decoder_case(nmodel):
+    """VAE decoder (post_quant_conv + decode) on tiny latents."""
+    dec = nmodel.Decoder(**VAE_TINY).eval()
+    shapes = {k: list(v.shape) for k, v in dec.state_dict().items()}
+    dec.load_state_dict(synth_state_dict(shapes))
+    g = torch.Generator().manual_seed(123)
+    z = torch.randn(2, 4, 8, 8, generator=g)
+    with torch.no_grad():
+        image = dec(z)
+    torch.save(dict(cfg=VAE_TINY, z=z, image=image), HERE / "vae_decoder_tiny.pt")
+    (HERE / "vae_decoder_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
+    print("decoder: image", tuple(image.shape), float(image.abs().mean()))
+
+
+def analytic_denoiser(x, sigma, c, *args, **kwargs):
+    """A closed-form stand-in for denoiser(network, ...) so that sampler arithmetic can be pinned without a network:
+    depends on x, on sigma and (through "vector") on the conditioning, so guidance has something to act on."""
+    shrink = 1.0 / (1.0 + sigma**2)
+    return x * shrink[:, None, None, None] + 0.1 * torch.tanh(c["vector"])[:, :, None, None] * (sigma / (1.0 + sigma))[:, None, None, None]
+
+
+SAMPLER_CASES = {
+    # name: (class name, init kwargs, guidance scale or None, steps)
+    "euler": ("EulerEDMSampler", {}, None, 7),
+    "euler_cfg": ("EulerEDMSampler", {}, 5.0, 7),
+    "euler_churn_cfg": ("EulerEDMSampler", {"s_churn": 2.0, "s_tmin": 0.5, "s_tmax": 10.0, "s_noise": 1.003}, 3.0, 6),
+    "heun_cfg": ("HeunEDMSampler", {}, 4.0, 5),
+    "euler_a_cfg": ("EulerAncestralSampler", {"eta": 0.8, "s_noise": 0.9}, 6.0, 7),
+    "dpmpp2s_a": ("DPMPP2SAncestralSampler", {}, None, 6),
+    "dpmpp2m_cfg": ("DPMPP2MSampler", {}, 7.5, 8),
+    "lms_cfg": ("LinearMultistepSampler", {"order": 3}, 2.0, 6),
+}
+
+
+def sampler_inputs():
+    g = torch.Generator().manual_seed(2024)
+    x0 = torch.randn(3, 4, 6, 5, generator=g)
+    cond = {"vector": torch.randn(3, 4, generator=g)}
+    uc = {"vector": torch.randn(3, 4, generator=g)}
+    return x0, cond, uc
+
+
+def seeded_noise_sampler(seed: int):
+    g = torch.Generator().manual_seed(seed)
+    return lambda x: torch.randn(x.shape, generator=g).to(x)
+
+
+def sampler_cases(nd):
+    """Every sampler class against the analytic denoiser (pins the sampler arithmetic), then Euler+CFG and Heun+CFG
+    trajectories through the tiny SDXL UNet with the reference's DiscreteDenoiser (pins the whole sampling path)."""
+    import neurosis.modules.diffusion.discretization as ndisc
+    import neurosis.modules.diffusion.sampling as ns
+    import numpy as np
+    from neurosis.modules.guidance import VanillaCFG
+
+    # torch >= 2.x refuses to index with the negative-stride numpy view the reference builds for n < 1000
+    # ("At least one stride in the given numpy array is negative"): hand it the same indices as a contiguous array
+    spaced = ndisc.generate_roughly_equally_spaced_steps
+    ndisc.generate_roughly_equally_spaced_steps = lambda n, m: np.ascontiguousarray(spaced(n, m))
+
+    out = {}
+    for name, (cls, kwargs, scale, steps) in SAMPLER_CASES.items():
+        x0, cond, uc = sampler_inputs()
+        sampler = getattr(ns, cls)(discretization=nd.LegacyDDPMDiscretization(), guider=None if scale is None else VanillaCFG(scale), num_steps=steps,
+                                   device="cpu", **kwargs)
+        if hasattr(sampler, "noise_sampler"):
+            sampler.noise_sampler = seeded_noise_sampler(77)
+        torch.manual_seed(4321)                      # the churn noise comes from the global generator (torch.randn_like)
+        with torch.no_grad():
+            out[name] = sampler(analytic_denoiser, x0.clone(), cond, uc=uc)
+        print(f"sampler {name}: |x|={float(out[name].abs().mean()):.5f}")
+    torch.save(out, HERE / "sampler_analytic.pt")
+
+    torch.manual_seed(0)
+    net = nd.UNetModel(**UNET_TINY).eval()
+    shapes = json.loads((HERE / "unet_sdxl_tiny_keys.json").read_text())
+    net.load_state_dict(synth_state_dict(shapes))
+    denoiser = nd.DiscreteDenoiser(preconditioning=nd.EpsPreconditioning(), num_idx=1000, discretization=nd.LegacyDDPMDiscretization())
+    wrapper = nd.OpenAIWrapper(net)
+    g = torch.Generator().manual_seed(555)
+    B = 2
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    cond = {"crossattn": torch.randn(B, 7, UNET_TINY["context_dim"], generator=g), "vector": torch.randn(B, UNET_TINY["adm_in_channels"], generator=g)}
+    uc = {"crossattn": torch.randn(B, 7, UNET_TINY["context_dim"], generator=g), "vector": torch.zeros(B, UNET_TINY["adm_in_channels"])}
+
+    def denoiser_cb(inputs, sigma, c):
+        return denoiser(wrapper, inputs, sigma, c, "D")
+
+    fixture = dict(noise=noise, cond=cond, uc=uc, runs={})
+    for name, cls, steps, scale in (("euler_cfg", "EulerEDMSampler", 4, 5.0), ("heun_cfg", "HeunEDMSampler", 3, 3.0), ("euler_plain", "EulerEDMSampler", 3, None)):
+        sampler = getattr(ns, cls)(discretization=nd.LegacyDDPMDiscretization(), guider=None if scale is None else VanillaCFG(scale), num_steps=steps, device="cpu")
+        trajectory = []
+        step = sampler.sampler_step
+
+        def recording_step(*a, _step=step, **k):
+            x = _step(*a, **k)
+            trajectory.append(x.detach().clone())
+            return x
+
+        sampler.sampler_step = recording_step
+        with torch.no_grad():
+            final = sampler(denoiser_cb, noise.clone(), cond, uc=uc)
+        fixture["runs"][name] = dict(cls=cls, steps=steps, scale=scale, trajectory=trajectory, final=final)
+        print(f"unet sampler {name}: |x|={float(final.abs().mean()):.5f} steps={len(trajectory)}")
+    torch.save(fixture, HERE / "sampler_unet_tiny.pt")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -273,3 +380,7 @@ if __name__ == "__main__":
         adafactor_case()
     if "conditioner" in which:
         conditioner_case()
+    if "decoder" in which:
+        decoder_case(nmodel)
+    if "sampler" in which:
+        sampler_cases(nd)
