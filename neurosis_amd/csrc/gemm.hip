@@ -673,7 +673,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
   unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int kt = 0; kt < nk; ++kt) {
-    // vmcnt(0) + barrier: tile kt has landed for every wave, and every wave is done reading the other buffer
+    // vmcnt(0) + barrier: tile kt has landed for every wave, and every wave is done reading the other buffer.  The wait is
+    // spelled out: left to __syncthreads(), hipcc has been seen placing it AFTER the barrier (it orders the DMA against this
+    // wave's own LDS reads only), which lets a wave read rows another wave's DMA has not delivered yet.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const char* cur = smem + (kt & 1) * V2_STAGE_BYTES;
     // fragment reads of BOTH k sub-steps first, THEN the next tile's DMA, then the MFMAs.  hipcc (ROCm 7.2) puts an
@@ -1079,7 +1082,9 @@ __global__ __launch_bounds__(SK_NT, 4) void nk_gemm_sk_kernel(const NkGemmParams
       for (int j = 0; j < 2; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     for (int kt = k0; kt < k1; ++kt, ++slab) {
-      // vmcnt(0) + barrier: this slab has landed for every wave, and every wave is done reading the other stage
+      // vmcnt(0) + barrier: this slab has landed for every wave, and every wave is done reading the other stage (the wait is
+      // explicit for the reason given in nk_gemm_dma_kernel)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const char* cur = smem + (slab & 1) * V2_STAGE_BYTES;
       bf16x8_t af[2][4], bfr[2][2];
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(SK_NT, 4) void nk_gemm_sk_kernel(const NkGemmParams
       // not the end of the tile: publish the partial and raise this ticket's flag
       sk_store_partial(p.sk_ws + (size_t)w * SK_TILE_FLOATS, acc, wave, lane);
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(p.sk_flags + w, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(p.sk_flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (k0 > 0) {
         // last part of a shared tile: add the partials of the workgroups before us (lower tickets: they started earlier),
@@ -1122,7 +1127,7 @@ __global__ __launch_bounds__(SK_NT, 4) void nk_gemm_sk_kernel(const NkGemmParams
             // order, so it is running or done.  The wait is bounded all the same (~0.2 s): on expiry the launch is marked
             // failed (checked by nk_gemm_sk_status) instead of hanging the device.
             int spins = 0;
-            while (__hip_atomic_load(p.sk_flags + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+            while (__hip_atomic_load(p.sk_flags + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
               __builtin_amdgcn_s_sleep(8);
               if (++spins > (1 << 21)) {
                 if (tid == 0) __hip_atomic_store(p.sk_flags + SK_MAX_GRID + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1130,6 +1135,11 @@ __global__ __launch_bounds__(SK_NT, 4) void nk_gemm_sk_kernel(const NkGemmParams
               }
             }
             sk_add_partial(p.sk_ws + (size_t)ticket * SK_TILE_FLOATS, acc, wave, lane);
+            // Every published partial has exactly one reader (the workgroup finishing that tile), which lowers the flag again
+            // once all its waves are past the wait: the flags are all 0 when the launch ends, so there is no per-launch
+            // state in the kernel arguments and a launch replayed from a captured hipGraph behaves like a fresh one.
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.sk_flags + ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if (s_li <= ts) break;
         }
@@ -1310,7 +1320,6 @@ struct SkWorkspace {
   unsigned* counter = nullptr;
   unsigned* flags = nullptr;
   float* ws = nullptr;
-  unsigned base = 0, epoch = 0;
 };
 static std::mutex sk_mutex;
 static std::unordered_map<void*, SkWorkspace> sk_spaces;
@@ -1340,6 +1349,11 @@ static int sk_prepare(NkGemmParams& p, int grid, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(sk_mutex);
   SkWorkspace& w = sk_spaces[(void*)stream];
   if (!w.ws) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+      nk_set_error(__FILE__, __LINE__, "stream-K workspace requested while the stream is capturing: run the launch once on this stream before capturing it");
+      return NK_ERR_LAUNCH;
+    }
     char* raw = nullptr;
     const size_t ws_bytes = (size_t)SK_MAX_GRID * SK_TILE_FLOATS * sizeof(float);
     if (hipMalloc((void**)&raw, ws_bytes + (SK_MAX_GRID + 64) * sizeof(unsigned)) != hipSuccess) {
@@ -1348,17 +1362,15 @@ static int sk_prepare(NkGemmParams& p, int grid, hipStream_t stream) {
     }
     w.ws = (float*)raw;
     w.flags = (unsigned*)(raw + ws_bytes);
-    w.counter = w.flags + SK_MAX_GRID;
-    if (hipMemset(w.flags, 0, (SK_MAX_GRID + 64) * sizeof(unsigned)) != hipSuccess) return NK_ERR_LAUNCH;
+    w.counter = w.flags + SK_MAX_GRID;         // flags[SK_MAX_GRID + 1] is the timeout mark
+    // zeroed ON THE LAUNCHING STREAM (a null-stream memset is not ordered against a non-blocking stream's kernels)
+    if (hipMemsetAsync(w.flags, 0, (SK_MAX_GRID + 64) * sizeof(unsigned), stream) != hipSuccess) return NK_ERR_LAUNCH;
   }
-  w.epoch += 1;
-  if (w.epoch == 0) w.epoch = 1;   // 0 is the flags' initial value
   p.sk_counter = w.counter;
   p.sk_flags = w.flags;
   p.sk_ws = w.ws;
-  p.sk_base = w.base;
-  p.sk_epoch = w.epoch;
-  w.base += (unsigned)grid;
+  p.sk_base = 0;
+  p.sk_epoch = 0;
   return NK_OK;
 }
 

@@ -46,10 +46,10 @@ struct NkGemmParams {
   const bf16_t* Bb[8];
   void* Cb[8];
   // stream-K (nk_gemm_sk_kernel): per-stream workspace owned by the dispatcher
-  unsigned* sk_counter;     // ticket counter (monotonic across launches)
-  unsigned sk_base;         // its value before this launch
-  unsigned* sk_flags;       // [grid] flag[ticket] == sk_epoch once that workgroup's partial tile is in sk_ws
-  unsigned sk_epoch;
+  unsigned* sk_counter;     // (unused)
+  unsigned sk_base;         // (unused)
+  unsigned* sk_flags;       // [grid] flag[ticket] = 1 while that workgroup's partial tile waits in sk_ws; its one reader lowers it
+  unsigned sk_epoch;        // (unused: no per-launch state, so a launch replayed from a hipGraph is a fresh one)
   float* sk_ws;             // [grid][128*128] fp32 partial tiles in accumulator-register order
   int sk_chunked;           // 1: each XCD owns a contiguous eighth of the tile list
   int sk_debug;             // ablation switches (NK_SK_DEBUG): 1 = no epilogue stores, 2 = no fixup exchange

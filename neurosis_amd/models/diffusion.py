@@ -189,7 +189,11 @@ class DiffusionEngine(nn.Module):
 
         device = next(self.model.parameters()).device
         randn = torch.randn(batch_size, *shape, device=device) if noise is None else noise.to(device=device, dtype=torch.float32).clone()
-        return self.sampler(FusedDenoiser(self.model, self.denoiser, **model_kwargs), randn, cond, uc=uc)
+        if model_kwargs:
+            fused = FusedDenoiser(self.model, self.denoiser, **model_kwargs)
+        else:   # kept between calls: it owns the captured hipGraph of a sampling step
+            fused = self.__dict__.setdefault("_fused_denoiser", FusedDenoiser(self.model, self.denoiser))
+        return self.sampler(fused, randn, cond, uc=uc).clone()
 
     @torch.no_grad()
     def log_images(self, batch: dict, num_img: int = 4, split: str = "train", sample: bool = True, ucg_keys=None, **kwargs) -> dict:

@@ -116,7 +116,7 @@ def test_fused_unet_sampling_against_reference_trajectory(run):
     cond, uc = ({k: v.cuda() for k, v in d.items()} for d in (fx["cond"], fx["uc"]))
     trajectory = []
     step = sampler.sampler_step
-    sampler.sampler_step = lambda *a, **k: trajectory.append(step(*a, **k)) or trajectory[-1]
+    sampler.sampler_step = lambda *a, **k: trajectory.append(step(*a, **k).clone()) or trajectory[-1]   # (clone: graph replays reuse one buffer)
     fused_calls = []
     originals = {kernel: getattr(S.FusedDenoiser, kernel) for kernel in ("euler", "guided")}
 
@@ -162,6 +162,41 @@ def test_fused_route_equals_generic_route_on_the_same_network():
     with torch.no_grad():
         generic = sampler(generic_cb, fx["noise"].cuda().clone(), cond, uc=uc)
     assert rel_err(fused, generic) <= 1e-2 and cosine(fused, generic) >= 0.9999
+
+
+def test_captured_step_equals_eager_step_and_survives_weight_updates():
+    """The hipGraph of a sampling step replays the same kernels on the same buffers: same latents as launching them one by
+    one.  A second sample() with other conditioning reuses the graph (conditioning is copied in); after the parameters change
+    the step is captured again and sees the new weights."""
+    import neurosis_amd.modules.diffusion as D
+    import neurosis_amd.modules.diffusion.sampling as S
+    from neurosis_amd import ops
+    from neurosis_amd.modules.guidance import VanillaCFG
+
+    fx = torch.load(G / "sampler_unet_tiny.pt", weights_only=False)
+    sampler = S.EulerEDMSampler(discretization=D.LegacyDDPMDiscretization(), guider=VanillaCFG(5.0), num_steps=4)
+    engine = _tiny_engine(sampler)
+    cond, uc = ({k: v.cuda() for k, v in d.items()} for d in (fx["cond"], fx["uc"]))
+    eager = S.FusedDenoiser(engine.model, engine.denoiser, use_graph=False)
+    graphed = S.FusedDenoiser(engine.model, engine.denoiser, use_graph=True)
+    with torch.no_grad():
+        want = sampler(eager, fx["noise"].cuda().clone(), cond, uc=uc).clone()
+        got = sampler(graphed, fx["noise"].cuda().clone(), cond, uc=uc).clone()
+        assert rel_err(got, want) <= 1e-6
+        assert len(graphed._captured) == 1
+        graph = next(iter(graphed._captured.values()))
+        cond2 = {k: v.flip(0).contiguous() for k, v in cond.items()}
+        want2 = sampler(eager, fx["noise"].cuda().clone(), cond2, uc=uc).clone()
+        got2 = sampler(graphed, fx["noise"].cuda().clone(), cond2, uc=uc).clone()
+        assert next(iter(graphed._captured.values())) is graph
+        assert rel_err(got2, want2) <= 1e-6 and rel_err(got2, want) > 1e-3
+        for p in engine.model.parameters():
+            p.mul_(1.01)
+        ops.state.param_epoch += 1
+        want3 = sampler(eager, fx["noise"].cuda().clone(), cond, uc=uc).clone()
+        got3 = sampler(graphed, fx["noise"].cuda().clone(), cond, uc=uc).clone()
+        assert next(iter(graphed._captured.values())) is not graph
+        assert rel_err(got3, want3) <= 1e-6 and rel_err(got3, want) > 1e-4
 
 
 def test_vae_decoder_against_reference_golden():
