@@ -1,20 +1,8 @@
-from .fused import FusedDenoiser
-from .sampling import (
-    AncestralSampler,
-    BaseDiffusionSampler,
-    DPMPP2MSampler,
-    DPMPP2SAncestralSampler,
-    EDMSampler,
-    EulerAncestralSampler,
-    EulerEDMSampler,
-    HeunEDMSampler,
-    LinearMultistepSampler,
-    SingleStepDiffusionSampler,
-)
-from .sigma_generators import DiscreteSigmaGenerator, EDMSigmaGenerator, InjectedSigmaGenerator, SigmaGenerator
+"""Sampling side of the diffusion package: sigma generators for training (sigma_generators.py), the sampler classes
+(sampling.py) and the MI355X denoiser they drive (fused.py).  Each module lists its public names in __all__."""
+from . import fused as _fused, sampling as _sampling, sigma_generators as _sigma_generators
+from .fused import *  # noqa: F401,F403
+from .sampling import *  # noqa: F401,F403
+from .sigma_generators import *  # noqa: F401,F403
 
-__all__ = [
-    "AncestralSampler", "BaseDiffusionSampler", "DPMPP2MSampler", "DPMPP2SAncestralSampler", "DiscreteSigmaGenerator", "EDMSampler",
-    "EDMSigmaGenerator", "EulerAncestralSampler", "EulerEDMSampler", "FusedDenoiser", "HeunEDMSampler", "InjectedSigmaGenerator",
-    "LinearMultistepSampler", "SigmaGenerator", "SingleStepDiffusionSampler",
-]
+__all__ = sorted(_fused.__all__ + _sampling.__all__ + _sigma_generators.__all__)

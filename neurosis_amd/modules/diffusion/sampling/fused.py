@@ -35,6 +35,9 @@ from ..denoiser import Denoiser
 from ..wrappers import OpenAIWrapper
 
 
+__all__ = ["CapturedEulerStep", "FusedDenoiser"]
+
+
 class CapturedEulerStep:
     """One fused Euler step as a hipGraph over static buffers (latents, the two sigma vectors, stacked conditioning)."""
 

@@ -24,6 +24,11 @@ from .utils import _per_sample, get_ancestral_step, linear_multistep_coeff, to_d
 
 logger = logging.getLogger(__name__)
 
+__all__ = [
+    "AncestralSampler", "BaseDiffusionSampler", "DPMPP2MSampler", "DPMPP2SAncestralSampler", "EDMSampler", "EulerAncestralSampler",
+    "EulerEDMSampler", "HeunEDMSampler", "LinearMultistepSampler", "SingleStepDiffusionSampler",
+]
+
 ZERO_LEVEL = 1e-14     # "all noise levels are 0" threshold of the reference's early-outs
 
 

@@ -10,6 +10,9 @@ from torch import Tensor
 from ..discretization import Discretization
 
 
+__all__ = ["DiscreteSigmaGenerator", "EDMSigmaGenerator", "InjectedSigmaGenerator", "SigmaGenerator"]
+
+
 class SigmaGenerator(ABC):
     @abstractmethod
     def __call__(self, n_samples: int, t: Optional[Tensor] = None): ...
