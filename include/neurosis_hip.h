@@ -73,8 +73,9 @@ int nk_conv2d_dgrad(const NkConvDesc* d, const void* dy, const void* w, void* dx
 int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Fused attention  softmax(q k^T * scale) v, no mask, no dropout
- * (modules/attention.py:410-412 TorchSDPCrossAttention, :337-352 MemoryEfficientCrossAttention).
+ * Fused attention  softmax(q k^T * scale) v, no dropout; no mask
+ * (modules/attention.py:410-412 TorchSDPCrossAttention, :337-352 MemoryEfficientCrossAttention) or, forward only, the causal
+ * mask of the CLIP text transformers (models/text_encoder/clip.py:311-343 attn_mask; HF CLIPTextModel's causal mask).
  * q/k/v/o are token-major [B][L][H*D] views with explicit row and batch strides (elements), so they can be
  * column slices of a fused projection buffer.  lse is [B][H][Lq] fp32 (saved for the backward).
  * ---------------------------------------------------------------------------------------------- */
@@ -85,6 +86,7 @@ typedef struct NkAttnDesc {
   long sdq, sdk, sdv, sdo;      /* backward only: row strides of dq, dk, dv, do */
   long bdq, bdk, bdv, bdo;      /* backward only: batch strides */
   float scale;                  /* D^-0.5 */
+  int causal;                   /* forward only: key j contributes to query i iff j <= i (Lq == Lk) */
 } NkAttnDesc;
 int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, void* o, float* lse,
                      void* stream);
@@ -152,6 +154,11 @@ int nk_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 /* bias gradient: out[N] (+)= sum over rows of dy[M][N] (row stride ld) */
 long nk_colsum_ws_floats(long M, int N);
 int nk_colsum(const void* dy, float* out, float* ws, long M, int N, long ld, int accumulate, void* stream);
+
+/* y = gelu(x) elementwise over n bf16 values (n % 8 == 0).  mode 0: exact, 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU in open_clip's
+ * text tower, models/text_encoder/clip.py:333-343); mode 1: "quick_gelu" x * sigmoid(1.702 x) (HF CLIPTextModel of
+ * openai/clip-vit-large-patch14, models/text_encoder/clip.py:49-56). */
+int nk_gelu_fwd(const void* x, void* y, long n, int mode, void* stream);
 
 /* timestep_embedding (modules/diffusion/util.py:152-177): out[B][dim] bf16 = [cos | sin](t * freq) */
 int nk_timestep_embedding(const float* t, void* out, int B, int dim, float max_period, void* stream);

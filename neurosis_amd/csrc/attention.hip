@@ -31,6 +31,7 @@ struct AttnParams {
   long sdq, sdk, sdv, sdo;  // strides of gradients
   long bdq, bdk, bdv, bdo;
   float scale;
+  int causal;           // forward: key j is visible to query i iff j <= i
   int qsplit;           // dK/dV kernel: workgroups per key block along the query range (partials in dkv_part)
   float* dkv_part;      // [qsplit][2][B][Lk][H*D] fp32 partial dK / dV when qsplit > 1
 };
@@ -155,15 +156,17 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p
       for (int ks = 0; ks < KS; ++ks)
         s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, RS, hf * 32, ks, lane), qf[ks], s[hf], 0, 0, 0);
     }
-    // keys beyond Lk exist only in the last tile (wave-uniform branch)
+    // keys beyond Lk exist only in the last tile (wave-uniform branch); the causal variant (text transformers, L = 77)
+    // masks every tile it visits
     const int kbase = t * 64;
-    if (kbase + 64 > p.Lk) {
+    if (kbase + 64 > p.Lk || p.causal) {
+      const int last = p.causal ? min(p.Lk - 1, q0 + ql) : p.Lk - 1;   // highest visible key of this lane's query
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int key = kbase + hf * 32 + acc_row(r, h5);
-          s[hf][r] = key < p.Lk ? s[hf][r] : NEG_BIG;
+          s[hf][r] = key <= last ? s[hf][r] : NEG_BIG;
         }
     }
     float mloc = s[0][0];
@@ -587,6 +590,8 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
   p.sq = d->sq; p.sk = d->sk; p.sv = d->sv; p.so = d->so;
   p.bq = d->bq; p.bk = d->bk; p.bv = d->bv; p.bo = d->bo;
   p.scale = d->scale;
+  p.causal = d->causal != 0;
+  NK_CHECK_ARG(!d->causal || d->Lq == d->Lk);
   const int nw = attn_waves(d->Lq, d->H * d->B);
   dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
   const int dp = attn_dp(d->D);
@@ -626,6 +631,7 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = attn_check(d)) return e;
   NK_CHECK_ARG(q && k && v && o && lse && d_o && dq && dk && dv && delta_ws);
+  NK_CHECK_ARG(!d->causal);   // the causal variant serves the frozen text encoders: forward only
   NK_CHECK_ARG((d->sdq & 7) == 0 && (d->sdk & 7) == 0 && (d->sdv & 7) == 0 && (d->sdo & 7) == 0);
   NK_CHECK_ARG((d->bdq & 7) == 0 && (d->bdk & 7) == 0 && (d->bdv & 7) == 0 && (d->bdo & 7) == 0);
   AttnParams p = {};

@@ -100,6 +100,28 @@ extern "C" int nk_silu_bwd(const void* dy, const void* x, void* dx, long n, void
   return nk_check_launch("silu_bwd");
 }
 
+// ---- GELU of the CLIP text transformers (forward only: the encoders are frozen) -------------------
+// mode 0: exact erf form (open_clip's nn.GELU); mode 1: quick_gelu x * sigmoid(1.702 x) (openai/clip-vit-large-patch14)
+template <int MODE>
+__global__ void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(*(const uint4_t*)(x + i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      f[e] = MODE == 0 ? 0.5f * f[e] * (1.0f + erff(f[e] * 0.70710678118654752f)) : f[e] / (1.0f + __expf(-1.702f * f[e]));
+    *(uint4_t*)(y + i * 8) = pack8(f);
+  }
+}
+extern "C" int nk_gelu_fwd(const void* x, void* y, long n, int mode, void* stream) {
+  NK_CHECK_ARG(x && y && n > 0 && (n & 7) == 0 && (mode == 0 || mode == 1));
+  if (mode == 0)
+    hipLaunchKernelGGL(gelu_fwd_kernel<0>, dim3(ew_blocks(n >> 3)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n >> 3);
+  else
+    hipLaunchKernelGGL(gelu_fwd_kernel<1>, dim3(ew_blocks(n >> 3)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n >> 3);
+  return nk_check_launch("gelu_fwd");
+}
+
 // ---- out = a + b (gradient join where a tensor feeds two consumers) ----------------------------
 __global__ void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, long n8) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {

@@ -26,7 +26,7 @@ class NkAttnDesc(C.Structure):
     _fields_ = (
         [(n, i32) for n in ("B", "H", "Lq", "Lk", "D")]
         + [(n, i64) for n in ("sq", "sk", "sv", "so", "bq", "bk", "bv", "bo", "sdq", "sdk", "sdv", "sdo", "bdq", "bdk", "bdv", "bdo")]
-        + [("scale", f32)]
+        + [("scale", f32), ("causal", i32)]
     )
 
 
@@ -53,6 +53,7 @@ SIGNATURES: dict[str, list] = {
     "nk_geglu_fwd": [vp, vp, i64, i32, vp],
     "nk_geglu_bwd": [vp, vp, vp, i64, i32, vp],
     "nk_silu_fwd": [vp, vp, i64, vp],
+    "nk_gelu_fwd": [vp, vp, i64, i32, vp],
     "nk_silu_bwd": [vp, vp, vp, i64, vp],
     "nk_add": [vp, vp, vp, i64, vp],
     "nk_cat_channels": [vp, vp, vp, i64, i32, i32, vp],

@@ -506,6 +506,13 @@ def geglu_fwd(u: Tensor):
     return y, bwd
 
 
+def gelu(x: Tensor, quick: bool = False) -> Tensor:
+    """exact GELU, or x * sigmoid(1.702 x) with quick=True; forward only (frozen text encoders)"""
+    y = torch.empty_like(x)
+    call("nk_gelu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), int(quick), _stream())
+    return y
+
+
 def silu_fwd(x: Tensor):
     y = torch.empty_like(x)
     call("nk_silu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
@@ -539,9 +546,9 @@ def cat_fwd(a: Img, b: Img):
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
-def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head: int):
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head: int, causal: bool = False):
     """softmax(q k^T / sqrt(d)) v.  q [B*Lq, H*D], k/v [B*Lk, H*D] token matrices (column slices allowed).
-    bwd(do) -> (dq, dk, dv) dense token matrices."""
+    bwd(do) -> (dq, dk, dv) dense token matrices.  causal=True (frozen text transformers) is forward only."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _check2d(t, n)
     Lq, Lk = q.shape[0] // B, k.shape[0] // B
@@ -553,6 +560,7 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head:
     d.sq, d.sk, d.sv, d.so = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
     d.bq, d.bk, d.bv, d.bo = Lq * q.stride(0), Lk * k.stride(0), Lk * v.stride(0), Lq * o.stride(0)
     d.scale = float(dim_head) ** -0.5
+    d.causal = int(causal)
     call("nk_attention_fwd", C.byref(d), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), _stream())
 
     def bwd(do: Tensor, dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None):

@@ -81,6 +81,20 @@ class _StubFinder(importlib.abc.MetaPathFinder):
 
 
 def import_reference():
+    # transformers probes optional packages by importing them: let it look at the real environment before the stubs exist
+    import transformers.models.clip.modeling_clip  # noqa: F401
+    import transformers.models.clip.tokenization_clip  # noqa: F401
+    import transformers.tokenization_utils_base as tub
+
+    # transformers 5.x (this image) moved BatchEncoding out of transformers.tokenization_utils, where the reference
+    # (written against 4.36+) imports it from: alias the old location
+    import types
+    legacy = sys.modules.get("transformers.tokenization_utils")
+    if legacy is None or not hasattr(legacy, "BatchEncoding"):
+        legacy = legacy or types.ModuleType("transformers.tokenization_utils")
+        legacy.BatchEncoding = tub.BatchEncoding
+        sys.modules["transformers.tokenization_utils"] = legacy
+
     sys.meta_path.insert(0, _StubFinder())
     sys.path.insert(0, str(REF_SRC))
     import neurosis.modules.diffusion as nd  # noqa
@@ -95,10 +109,11 @@ def synth_tensor(name: str, shape, kind_hint: str = "") -> torch.Tensor:
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
     shape = tuple(shape)
     leaf = name.rsplit(".", 1)[-1]
-    is_norm = any(t in name for t in (".norm", "norm1", "norm2", "norm3", "norm_out", "in_layers.0", "out_layers.0", "out.0"))
+    is_norm = any(t in name for t in (".norm", "norm1", "norm2", "norm3", "norm_out", "in_layers.0", "out_layers.0", "out.0", "ln_1", "ln_2", "ln_final",
+                                      "layer_norm"))
     if leaf == "weight" and len(shape) == 1 and is_norm:
         return 1.0 + 0.1 * torch.randn(shape, generator=g)
-    if leaf == "bias":
+    if leaf == "bias" or leaf.endswith("_bias"):
         return 0.05 * torch.randn(shape, generator=g)
     fan_in = 1
     for s in shape[1:]:
@@ -365,9 +380,117 @@ def sampler_cases(nd):
     torch.save(fixture, HERE / "sampler_unet_tiny.pt")
 
 
+HF_CLIP_TINY = dict(vocab_size=1000, hidden_size=64, intermediate_size=256, num_hidden_layers=4, num_attention_heads=4, max_position_embeddings=77,
+                    hidden_act="quick_gelu", eos_token_id=2, bos_token_id=0, pad_token_id=1)
+OPENCLIP_TINY = dict(vocab_size=1000, width=128, layers=3, heads=2, context_length=77, embed_dim=96)
+
+
+def clip_token_ids():
+    """[3, 77] ids in the CLIP convention: BOS = vocab-2, EOS = vocab-1 (the highest id), padding after EOS = EOS (bigG) --
+    prompts of different lengths, one filling the whole context."""
+    g = torch.Generator().manual_seed(31)
+    ids = torch.randint(3, 990, (3, 77), generator=g)
+    ids[:, 0] = 998
+    for row, end in enumerate((9, 40, 76)):
+        ids[row, end:] = 999
+    return ids
+
+
+class _OpenCLIPTextStandIn(torch.nn.Module):
+    """open_clip is not installed here (reference pyproject: open-clip-torch >= 2.2.0).  This is its published text tower --
+    open_clip/transformer.py ResidualAttentionBlock (ln_1 -> nn.MultiheadAttention with the additive causal mask -> residual,
+    ln_2 -> c_fc, GELU, c_proj -> residual) under open_clip.CLIP's attribute names -- so that the REFERENCE's own
+    encode_with_transformer / text_transformer_forward / pool (models/text_encoder/clip.py:311-343) can run over it."""
+
+    class Block(torch.nn.Module):
+        def __init__(self, width, heads):
+            super().__init__()
+            nn = torch.nn
+            self.ln_1, self.ln_2 = nn.LayerNorm(width), nn.LayerNorm(width)
+            self.attn = nn.MultiheadAttention(width, heads)
+            self.mlp = nn.Sequential()
+            self.mlp.add_module("c_fc", nn.Linear(width, 4 * width))
+            self.mlp.add_module("gelu", nn.GELU())
+            self.mlp.add_module("c_proj", nn.Linear(4 * width, width))
+
+        def forward(self, x, attn_mask=None):
+            h = self.ln_1(x)
+            x = x + self.attn(h, h, h, need_weights=False, attn_mask=attn_mask)[0]
+            return x + self.mlp(self.ln_2(x))
+
+    def __init__(self, vocab_size, width, layers, heads, context_length, embed_dim):
+        super().__init__()
+        nn = torch.nn
+        self.token_embedding = nn.Embedding(vocab_size, width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, width))
+        self.transformer = nn.Module()
+        self.transformer.resblocks = nn.ModuleList(self.Block(width, heads) for _ in range(layers))
+        self.transformer.grad_checkpointing = False
+        self.ln_final = nn.LayerNorm(width)
+        self.text_projection = nn.Parameter(torch.empty(width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]))
+        mask = torch.empty(context_length, context_length).fill_(float("-inf")).triu_(1)
+        self.register_buffer("attn_mask", mask, persistent=False)
+
+
+def _bare(cls):
+    """an instance of a reference embedder without running its constructor (which downloads tokenizers / weights)"""
+    obj = cls.__new__(cls)
+    torch.nn.Module.__init__(obj)
+    obj.ucg_rate, obj.is_trainable, obj.extended_chunks, obj.max_length, obj.device = 0.0, False, 0, 77, "cpu"
+    return obj
+
+
+def text_encoder_cases():
+    """The reference's FrozenCLIPEmbedder.forward over transformers' CLIPTextModel (tiny, seeded weights) and its
+    FrozenOpenCLIPEmbedder2.forward over the open_clip stand-in above, on fixed token ids (the tokenizer is replaced by a
+    function returning them: the CLIP vocabulary is not on this machine)."""
+    import neurosis.models.text_encoder.clip as nclip
+    from transformers import CLIPTextModel
+    from transformers.models.clip import CLIPTextConfig
+
+    ids = clip_token_ids()
+    tokenizer = lambda text, **kw: {"input_ids": ids[: len(text)]}  # noqa: E731
+    prompts = ["a", "b", "c"]
+
+    hf = CLIPTextModel(CLIPTextConfig(**HF_CLIP_TINY)).eval()
+    hf_shapes = {k: list(v.shape) for k, v in hf.state_dict().items()}
+    hf.load_state_dict(synth_state_dict(hf_shapes))
+    out = {"ids": ids, "hf_cfg": HF_CLIP_TINY, "openclip_cfg": OPENCLIP_TINY, "hf": {}, "openclip": {}}
+    for tag, layer, layer_idx, pooled in (("hidden11_style", "hidden", 3, False), ("penultimate_pooled", "penultimate", None, True),
+                                          ("hidden_neg", "hidden", 1, True)):
+        emb = _bare(nclip.FrozenCLIPEmbedder)
+        emb.transformer, emb.tokenizer = hf, tokenizer
+        emb.layer, emb.return_pooled, emb.output_hidden_states = layer, pooled, True
+        emb.layer_idx = 10 if layer == "penultimate" else layer_idx        # what the reference constructor assigns
+        if layer == "penultimate":
+            emb.layer_idx = 2                                              # ... scaled to this 4-layer model: depth - 2
+        with torch.no_grad():
+            res = emb(prompts)
+        out["hf"][tag] = dict(layer=layer, layer_idx=emb.layer_idx, return_pooled=pooled, result=res)
+    with torch.no_grad():
+        full = hf(input_ids=ids, output_hidden_states=True)
+    out["hf"]["raw"] = dict(last_hidden_state=full.last_hidden_state, pooler_output=full.pooler_output, hidden_states=list(full.hidden_states))
+
+    oc = _OpenCLIPTextStandIn(**OPENCLIP_TINY).eval()
+    oc_shapes = {k: list(v.shape) for k, v in oc.state_dict().items()}
+    oc.load_state_dict(synth_state_dict(oc_shapes))
+    for tag, layer, pooled, legacy in (("penultimate_pooled", "penultimate", True, False), ("last", "last", False, False), ("legacy_last", "last", False, True),
+                                       ("pooled_layer", "pooled", False, False)):
+        emb = _bare(nclip.FrozenOpenCLIPEmbedder2)
+        emb.model, emb.tokenizer = oc, tokenizer
+        emb.layer, emb.return_pooled, emb.legacy = layer, pooled, legacy
+        with torch.no_grad():
+            res = emb(prompts)
+        out["openclip"][tag] = dict(layer=layer, return_pooled=pooled, legacy=legacy, result=res)
+    torch.save(out, HERE / "text_encoders_tiny.pt")
+    (HERE / "text_encoders_tiny_keys.json").write_text(json.dumps({"hf": hf_shapes, "openclip": oc_shapes}, indent=0))
+    print("text encoders: hf", tuple(full.last_hidden_state.shape), "openclip pooled", tuple(out["openclip"]["penultimate_pooled"]["result"][1].shape))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -384,3 +507,5 @@ if __name__ == "__main__":
         decoder_case(nmodel)
     if "sampler" in which:
         sampler_cases(nd)
+    if "text" in which:
+        text_encoder_cases()
