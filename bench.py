@@ -6,10 +6,12 @@
 
 Workload (BASELINE.json configs[1]): SDXL-base UNet (2.567 B parameters, random init), 1024x1024 synthetic
 images, batch 4 per GPU, bf16 MFMA arithmetic with fp32 accumulation / statistics / master weights; frozen VAE
-encoder in the step; text-encoder outputs are synthetic inputs (frozen TE, out of scope).  One "step" =
-VAE encode -> noise + preconditioning -> UNet forward -> weighted MSE -> UNet backward -> (N>1: flat gradient
-all-reduce over RCCL, overlapped with backward) -> fused AdamW update of every parameter.  Nothing is skipped
-or cached inside the timed region.  Weak scaling: every rank processes its own 4 images.
+encoder and the frozen SDXL conditioner (CLIP ViT-L + OpenCLIP ViT-bigG text encoders on synthetic token ids -- the
+CLIP vocabulary is not on the box -- plus the size / crop embedders) in the step, as in the reference's
+training_step (--precomputed-te feeds synthetic text-encoder OUTPUTS instead).  One "step" = VAE encode ->
+conditioner -> noise + preconditioning -> UNet forward -> weighted MSE -> UNet backward -> (N>1: flat gradient
+all-reduce over RCCL, overlapped with backward) -> fused Adafactor (or AdamW) update of every UNet parameter.
+Nothing is skipped or cached inside the timed region.  Weak scaling: every rank processes its own 4 images.
 
 Prints ONE JSON line on rank 0 (see the task contract); extra objects:
   roofline     -- the dominant kernel (the MFMA tile engine nk_gemm_kernel<...>, ~88 % of the step's FLOPs):
@@ -52,7 +54,20 @@ def reinit_zero_modules(net, std=0.02, seed=0):
                 p.copy_(torch.randn(p.shape, generator=g, device=p.device) * std)
 
 
-def build_engine(device, image_hw=(1024, 1024)):
+def build_conditioner(device):
+    """configs/sdxl/sdxl.example.yaml:118-160: CLIP-L hidden layer 11, OpenCLIP bigG penultimate + pooled, three size embedders"""
+    from neurosis_amd.models.text_encoder import FrozenCLIPEmbedder, FrozenOpenCLIPEmbedder2
+    from neurosis_amd.modules.encoders import ConcatTimestepEmbedderND, GeneralConditioner
+
+    torch.manual_seed(7)
+    embedders = [FrozenCLIPEmbedder(layer="hidden", layer_idx=11, input_key="caption_ids", device=device),
+                 FrozenOpenCLIPEmbedder2(arch="ViT-bigG-14", version=None, layer="penultimate", always_return_pooled=True, legacy=False,
+                                         input_key="caption_ids", device=device)]
+    embedders += [ConcatTimestepEmbedderND(outdim=256, input_key=k) for k in ("original_size_as_tuple", "crop_coords_top_left", "target_size_as_tuple")]
+    return GeneralConditioner(embedders).to(device)
+
+
+def build_engine(device, image_hw=(1024, 1024), conditioner=None):
     import neurosis_amd.modules.diffusion as D
     from neurosis_amd.models.autoencoder import AutoencoderKL
     from neurosis_amd.models.diffusion import DiffusionEngine
@@ -65,7 +80,8 @@ def build_engine(device, image_hw=(1024, 1024)):
     denoiser = denoiser.to(device)
     reinit_zero_modules(unet)
     loss_fn = D.StandardDiffusionLoss(sigma_generator=D.InjectedSigmaGenerator(), loss_weighting=D.EpsWeighting())
-    eng = DiffusionEngine(model=unet, denoiser=denoiser, first_stage_model=vae, loss_fn=loss_fn, scale_factor=SCALE_FACTOR, input_key="image")
+    eng = DiffusionEngine(model=unet, denoiser=denoiser, first_stage_model=vae, loss_fn=loss_fn, scale_factor=SCALE_FACTOR, input_key="image",
+                          conditioner=conditioner)
     eng.setup_flat_params()
     return eng
 
@@ -73,13 +89,19 @@ def build_engine(device, image_hw=(1024, 1024)):
 MIXED_BUCKETS = [(1216, 832), (832, 1216), (1024, 1024), (1152, 896), (896, 1152)]   # (H, W)
 
 
-def synthetic_batch(device, batch, hw, gen):
+def synthetic_batch(device, batch, hw, gen, precomputed_te=True):
     H, W = hw
-    return {
-        "image": torch.rand(batch, 3, H, W, device=device, generator=gen) * 2 - 1,
-        "crossattn": torch.randn(batch, 77, 2048, device=device, generator=gen),
-        "vector": torch.randn(batch, 2816, device=device, generator=gen),
-    }
+    image = torch.rand(batch, 3, H, W, device=device, generator=gen) * 2 - 1
+    if precomputed_te:
+        return {"image": image, "crossattn": torch.randn(batch, 77, 2048, device=device, generator=gen),
+                "vector": torch.randn(batch, 2816, device=device, generator=gen)}
+    # token ids in the CLIP convention: BOS, a prompt of random length, EOS (the highest id) to the end of the context
+    ids = torch.randint(1000, 40000, (batch, 77), device=device, generator=gen)
+    length = torch.randint(5, 76, (batch, 1), device=device, generator=gen)
+    ids = torch.where(torch.arange(77, device=device)[None] >= length, torch.full_like(ids, 49407), ids)
+    ids[:, 0] = 49406
+    size = torch.tensor([[float(H), float(W)]] * batch, device=device)
+    return {"image": image, "caption_ids": ids, "original_size_as_tuple": size, "crop_coords_top_left": torch.zeros_like(size), "target_size_as_tuple": size}
 
 
 def draw_sigmas(batch, gen_cpu, device):
@@ -261,6 +283,8 @@ def main():
                          "{832x1216, 1216x832, 1024x1024, 896x1152, 1152x896}; not the metric's configuration")
     ap.add_argument("--optimizer", default="adafactor", choices=["adafactor", "adamw"],
                     help="adafactor = the reference example config's optimizer (scale_parameter, relative_step, warmup_init); adamw = fused flat AdamW")
+    ap.add_argument("--precomputed-te", action="store_true",
+                    help="feed synthetic text-encoder outputs instead of running the frozen conditioner (CLIP-L + OpenCLIP-bigG) in the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the multi-rank control flow)")
@@ -289,7 +313,7 @@ def main():
     from neurosis_amd.dp import FlatDataParallel
 
     lib.load()  # fail loudly if the HIP library is missing
-    eng = build_engine(device, (args.res, args.res))
+    eng = build_engine(device, (args.res, args.res), None if args.precomputed_te else build_conditioner(device))
     unet = eng.model.diffusion_model
     if args.optimizer == "adafactor":
         eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)   # configs/sdxl/sdxl.example.yaml:158-164
@@ -309,7 +333,7 @@ def main():
             hw = (args.res, args.res)
             if args.mixed_res:   # (H, W) of this rank's bucket for this step (N/dataset/aspect/lists.py:14-56)
                 hw = MIXED_BUCKETS[int(torch.randint(len(MIXED_BUCKETS), (1,), generator=gen_cpu))]
-            batch = synthetic_batch(device, args.batch, hw, gen)
+            batch = synthetic_batch(device, args.batch, hw, gen, args.precomputed_te)
             sig = draw_sigmas(args.batch, gen_cpu, device)
             eng.accumulate(mb, dp, last=mb == args.accumulate - 1)
             loss = eng.training_step(batch, 0, sigmas=sig)
@@ -334,6 +358,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # The long-lived object graph (modules, parameters, descriptor tables) goes to the permanent generation: a full
+    # collection of the cyclic GC otherwise walks all of it every ~10 steps and holds the launching thread for ~70 ms
+    # (measured: one 268 ms step in twelve).  Garbage made by the steps themselves is still collected.
+    import gc
+    gc.collect()
+    gc.freeze()
     if dp is not None:
         dp.reducer.record_timing = True
     barrier()
@@ -348,7 +378,8 @@ def main():
         dp.reducer.record_timing = False
     # per-step GPU times (event to event on the compute stream), this rank
     marks = step_marks + [end_mark]
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
+    in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
+    per_step = sorted(in_order)
     pct = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]
     comm = None
     if comm_marks:
@@ -398,10 +429,10 @@ def main():
             "metric": "train images/sec (node) SDXL 1024^2", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"SDXL-base {'mixed-res buckets (~1024^2 pixels)' if args.mixed_res else str(args.res) + '^2'} bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, frozen TE outputs synthetic",
+            "config": {"workload": f"SDXL-base {'mixed-res buckets (~1024^2 pixels)' if args.mixed_res else str(args.res) + '^2'} bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, {'frozen TE outputs synthetic' if args.precomputed_te else 'frozen CLIP-L + OpenCLIP-bigG conditioner on synthetic token ids'}",
                        "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}", "activation_checkpointing": False, "accumulate_grad_batches": args.accumulate},
             "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-            "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "comm": comm,
+            "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "step_ms_in_order": [round(t, 1) for t in in_order], "comm": comm,
             "stream_k_fixup_timeouts": lib.query("nk_gemm_sk_status"),   # 0: every K-split tile was joined (gemm.hip)
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1,6 +1,7 @@
 """How long does the host take to ENQUEUE one training step (no device sync inside)?"""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 dev = torch.device("cuda", 0)
 eng = bench.build_engine(dev)
@@ -9,6 +10,7 @@ def step():
     batch = bench.synthetic_batch(dev, 4, (1024, 1024), gen)
     sig = bench.draw_sigmas(4, gen_cpu, dev)
     loss = eng.training_step(batch, 0, sigmas=sig); loss.backward(); eng.optimizer_step(lr=1e-6)
+eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)
 for _ in range(2): step()
 torch.cuda.synchronize()
 for _ in range(3):
