@@ -24,6 +24,7 @@ import zlib
 from pathlib import Path
 from unittest import mock
 
+import numpy as np
 import torch
 
 HERE = Path(__file__).resolve().parent
@@ -488,9 +489,71 @@ def text_encoder_cases():
     print("text encoders: hf", tuple(full.last_hidden_state.shape), "openclip pooled", tuple(out["openclip"]["penultimate_pooled"]["result"][1].shape))
 
 
+BUCKET_LIST_CASES = {
+    "default": {}, "n15": dict(n_buckets=15), "n9_atan": dict(n_buckets=9, use_atan=True), "interp": dict(n_buckets=15, bias_square=False),
+    "small": dict(n_buckets=7, edge_min=256, edge_max=1024, edge_step=64, max_aspect=2.0, tgt_pixels=512 * 512, tolerance=10),
+}
+BUCKET_RATIOS = [0.2, 0.25, 0.3333, 0.5, 0.5625, 0.6667, 0.75, 0.8, 0.95, 1.0, 1.05, 1.25, 1.3333, 1.5, 1.7778, 2.0, 2.3, 3.0, 4.0]
+
+
+def bucket_assignment(n=400):
+    """a synthetic dataset: the bucket index of each of n samples (some buckets smaller than a batch)"""
+    g = np.random.default_rng(5)
+    return g.choice([3, 7, 8, 12, 20, 21, 33], size=n, p=[0.01, 0.2, 0.15, 0.3, 0.25, 0.08, 0.01]).astype(np.int32)
+
+
+def dataset_cases():
+    """Aspect buckets, the bucketed batch schedule and the distributed sampler (SURVEY N4 data side)."""
+    import pandas as pd
+    from neurosis.dataset.aspect.bucket import AspectBucketList
+    from neurosis.dataset.aspect.lists import SDXLBucketList
+    from neurosis.dataset.aspect.sampler import AspectDistributedSampler
+    from neurosis.dataset.imagefolder.aspect import ImageFolderDataset
+
+    out = {"lists": {}, "lookup": {}, "schedule": {}, "sampler": {}}
+    for name, kw in BUCKET_LIST_CASES.items():
+        try:
+            lst = AspectBucketList(**kw)
+        except ValueError as err:          # (the reference's own defaults ask for more buckets than its constraints yield)
+            out["lists"][name] = out["lookup"][name] = f"ValueError: {err}"
+            continue
+        out["lists"][name] = [(b.width, b.height, b.error) for b in lst]
+        out["lookup"][name] = [int(lst.bucket_idx(r)) for r in BUCKET_RATIOS]
+    for name, kw in (("sdxl", {}), ("sdxl_atan", dict(use_atan=True)), ("sdxl_interp", dict(bias_square=False))):
+        lst = SDXLBucketList(**kw)
+        out["lists"][name] = [(b.width, b.height, b.error) for b in lst]
+        out["lookup"][name] = [int(lst.bucket_idx(r)) for r in BUCKET_RATIOS]
+
+    class _Holder:       # what get_batch_iterator reads from `self`
+        pass
+
+    for batch_size in (4, 16):
+        holder = _Holder()
+        holder.samples, holder.batch_size = pd.DataFrame({"bucket_idx": bucket_assignment()}), batch_size
+        np.random.seed(1234)
+        out["schedule"][batch_size] = list(ImageFolderDataset.get_batch_iterator(holder))
+
+    class _Batches:
+        def get_batch_iterator(self):
+            return iter(out["schedule"][4])
+
+    for world, drop_last, shuffle in ((2, False, True), (8, False, True), (8, True, True), (3, False, False)):
+        per_rank = []
+        for rank in range(world):
+            sampler = AspectDistributedSampler(_Batches(), num_replicas=world, rank=rank, shuffle=shuffle, seed=11, drop_last=drop_last)
+            epochs = []
+            for epoch in (0, 3):
+                sampler.set_epoch(epoch)
+                epochs.append(list(sampler))
+            per_rank.append(epochs)
+        out["sampler"][(world, drop_last, shuffle)] = per_rank
+    torch.save(out, HERE / "dataset_aspect.pt")
+    print("dataset: lists", {k: len(v) for k, v in out["lists"].items()}, "batches", {k: len(v) for k, v in out["schedule"].items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -509,3 +572,5 @@ if __name__ == "__main__":
         sampler_cases(nd)
     if "text" in which:
         text_encoder_cases()
+    if "dataset" in which:
+        dataset_cases()
