@@ -219,8 +219,8 @@ def collate_bucket_batch(samples: Sequence[dict], image_key: str = "image", capt
     fp32 rows on the device)."""
     first = samples[0]
     batch = {key: [s[key] for s in samples] for key in first}
-    batch[image_key] = torch.stack([torch.as_tensor(s[image_key]) for s in samples], dim=0)
     shapes = {tuple(s[image_key].shape) for s in samples}
     if len(shapes) != 1:
         raise ValueError(f"a bucketed batch must hold one image shape, got {sorted(shapes)}")
+    batch[image_key] = torch.stack([torch.as_tensor(s[image_key]) for s in samples], dim=0)
     return batch
