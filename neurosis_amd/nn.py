@@ -109,7 +109,8 @@ class Conv2d(nn.Module):
 
     def _padded_params(self):
         """(weight, bias) stand-ins with channels padded to multiples of 8 (tiny tensors, rebuilt per param epoch)."""
-        if self._pad_cache is not None and self._pad_cache[0] == ops.state.param_epoch and self._pad_cache[1].device == self.weight.device:
+        stamp = (ops._param_stamp(self.weight), None if self.bias is None else ops._param_stamp(self.bias))
+        if self._pad_cache is not None and self._pad_cache[0] == stamp and self._pad_cache[1].device == self.weight.device:
             return self._pad_cache[1], self._pad_cache[2]
         ci, co, k = _pad8(self.in_channels), _pad8(self.out_channels), self.kernel_size
         with torch.no_grad():
@@ -121,7 +122,7 @@ class Conv2d(nn.Module):
                 b = torch.zeros(co, device=self.weight.device)
                 b[: self.out_channels] = self.bias.detach()
                 bp = nn.Parameter(b, requires_grad=False)
-        self._pad_cache = (ops.state.param_epoch, wp, bp)
+        self._pad_cache = (stamp, wp, bp)
         return wp, bp
 
     def fwd(self, x: Img, rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None, upsample: bool = False, need_dx: bool = True):

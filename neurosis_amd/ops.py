@@ -178,15 +178,26 @@ class Img:
 # ------------------------------------------------------------------------------------------------
 # parameter plumbing: bf16 shadows and fp32 grads
 # ------------------------------------------------------------------------------------------------
+def _param_stamp(p: Tensor):
+    """What a cached derivative of parameter `p` (bf16 shadow, channel-padded copy) is valid for.  Store-managed parameters are
+    updated by raw-pointer kernels, which torch's version counter does not see: they go by the global epoch the store bumps.
+    Everything else (frozen VAE / text-encoder weights, stand-alone modules) goes by the tensor's own version counter and
+    address, so that an optimizer step on the UNet does not invalidate 850 M frozen parameters' shadows every step."""
+    if getattr(p, "_nk_store", None) is not None:
+        return ("epoch", state.param_epoch)
+    return ("version", p._version, p.data_ptr())
+
+
 def shadow(p: Tensor) -> Tensor:
     """bf16 copy of an fp32 parameter in the same physical layout (flat store view, or cached cast)."""
-    s = getattr(p, "_nk_shadow", None)
-    if s is not None and getattr(p, "_nk_shadow_epoch", -1) == state.param_epoch:
-        return s
     if getattr(p, "_nk_store", None) is not None:
-        # store-managed: the store refreshes all shadows at once
-        p._nk_store.refresh()
+        if getattr(p, "_nk_shadow_epoch", -1) != state.param_epoch:
+            p._nk_store.refresh()      # store-managed: the store refreshes all shadows at once
         return p._nk_shadow
+    s = getattr(p, "_nk_shadow", None)
+    stamp = _param_stamp(p)
+    if s is not None and getattr(p, "_nk_shadow_stamp", None) == stamp:
+        return s
     flat = _phys_flat(p)
     s = torch.empty(flat.numel(), dtype=BF16, device=p.device)
     n = flat.numel()
@@ -199,7 +210,7 @@ def shadow(p: Tensor) -> Tensor:
         call("nk_cast_f32_to_bf16", pad.data_ptr(), s8.data_ptr(), pad.numel(), _stream())
         s = s8[:n]
     p._nk_shadow = s
-    p._nk_shadow_epoch = state.param_epoch
+    p._nk_shadow_stamp = stamp
     return s
 
 
