@@ -100,3 +100,34 @@ def test_engine_accumulate_helper_overwrites_then_adds():
     assert float((eng.store.grad - 2 * g1).norm() / (2 * g1).norm()) < 1e-2
     eng.optimizer_step(lr=1e-6)
     assert ops.state.grad_accumulate is False
+
+
+@pytest.mark.parametrize("optimizer", ["adafactor", "adamw"])
+def test_optimizer_on_its_own_stream_equals_in_line(optimizer):
+    """optimizer_step() runs on a second stream and is joined where the next UNet forward starts: three training steps give
+    the parameters the in-line order gives (same kernels on the same data; tolerance covers the fp32 atomics of split-K weight
+    gradients, which differ run to run either way), and nothing reads the weights before the join."""
+    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
+    finals, losses = [], []
+    for overlap in (True, False):
+        eng = _build(fx, shapes)
+        eng.overlap_optimizer = overlap
+        if optimizer == "adafactor":
+            eng.configure_adafactor(scale_parameter=False, relative_step=False, warmup_init=False, lr=1e-3)
+        run = []
+        for _ in range(3):
+            loss = _loss(eng, fx, slice(0, 2))
+            loss.mean().backward()
+            eng.optimizer_step(lr=1e-3)
+            assert eng._optimizer_in_flight is overlap
+            run.append(loss.detach().float().cpu())
+        eng.join_optimizer()
+        assert eng._optimizer_in_flight is False
+        torch.cuda.synchronize()
+        finals.append(eng.store.master.clone())
+        losses.append(torch.stack(run))
+    assert float((losses[0] - losses[1]).abs().max() / losses[1].abs().max()) <= 2e-3
+    assert float((finals[0] - finals[1]).norm() / finals[1].norm()) <= 1e-4
+    moved = float((finals[1] - _build(fx, shapes).store.master).norm())
+    assert moved > 0.0
