@@ -155,6 +155,10 @@ int nk_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 long nk_colsum_ws_floats(long M, int N);
 int nk_colsum(const void* dy, float* out, float* ws, long M, int N, long ld, int accumulate, void* stream);
 
+/* backward of nk_softmax_rows, in place on dp [M][L] bf16 given the probabilities p: ds = p * (dp - sum_j dp*p) * scale
+ * (AttnBlock of the VAE, modules/diffusion/model.py:144-222, when the autoencoder itself is trained: SURVEY 8(f) N2) */
+int nk_softmax_rows_bwd(const void* p, void* dp, long M, int L, float scale, void* stream);
+
 /* y = gelu(x) elementwise over n bf16 values (n % 8 == 0).  mode 0: exact, 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU in open_clip's
  * text tower, models/text_encoder/clip.py:333-343); mode 1: "quick_gelu" x * sigmoid(1.702 x) (HF CLIPTextModel of
  * openai/clip-vit-large-patch14, models/text_encoder/clip.py:49-56). */

@@ -439,6 +439,45 @@ extern "C" int nk_softmax_rows(void* s, long M, int L, void* stream) {
   return nk_check_launch("softmax_rows");
 }
 
+// ---- backward of the row softmax, in place on dp: ds = p * (dp - sum_j dp*p) * scale ---------------
+// (the VAE mid-block attention when the VAE itself is trained: its probabilities are kept from the forward pass)
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const bf16_t* __restrict__ p, bf16_t* __restrict__ dp, long M, int L,
+                                                               float scale) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (long row = blockIdx.x; row < M; row += gridDim.x) {
+    const bf16_t* pr = p + row * L;
+    bf16_t* dr = dp + row * L;
+    float dot = 0.f;
+    for (int i = tid * 8; i < L; i += 256 * 8) {
+      float a[8], b[8];
+      unpack8(*(const uint4_t*)(pr + i), a);
+      unpack8(*(const uint4_t*)(dr + i), b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot += a[e] * b[e];
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    for (int i = tid * 8; i < L; i += 256 * 8) {
+      float a[8], b[8];
+      unpack8(*(const uint4_t*)(pr + i), a);
+      unpack8(*(const uint4_t*)(dr + i), b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = a[e] * (b[e] - dot) * scale;
+      *(uint4_t*)(dr + i) = pack8(b);
+    }
+    __syncthreads();
+  }
+}
+extern "C" int nk_softmax_rows_bwd(const void* p, void* dp, long M, int L, float scale, void* stream) {
+  NK_CHECK_ARG(p && dp && M > 0 && L > 0 && (L & 7) == 0);
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((int)(M < 4096 ? M : 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p,
+                     (bf16_t*)dp, M, L, scale);
+  return nk_check_launch("softmax_rows_bwd");
+}
+
 // ---- EDM noising + preconditioning (loss.py:117-140, denoiser.py:41-49) -------------------------
 // z_t = x + sigma*eps (fp32, NCHW) ; net_in = bf16 channels-last (z_t * c_in), channels padded to Cpad
 __global__ void edm_prepare_kernel(const float* __restrict__ x, const float* __restrict__ eps,

@@ -44,6 +44,7 @@ SIGNATURES: dict[str, list] = {
     "nk_attention_fwd": [adp, vp, vp, vp, vp, vp, vp],
     "nk_attention_bwd": [adp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nk_softmax_rows": [vp, i64, i32, vp],
+    "nk_softmax_rows_bwd": [vp, vp, i64, i32, f32, vp],
     "nk_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "nk_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "nk_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],

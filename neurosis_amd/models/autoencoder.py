@@ -11,8 +11,11 @@ from typing import Optional
 import torch
 from torch import nn
 
+from .. import ops
+from ..lib import call
 from ..modules.diffusion.model import Decoder, Encoder
-from ..nn import Conv2d
+from ..nn import Conv2d, FlatParamStore
+from ..ops import BF16, Img
 
 
 class AutoencoderKL(nn.Module):
@@ -64,3 +67,159 @@ class AutoencoderKL(nn.Module):
             return dec(z, **kwargs)
         finally:
             dec.standalone, dec.post_quant_conv = prev
+
+
+class DiagonalGaussianRegularizer(nn.Module):
+    """`neurosis.modules.regularizers.DiagonalGaussianRegularizer` (:23-42) over `DiagonalGaussianDistribution`
+    (modules/distributions.py:28-72): moments = [mean | logvar] on the channel axis, logvar clamped to [-30, 20],
+    z = mean + exp(logvar / 2) * eps (or the mode with sample=False), log["kl_loss"] = sum_b KL(b) / B.
+    `regularize` also returns the backward of the map moments -> (z, kl_loss): the tensors are latent-sized
+    ([B, 2*z, H/8, W/8] fp32), plain torch arithmetic on the device."""
+
+    def __init__(self, sample: bool = True) -> None:
+        super().__init__()
+        self.sample = sample
+
+    def get_trainable_parameters(self):
+        yield from ()
+
+    def regularize(self, moments: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        mean, raw_logvar = torch.chunk(moments, 2, dim=1)
+        logvar = raw_logvar.clamp(-30.0, 20.0)
+        std, var = torch.exp(0.5 * logvar), torch.exp(logvar)
+        if self.sample:
+            eps = torch.randn(mean.shape).to(mean.device) if noise is None else noise.to(mean)
+            z = mean + std * eps
+        else:
+            eps, z = None, mean
+        kl = 0.5 * torch.sum(mean * mean + var - 1.0 - logvar, dim=[1, 2, 3])
+        batch = moments.shape[0]
+        log = {"kl_loss": kl.sum() / batch}
+
+        def bwd(dz: torch.Tensor, d_kl_loss: float = 0.0) -> torch.Tensor:
+            """gradient w.r.t. the moments of  <dz, z> + d_kl_loss * kl_loss"""
+            d_mean = dz + (d_kl_loss / batch) * mean
+            d_logvar = (d_kl_loss / batch) * 0.5 * (var - 1.0)
+            if eps is not None:
+                d_logvar = d_logvar + dz * eps * 0.5 * std
+            inside = (raw_logvar >= -30.0) & (raw_logvar <= 20.0)
+            return torch.cat((d_mean, d_logvar * inside), dim=1)
+
+        return z, log, bwd
+
+    def forward(self, z: torch.Tensor):
+        out, log, _ = self.regularize(z)
+        return out, log
+
+
+class AutoencodingEngine(nn.Module):
+    """The reconstruction part of `neurosis.models.autoencoder.AutoencodingEngine` (autoencoder.py:131-293) without Lightning:
+    encode -> regularize -> decode, a "simple" reconstruction loss (the branch of inner_training_step where `self.loss(x, xrec)`
+    returns a tensor, :247-256), manual optimisation.  The adversarial / perceptual loss (GeneralLPIPSWithDiscriminator: LPIPS
+    feature nets, PatchGAN, adaptive weighting, second optimizer) is the part of SURVEY 8(f) N2 that is not built.
+
+    MI355X shape of it: images enter as fp32 NCHW and leave the same way, everything between is channels-last bf16 tokens
+    through `Encoder.fwdb` / `Decoder.fwdb` (explicit backward closures, weight gradients on the side stream as in the UNet),
+    the l2 loss and its gradient come from one kernel over the decoder's output tokens, parameters / gradients / AdamW state
+    live in one FlatParamStore across encoder and decoder."""
+
+    def __init__(self, *, encoder: Encoder, decoder: Decoder, loss="l2", regularizer: Optional[nn.Module] = None, input_key: str = "image",
+                 regularization_weights: Optional[dict] = None, **kwargs):
+        super().__init__()
+        self.encoder, self.decoder = encoder, decoder
+        self.regularization = regularizer if regularizer is not None else DiagonalGaussianRegularizer()
+        if isinstance(loss, nn.MSELoss) or loss in ("l2", "mse"):
+            self.rec_loss_type = "l2"
+        elif isinstance(loss, nn.L1Loss) or loss in ("l1", "mae"):
+            self.rec_loss_type = "l1"
+        else:
+            raise NotImplementedError("only the simple reconstruction losses (l2 / l1) are built; GeneralLPIPSWithDiscriminator is not")
+        self.input_key = input_key
+        self.regularization_weights = dict(regularization_weights or {})     # e.g. {"kl_loss": 1e-6}; the reference's simple branch uses none
+        self.global_step = 0
+        self.store: Optional[FlatParamStore] = None
+        self.last_log: dict = {}
+
+    # -- reference surface -------------------------------------------------------------------------
+    def get_input(self, batch: dict) -> torch.Tensor:
+        return batch[self.input_key]
+
+    def get_autoencoder_params(self, decoder_only: bool = False) -> list:
+        params = list(self.decoder.parameters())
+        return params if decoder_only else params + list(self.encoder.parameters())
+
+    def get_last_layer(self):
+        return self.decoder.get_last_layer()
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_reg_log: bool = False, unregularized: bool = False):
+        z = self.encoder(x)
+        if unregularized:
+            return z, dict()
+        z, reg_log = self.regularization(z)
+        return (z, reg_log) if return_reg_log else z
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, **kwargs) -> torch.Tensor:
+        return self.decoder(z, **kwargs)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, **kwargs):
+        z, reg_log = self.encode(x, return_reg_log=True)
+        return z, self.decode(z, **kwargs), reg_log
+
+    # -- training ----------------------------------------------------------------------------------
+    def setup_flat_params(self) -> FlatParamStore:
+        self.store = FlatParamStore(self.get_autoencoder_params())
+        ops.state.assume_zeroed = False
+        if ops.state.wgrad_stream is None:
+            ops.state.wgrad_stream = torch.cuda.Stream()
+        return self.store
+
+    @torch.no_grad()
+    def loss_and_backward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        """forward + backward of  rec_loss(x, decode(regularize(encode(x)))) + sum_k w_k * reg_log[k]  into the parameters'
+        gradients.  Returns (loss, z, xrec, reg_log); xrec fp32 NCHW.  `noise` may be injected (parity tests)."""
+        B, C, H, W = x.shape
+        x = x.float().contiguous()
+        cpad = (C + 7) // 8 * 8
+        moments_img, b_enc = self.encoder.fwdb(Img(ops.nchw_to_tokens(x, cpad), B, H, W))
+        mc = self.encoder.quant_conv.out_channels if self.encoder.standalone else self.encoder.conv_out.out_channels
+        moments = ops.tokens_to_nchw(moments_img.t, B, mc, moments_img.H, moments_img.W, dtype=torch.float32)
+        z, reg_log, b_reg = self.regularization.regularize(moments, noise)
+        zc = z.shape[1]
+        out_img, b_dec = self.decoder.fwdb(Img(ops.nchw_to_tokens(z.contiguous(), (zc + 7) // 8 * 8), B, z.shape[2], z.shape[3]))
+        xrec = ops.tokens_to_nchw(out_img.t, B, C, out_img.H, out_img.W, dtype=torch.float32)
+        dev = x.device
+        if self.rec_loss_type == "l2":
+            # mean((xrec - x)^2) over everything = sum_b (1/B) * mean_chw: the edm loss kernel with c_out = 1, c_skip = 0, w = 1/B
+            one, zero = torch.ones(B, device=dev), torch.zeros(B, device=dev)
+            weight = torch.full((B,), 1.0 / B, device=dev)
+            per_sample = torch.empty(B, dtype=torch.float32, device=dev)
+            d_out = torch.empty_like(out_img.t)
+            call("nk_edm_loss", out_img.t.data_ptr(), x.data_ptr(), x.data_ptr(), one.data_ptr(), zero.data_ptr(), weight.data_ptr(), per_sample.data_ptr(),
+                 d_out.data_ptr(), B, C, H * W, out_img.C, 1.0, ops._stream())
+            rec = per_sample.sum()
+        else:
+            diff = xrec - x
+            rec = diff.abs().mean()
+            d_out = ops.nchw_to_tokens((torch.sign(diff) / diff.numel()).contiguous(), out_img.C)
+        loss = rec
+        for key, w in self.regularization_weights.items():
+            loss = loss + w * reg_log[key]
+        dz = ops.tokens_to_nchw(b_dec(d_out), B, zc, z.shape[2], z.shape[3], dtype=torch.float32)
+        d_moments = b_reg(dz, float(self.regularization_weights.get("kl_loss", 0.0)))
+        b_enc(ops.nchw_to_tokens(d_moments.contiguous(), moments_img.C))
+        ops.join_wgrad_stream()
+        return loss, z, xrec, reg_log
+
+    def training_step(self, batch: dict, batch_idx: int = 0, lr: float = 4.5e-6, betas=(0.5, 0.9), weight_decay: float = 0.0, noise=None) -> torch.Tensor:
+        """autoencoder.py:280-293 with one optimizer (no discriminator): gradients are overwritten by the backward, then one
+        fused AdamW step over the flat buffers."""
+        if self.store is None:
+            raise RuntimeError("call setup_flat_params() first")
+        loss, _, _, reg_log = self.loss_and_backward(self.get_input(batch), noise)
+        self.store.adamw_step(lr, betas, 1e-8, weight_decay)
+        self.global_step += 1
+        self.last_log = {"train/loss/rec": loss.detach(), **{f"train/{k}": v.detach() for k, v in reg_log.items()}}
+        return loss

@@ -1,11 +1,12 @@
 """VAE Encoder and Decoder on MI355X: the class surface of neurosis.modules.diffusion.model.{Encoder,Decoder}
 (/root/reference/src/neurosis/modules/diffusion/model.py:456-606 and :609-765) over the HIP kernels.
 
-The diffusion engine only ever runs these under no_grad (DiffusionEngine.encode_first_stage / decode_first_stage,
-models/diffusion.py:172-197), so both mirrors are forward-only: same constructor arguments, module tree and
-state_dict keys (conv_in, down.{l}.block.{i}.{norm1,conv1,norm2,conv2,nin_shortcut}, down.{l}.downsample.conv,
-up.{l}.block.{i}.*, up.{l}.upsample.conv, mid.{block_1,attn_1,block_2}, norm_out, conv_out, quant_conv /
-post_quant_conv).  Training the VAE itself is not built.
+Same constructor arguments, module tree and state_dict keys (conv_in, down.{l}.block.{i}.{norm1,conv1,norm2,conv2,
+nin_shortcut}, down.{l}.downsample.conv, up.{l}.block.{i}.*, up.{l}.upsample.conv, mid.{block_1,attn_1,block_2}, norm_out,
+conv_out, quant_conv / post_quant_conv).  Two ways in: `fwd` / `forward` -- forward only, what the diffusion engine runs
+under no_grad (DiffusionEngine.encode_first_stage / decode_first_stage, models/diffusion.py:172-197) -- and `fwdb`, which also
+returns the backward closure of the block (weight gradients into the parameters' .grad, input gradient returned) for
+training the autoencoder itself (models/autoencoder.AutoencodingEngine; SURVEY 8(f) N2, reconstruction part).
 """
 from __future__ import annotations
 
@@ -29,6 +30,12 @@ def _gn(x: Img, norm: nn.GroupNorm, silu: bool) -> Img:
     return ops.groupnorm_fwd(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)[0]
 
 
+def _conv_fwdb(conv: Conv2d, x: Img, **kw):
+    """(y Img, bwd) with bwd(dy tokens) -> dx tokens"""
+    y, b = conv.fwd(x, **kw)
+    return y, lambda dy: b(dy)[0].t
+
+
 class Downsample(nn.Module):
     """model.py:65-82: ConstantPad2d((0,1,0,1)) + 3x3 stride-2 conv, as one implicit-GEMM gather."""
 
@@ -41,6 +48,9 @@ class Downsample(nn.Module):
 
     def fwd(self, x: Img) -> Img:
         return self.conv.fwd(x, need_dx=False)[0]
+
+    def fwdb(self, x: Img):
+        return _conv_fwdb(self.conv, x)
 
 
 class Upsample(nn.Module):
@@ -56,6 +66,9 @@ class Upsample(nn.Module):
 
     def fwd(self, x: Img) -> Img:
         return self.conv.fwd(x, upsample=True, need_dx=False)[0]
+
+    def fwdb(self, x: Img):
+        return _conv_fwdb(self.conv, x, upsample=True)
 
 
 class ResnetBlock(nn.Module):
@@ -92,6 +105,28 @@ class ResnetBlock(nn.Module):
             s = x.t
         return self.conv2.fwd(h, residual=s, need_dx=False)[0]
 
+    def fwdb(self, x: Img):
+        """(y, bwd); bwd(dy tokens) -> dx tokens"""
+        n1, n2 = self.norm1, self.norm2
+        h0, b_n1 = ops.groupnorm_fwd(x, n1.weight, n1.bias, n1.num_groups, n1.eps, True)
+        h1, b_c1 = self.conv1.fwd(h0)
+        h2, b_n2 = ops.groupnorm_fwd(h1, n2.weight, n2.bias, n2.num_groups, n2.eps, True)
+        b_short = None
+        if self.in_channels != self.out_channels:
+            short, b_short = (self.conv_shortcut if self.use_conv_shortcut else self.nin_shortcut).fwd(x)
+            skip = short.t
+        else:
+            skip = x.t
+        y, b_c2 = self.conv2.fwd(h2, residual=skip)
+
+        def bwd(dy: Tensor) -> Tensor:
+            dh1 = b_n2(b_c2(dy)[0].t)
+            dh0 = b_c1(dh1)[0].t
+            through_skip = dy if b_short is None else b_short(dy)[0].t
+            return b_n1(dh0, dx_add=through_skip)
+
+        return y, bwd
+
 
 class AttnBlock(nn.Module):
     """model.py:144-243 (AttnBlock / MemoryEfficientAttnBlock / TorchSDPAttnBlock): single-head self-attention over
@@ -112,6 +147,20 @@ class AttnBlock(nn.Module):
         o = ops.attention_unfused(q, k, v, x.N)
         y = ops.gemm_nt(o, ops.w2d(self.proj_out.weight), self.proj_out.bias, residual=x.t)
         return Img(y, x.N, x.H, x.W)
+
+    def fwdb(self, x: Img):
+        n = self.norm
+        hn, b_n = ops.groupnorm_fwd(x, n.weight, n.bias, n.num_groups, n.eps, False)
+        (q, b_q), (k, b_k), (v, b_v) = (m.fwd(hn) for m in (self.q, self.k, self.v))
+        o, b_att = ops.attention_unfused_fwd(q.t, k.t, v.t, x.N)
+        y, b_p = self.proj_out.fwd(Img(o, x.N, x.H, x.W), residual=x.t)
+
+        def bwd(dy: Tensor) -> Tensor:
+            dq, dk, dv = b_att(b_p(dy)[0].t)
+            dhn = ops.add(ops.add(b_q(dq)[0].t, b_k(dk)[0].t), b_v(dv)[0].t)
+            return b_n(dhn, dx_add=dy)
+
+        return y, bwd
 
 
 MemoryEfficientAttnBlock = AttnBlock
@@ -203,6 +252,46 @@ class Encoder(nn.Module):
             h = self.quant_conv.fwd(h, need_dx=False)[0]
         return h
 
+    def fwdb(self, x: Img):
+        """encode (+ quant_conv when standalone) keeping the backward: (moments Img, bwd); bwd(d_moments tokens) -> None (the
+        image needs no gradient)."""
+        tape = []
+
+        def run(pair):
+            tape.append(pair[1])
+            return pair[0]
+
+        h, b_in = self.conv_in.fwd(x, need_dx=False)
+        for i_level in range(self.num_resolutions):
+            level = self.down[i_level]
+            for i_block in range(self.num_res_blocks):
+                h = run(level.block[i_block].fwdb(h))
+                if len(level.attn) > 0:
+                    h = run(level.attn[i_block].fwdb(h))
+            if i_level != self.num_resolutions - 1:
+                h = run(level.downsample.fwdb(h))
+        h = run(self.mid.block_1.fwdb(h))
+        if not isinstance(self.mid.attn_1, nn.Identity):
+            h = run(self.mid.attn_1.fwdb(h))
+        h = run(self.mid.block_2.fwdb(h))
+        no = self.norm_out
+        hn, b_no = ops.groupnorm_fwd(h, no.weight, no.bias, no.num_groups, no.eps, True)
+        h, b_out = self.conv_out.fwd(hn)
+        b_quant = None
+        if self.standalone:
+            h, b_quant = self.quant_conv.fwd(h)
+
+        def bwd(dh: Tensor) -> None:
+            if b_quant is not None:
+                dh = b_quant(dh)[0].t
+            dh = b_no(b_out(dh)[0].t)
+            for b in reversed(tape):
+                dh = b(dh)
+            tape.clear()
+            b_in(dh)
+
+        return h, bwd
+
     @torch.no_grad()
     def forward(self, x: Tensor, regularize: bool = False) -> Tensor:
         """model.py:585-606.  With regularize=True returns the DiagonalGaussian mode = the mean half of the
@@ -289,6 +378,45 @@ class Decoder(nn.Module):
         if self.give_pre_end:
             return h
         return self.conv_out.fwd(_gn(h, self.norm_out, True), need_dx=False)[0]
+
+    def fwdb(self, z: Img):
+        """(image Img, bwd); bwd(d_image tokens) -> dz tokens"""
+        if self.give_pre_end or self.tanh_out:
+            raise NotImplementedError("give_pre_end / tanh_out are not used by the SD/SDXL autoencoder configs")
+        tape = []
+
+        def run(pair):
+            tape.append(pair[1])
+            return pair[0]
+
+        h = z
+        if self.standalone:
+            h = run(_conv_fwdb(self.post_quant_conv, h))
+        h = run(_conv_fwdb(self.conv_in, h))
+        h = run(self.mid.block_1.fwdb(h))
+        if not isinstance(self.mid.attn_1, nn.Identity):
+            h = run(self.mid.attn_1.fwdb(h))
+        h = run(self.mid.block_2.fwdb(h))
+        for level in range(self.num_resolutions - 1, -1, -1):
+            stage = self.up[level]
+            for i, block in enumerate(stage.block):
+                h = run(block.fwdb(h))
+                if len(stage.attn) > 0:
+                    h = run(stage.attn[i].fwdb(h))
+            if level > 0:
+                h = run(stage.upsample.fwdb(h))
+        no = self.norm_out
+        hn, b_no = ops.groupnorm_fwd(h, no.weight, no.bias, no.num_groups, no.eps, True)
+        out, b_out = self.conv_out.fwd(hn)
+
+        def bwd(dout: Tensor) -> Tensor:
+            dh = b_no(b_out(dout)[0].t)
+            for b in reversed(tape):
+                dh = b(dh)
+            tape.clear()
+            return dh
+
+        return out, bwd
 
     @torch.no_grad()
     def forward(self, z: Tensor, cat_zero: bool = False, **kwargs):

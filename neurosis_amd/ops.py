@@ -604,6 +604,37 @@ def attention_unfused(q: Tensor, k: Tensor, v: Tensor, B: int) -> Tensor:
     return out
 
 
+def attention_unfused_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
+    """attention_unfused with a backward (the VAE mid block when the autoencoder is trained).  The probabilities are kept
+    ([B, L, L] bf16: 2 MB per sample at the 256^2 training resolution).  bwd(do) -> (dq, dk, dv), dense [B*L, D]."""
+    L, D = q.shape[0] // B, q.shape[1]
+    scale = float(D) ** -0.5
+    out = torch.empty_like(q)
+    probs = torch.empty(B, L, L, dtype=BF16, device=q.device)
+    for b in range(B):
+        sl = slice(b * L, (b + 1) * L)
+        gemm_nt(q[sl], k[sl], alpha=scale, out=probs[b])
+        call("nk_softmax_rows", probs[b].data_ptr(), L, L, _stream())
+        gemm_nn(probs[b], v[sl], out=out[sl])
+
+    def bwd(do: Tensor):
+        _check2d(do, "do")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        acc32 = torch.empty(L, D, dtype=torch.float32, device=q.device)
+        for b in range(B):
+            sl = slice(b * L, (b + 1) * L)
+            dp = gemm_nt(do[sl], v[sl])                                    # dP = dO V^T
+            gemm_tn_f32(probs[b], do[sl], acc32, False)                    # dV = P^T dO
+            dv[sl].copy_(cast_bf16(acc32))
+            call("nk_softmax_rows_bwd", probs[b].data_ptr(), dp.data_ptr(), L, L, scale, _stream())    # dP -> dS (scaled)
+            gemm_nn(dp, k[sl], out=dq[sl])                                 # dQ = dS K
+            gemm_tn_f32(dp, q[sl], acc32, False)                           # dK = dS^T Q
+            dk[sl].copy_(cast_bf16(acc32))
+        return dq, dk, dv
+
+    return out, bwd
+
+
 # ------------------------------------------------------------------------------------------------
 # misc
 # ------------------------------------------------------------------------------------------------

@@ -253,6 +253,37 @@ def vae_encode(sd: SD, dd: dict, x: Tensor) -> Tensor:
     return mean
 
 
+def vae_moments(sd: SD, dd: dict, x: Tensor) -> Tensor:
+    """Encoder.forward(x, regularize=False) incl. quant_conv: the [mean | logvar] moments (model.py:558-606)."""
+    ch_mult = list(dd["ch_mult"])
+    h = conv(sd, "conv_in", x)
+    for lvl in range(len(ch_mult)):
+        for ib in range(dd["num_res_blocks"]):
+            h = vae_resnet(sd, f"down.{lvl}.block.{ib}", h)
+            if f"down.{lvl}.attn.{ib}.norm.weight" in sd:
+                h = vae_attn(sd, f"down.{lvl}.attn.{ib}", h)
+        if lvl != len(ch_mult) - 1:
+            h = conv(sd, f"down.{lvl}.downsample.conv", F.pad(h, (0, 1, 0, 1)), stride=2, padding=0)
+    h = vae_resnet(sd, "mid.block_2", vae_attn(sd, "mid.attn_1", vae_resnet(sd, "mid.block_1", h)))
+    h = conv(sd, "conv_out", F.silu(group_norm(sd, "norm_out", h, 1e-6)))
+    return conv(sd, "quant_conv", h, padding=0) if "quant_conv.weight" in sd else h
+
+
+def vae_reconstruction_loss(enc_sd: SD, dec_sd: SD, dd: dict, x: Tensor, noise: Tensor, kl_weight: float = 0.0):
+    """AutoencodingEngine.forward (models/autoencoder.py:222-225) with DiagonalGaussianRegularizer(sample=True)
+    (modules/regularizers.py:23-42, modules/distributions.py:28-60; the sample's noise injected) and the engine's simple-loss
+    branch (:247-256) with nn.MSELoss; `kl_weight` adds regularization_weights["kl_loss"] * kl_loss as
+    GeneralLPIPSWithDiscriminator does (discriminator_loss.py:283-286).  Returns (loss, moments, z, xrec, kl_loss)."""
+    moments = vae_moments(enc_sd, dd, x)
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    z = mean + torch.exp(0.5 * logvar) * noise
+    kl = 0.5 * torch.sum(mean ** 2 + torch.exp(logvar) - 1.0 - logvar, dim=[1, 2, 3])
+    kl_loss = kl.sum() / kl.shape[0]
+    xrec = vae_decode(dec_sd, dd, z)
+    return F.mse_loss(x, xrec) + kl_weight * kl_loss, moments, z, xrec, kl_loss
+
+
 def vae_decode(sd: SD, dd: dict, z: Tensor) -> Tensor:
     """Decoder.forward, modules/diffusion/model.py:707-765: post_quant_conv (standalone, :700-704) -> conv_in -> mid ->
     for level = L-1 .. 0: (num_res_blocks + 1) resnets (+ attn) then Upsample (nearest x2 + 3x3 conv, :44-62) except at

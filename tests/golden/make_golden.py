@@ -288,6 +288,53 @@ def decoder_case(nmodel):
     print("decoder: image", tuple(image.shape), float(image.abs().mean()))
 
 
+VAE_GRAD_KEYS = [
+    "encoder.conv_in.weight", "encoder.down.0.block.0.conv1.weight", "encoder.down.1.block.0.nin_shortcut.weight", "encoder.down.1.downsample.conv.weight",
+    "encoder.mid.attn_1.q.weight", "encoder.mid.attn_1.k.weight", "encoder.norm_out.weight", "encoder.conv_out.bias",
+    "encoder.quant_conv.weight", "decoder.post_quant_conv.weight", "decoder.conv_in.weight", "decoder.mid.attn_1.v.bias", "decoder.mid.block_2.norm2.bias",
+    "decoder.up.1.upsample.conv.weight", "decoder.up.1.block.0.nin_shortcut.weight", "decoder.up.0.block.2.conv2.weight", "decoder.norm_out.bias",
+    "decoder.conv_out.weight",
+]
+
+
+def vae_train_case(nmodel):
+    """One reconstruction training step's forward + backward of the autoencoder (AutoencodingEngine.forward, autoencoder.py:
+    222-225: encode -> DiagonalGaussianRegularizer(sample=True) -> decode; loss = mse(x, xrec) as the engine's simple-loss
+    branch, and a second case with a KL term as GeneralLPIPSWithDiscriminator's regularization_weights would add it)."""
+    from neurosis.modules.regularizers import DiagonalGaussianRegularizer
+
+    enc, dec = nmodel.Encoder(**VAE_TINY).train(), nmodel.Decoder(**VAE_TINY).train()
+    shapes = {f"encoder.{k}": list(v.shape) for k, v in enc.state_dict().items()}
+    shapes.update({f"decoder.{k}": list(v.shape) for k, v in dec.state_dict().items()})
+    sd = synth_state_dict(shapes)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")})
+    reg = DiagonalGaussianRegularizer(sample=True)
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    out = {"cfg": VAE_TINY, "x": x, "cases": {}}
+    for tag, kl_weight in (("rec_only", 0.0), ("rec_kl", 1e-2)):
+        for p in list(enc.parameters()) + list(dec.parameters()):
+            p.grad = None
+        torch.manual_seed(2718)
+        noise = torch.randn(2, 4, 8, 8)
+        torch.manual_seed(2718)                   # posterior.sample() draws torch.randn(mean.shape) from the global generator
+        moments = enc(x)
+        z, log = reg(moments)
+        xrec = dec(z)
+        loss = torch.nn.functional.mse_loss(x, xrec) + kl_weight * log["kl_loss"]
+        loss.backward()
+        named = {f"encoder.{k}": p for k, p in enc.named_parameters()}
+        named.update({f"decoder.{k}": p for k, p in dec.named_parameters()})
+        out["cases"][tag] = dict(kl_weight=kl_weight, noise=noise, moments=moments.detach(), z=z.detach(), xrec=xrec.detach(), loss=loss.detach(),
+                                 kl_loss=log["kl_loss"].detach(), grads={k: named[k].grad.clone() for k in VAE_GRAD_KEYS},
+                                 grad_norms={k: float(p.grad.norm()) for k, p in named.items()})
+        assert torch.allclose(z.detach(), moments[:, :4].detach() + torch.exp(0.5 * moments[:, 4:].detach().clamp(-30, 20)) * noise, atol=1e-6)
+        print(f"vae train {tag}: loss={float(loss):.5f} kl={float(log['kl_loss']):.3f}")
+    torch.save(out, HERE / "vae_train_tiny.pt")
+    (HERE / "vae_train_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
+
+
 def analytic_denoiser(x, sigma, c, *args, **kwargs):
     """A closed-form stand-in for denoiser(network, ...) so that sampler arithmetic can be pinned without a network:
     depends on x, on sigma and (through "vector") on the conditioning, so guidance has something to act on."""
@@ -553,7 +600,7 @@ def dataset_cases():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -574,3 +621,5 @@ if __name__ == "__main__":
         text_encoder_cases()
     if "dataset" in which:
         dataset_cases()
+    if "vae_train" in which:
+        vae_train_case(nmodel)
