@@ -159,6 +159,20 @@ int nk_colsum(const void* dy, float* out, float* ws, long M, int N, long ld, int
  * (AttnBlock of the VAE, modules/diffusion/model.py:144-222, when the autoencoder itself is trained: SURVEY 8(f) N2) */
 int nk_softmax_rows_bwd(const void* p, void* dp, long M, int L, float scale, void* stream);
 
+/* PatchGAN discriminator pieces (modules/losses/patchgan/model.py:21-95).  Tokens x[M][C] bf16, M = N*H*W.
+ * LeakyReLU: y = x >= 0 ? x : slope*x; the backward takes the OUTPUT y (same sign as x).
+ * BatchNorm2d in training mode with the following LeakyReLU fused (slope = 1: none): batch mean / biased variance per
+ * channel over all M rows, y = act((x - mean) * rstd * gamma + beta); running_mean / running_var (optional) updated with
+ * `momentum` and the unbiased variance, as nn.BatchNorm2d does.  backward: dgamma, dbeta (+= when accumulate) and dx.
+ * ws: nk_batchnorm_ws_floats(M, C) fp32 elements of scratch. */
+int nk_leaky_relu_fwd(const void* x, void* y, long n, float slope, void* stream);
+int nk_leaky_relu_bwd(const void* dy, const void* y, void* dx, long n, float slope, void* stream);
+long nk_batchnorm_ws_floats(long M, int C);
+int nk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean,
+                     float* running_var, float* ws, long M, int C, float eps, float momentum, float slope, void* stream);
+int nk_batchnorm_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd, void* dx,
+                     float* dgamma, float* dbeta, float* ws, long M, int C, float slope, int accumulate, void* stream);
+
 /* y = gelu(x) elementwise over n bf16 values (n % 8 == 0).  mode 0: exact, 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU in open_clip's
  * text tower, models/text_encoder/clip.py:333-343); mode 1: "quick_gelu" x * sigmoid(1.702 x) (HF CLIPTextModel of
  * openai/clip-vit-large-patch14, models/text_encoder/clip.py:49-56). */

@@ -1,0 +1,217 @@
+// PatchGAN discriminator pieces: BatchNorm2d in training mode with the LeakyReLU that always follows it
+// fused in, and a stand-alone LeakyReLU for the first layer (modules/losses/patchgan/model.py:21-95).
+//
+// Layout: channels-last bf16 tokens x[M][C], M = N*H*W.  Batch statistics are per CHANNEL over all M rows -- a column
+// reduction, done like the bias-gradient column sums: 16 row lanes x 16 chunk lanes per workgroup (a chunk = 8 channels =
+// 16 B), fp32 partials per 64-row slab, single-writer finalisation in a fixed order (bitwise reproducible).  All three passes
+// are HBM-bound: forward = 2 reads + 1 write of x, backward = 3 reads + 1 write.
+#include "nk_common.h"
+#include "../../include/neurosis_hip.h"
+
+#define BN_ROWS 64
+static int bn_slabs(long M) { return (int)((M + BN_ROWS - 1) / BN_ROWS); }
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// ---- LeakyReLU --------------------------------------------------------------------------------------
+__global__ void leaky_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8, float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(*(const uint4_t*)(x + i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = leaky(f[e], slope);
+    *(uint4_t*)(y + i * 8) = pack8(f);
+  }
+}
+// dx = dy where the OUTPUT is >= 0 (same sign as the input for slope > 0), else dy * slope
+__global__ void leaky_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, bf16_t* __restrict__ dx, long n8,
+                                 float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8], g[8];
+    unpack8(*(const uint4_t*)(y + i * 8), f);
+    unpack8(*(const uint4_t*)(dy + i * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = f[e] >= 0.f ? g[e] : g[e] * slope;
+    *(uint4_t*)(dx + i * 8) = pack8(g);
+  }
+}
+static int ew_grid(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
+}
+extern "C" int nk_leaky_relu_fwd(const void* x, void* y, long n, float slope, void* stream) {
+  NK_CHECK_ARG(x && y && n > 0 && (n & 7) == 0 && slope > 0.f);
+  hipLaunchKernelGGL(leaky_fwd_kernel, dim3(ew_grid(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n >> 3, slope);
+  return nk_check_launch("leaky_relu_fwd");
+}
+extern "C" int nk_leaky_relu_bwd(const void* dy, const void* y, void* dx, long n, float slope, void* stream) {
+  NK_CHECK_ARG(dy && y && dx && n > 0 && (n & 7) == 0 && slope > 0.f);
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(ew_grid(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)y,
+                     (bf16_t*)dx, n >> 3, slope);
+  return nk_check_launch("leaky_relu_bwd");
+}
+
+// ---- column partials: part[slab][2][C] = { sum_m a, sum_m a*b } over the slab's rows -----------------
+// MODE 0 (forward statistics):  a = x,               b = x
+// MODE 1 (backward sums):       a = g = dy * act'(y), b = xhat = (x - mean) * rstd     ->  { sum g, sum g*xhat }
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                         const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ part, long M, int C,
+                                                         float slope) {
+  __shared__ float ps[2][16][16 * 8 + 4];
+  const int tid = threadIdx.x, cx = tid & 15, ry = tid >> 4;
+  const int chunk = blockIdx.y * 16 + cx;
+  const bool cok = chunk < (C >> 3);
+  const long row_lo = (long)blockIdx.x * BN_ROWS;
+  float s0[8], s1[8], mu[8], rs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f, mu[e] = 0.f, rs[e] = 1.f;
+  if (cok) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mu[e] = mean[chunk * 8 + e], rs[e] = rstd[chunk * 8 + e];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long r = row_lo + ry + 16 * i;
+      if (r >= M) continue;
+      float a[8], b[8];
+      unpack8(*(const uint4_t*)(x + r * C + chunk * 8), b);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[e] += b[e], s1[e] += b[e] * b[e];
+      } else {
+        float o[8];
+        unpack8(*(const uint4_t*)(dy + r * C + chunk * 8), a);
+        if (slope != 1.f) {
+          unpack8(*(const uint4_t*)(y + r * C + chunk * 8), o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = o[e] >= 0.f ? a[e] : a[e] * slope;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[e] += a[e], s1[e] += a[e] * (b[e] - mu[e]) * rs[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ps[0][ry][cx * 8 + e] = s0[e], ps[1][ry][cx * 8 + e] = s1[e];
+  __syncthreads();
+  const int which = tid >> 7, col = tid & 127;
+  const int c = blockIdx.y * 128 + col;
+  if (c < C) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += ps[which][r][col];
+    part[((long)blockIdx.x * 2 + which) * C + c] = a;
+  }
+}
+
+// forward finalisation: mean, rstd (biased variance), running statistics (unbiased variance, momentum) -- one thread per channel
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int slabs, int C, long M, float eps, float momentum,
+                                         float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < slabs; ++i) s += part[((long)i * 2) * C + c], q += part[((long)i * 2 + 1) * C + c];
+  const float m = s / (float)M;
+  const float var = fmaxf(q / (float)M - m * m, 0.f);
+  mean[c] = m;
+  rstd[c] = rsqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+// backward finalisation: dgamma = sum g*xhat, dbeta = sum g (kept in sums[2][C] for the dx pass, written / added to the grads)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int slabs, int C, float* __restrict__ sums,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, q = 0.f;
+  for (int i = 0; i < slabs; ++i) s += part[((long)i * 2) * C + c], q += part[((long)i * 2 + 1) * C + c];
+  sums[c] = s;
+  sums[C + c] = q;
+  dbeta[c] = accumulate ? dbeta[c] + s : s;
+  dgamma[c] = accumulate ? dgamma[c] + q : q;
+}
+
+// y = act((x - mean) * rstd * gamma + beta)
+__global__ void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ y, long M, int C,
+                                float slope) {
+  const int chunks = C >> 3;
+  const long total = M * chunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks) * 8;
+    float f[8];
+    unpack8(*(const uint4_t*)(x + i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = leaky((f[e] - mean[ch + e]) * rstd[ch + e] * gamma[ch + e] + beta[ch + e], slope);
+    *(uint4_t*)(y + i * 8) = pack8(f);
+  }
+}
+// dx = gamma * rstd * (g - sum_g / M - xhat * sum_gx / M),  g = dy * act'(y)
+__global__ void bn_bwd_dx_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                 const float* __restrict__ sums, bf16_t* __restrict__ dx, long M, int C, float slope) {
+  const int chunks = C >> 3;
+  const long total = M * chunks;
+  const float inv_m = 1.f / (float)M;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks) * 8;
+    float g[8], v[8], o[8];
+    unpack8(*(const uint4_t*)(dy + i * 8), g);
+    unpack8(*(const uint4_t*)(x + i * 8), v);
+    if (slope != 1.f) {
+      unpack8(*(const uint4_t*)(y + i * 8), o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = o[e] >= 0.f ? g[e] : g[e] * slope;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xhat = (v[e] - mean[ch + e]) * rstd[ch + e];
+      g[e] = gamma[ch + e] * rstd[ch + e] * (g[e] - sums[ch + e] * inv_m - xhat * sums[C + ch + e] * inv_m);
+    }
+    *(uint4_t*)(dx + i * 8) = pack8(g);
+  }
+}
+
+extern "C" long nk_batchnorm_ws_floats(long M, int C) { return (long)bn_slabs(M) * 2 * C + 2 * (long)C + 64; }
+
+extern "C" int nk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                float* running_mean, float* running_var, float* ws, long M, int C, float eps, float momentum,
+                                float slope, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(x && gamma && beta && y && mean && rstd && ws && M > 0 && C > 0 && (C & 7) == 0 && slope > 0.f);
+  NK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  const int slabs = bn_slabs(M);
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(slabs, (C + 127) / 128), dim3(256), 0, stream, (const bf16_t*)x, nullptr, nullptr, nullptr,
+                     nullptr, ws, M, C, 1.f);
+  if (int e = nk_check_launch("bn_partial<0>")) return e;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, slabs, C, M, eps, momentum, mean, rstd,
+                     running_mean, running_var);
+  if (int e = nk_check_launch("bn_stats_finalize")) return e;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, stream, (const bf16_t*)x, mean, rstd, gamma, beta,
+                     (bf16_t*)y, M, C, slope);
+  return nk_check_launch("bn_apply");
+}
+
+extern "C" int nk_batchnorm_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
+                                const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, long M, int C, float slope,
+                                int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(dy && x && y && gamma && mean && rstd && dx && dgamma && dbeta && ws && M > 0 && C > 0 && (C & 7) == 0 && slope > 0.f);
+  const int slabs = bn_slabs(M);
+  float* sums = ws + (long)slabs * 2 * C;
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(slabs, (C + 127) / 128), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
+                     (const bf16_t*)y, mean, rstd, ws, M, C, slope);
+  if (int e = nk_check_launch("bn_partial<1>")) return e;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, slabs, C, sums, dgamma, dbeta, accumulate);
+  if (int e = nk_check_launch("bn_bwd_finalize")) return e;
+  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)y, mean, rstd, gamma, sums, (bf16_t*)dx, M, C, slope);
+  return nk_check_launch("bn_bwd_dx");
+}

@@ -55,6 +55,10 @@ SIGNATURES: dict[str, list] = {
     "nk_geglu_bwd": [vp, vp, vp, i64, i32, vp],
     "nk_silu_fwd": [vp, vp, i64, vp],
     "nk_gelu_fwd": [vp, vp, i64, i32, vp],
+    "nk_leaky_relu_fwd": [vp, vp, i64, f32, vp],
+    "nk_leaky_relu_bwd": [vp, vp, vp, i64, f32, vp],
+    "nk_batchnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, vp],
+    "nk_batchnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
     "nk_silu_bwd": [vp, vp, vp, i64, vp],
     "nk_add": [vp, vp, vp, i64, vp],
     "nk_cat_channels": [vp, vp, vp, i64, i32, i32, vp],
@@ -82,6 +86,7 @@ SIZE_QUERIES: dict[str, list] = {
     "nk_groupnorm_ws_floats": [i32, i32, i32, i32],
     "nk_layernorm_ws_floats": [i32, i32],
     "nk_colsum_ws_floats": [i64, i32],
+    "nk_batchnorm_ws_floats": [i64, i32],
     "nk_attention_bwd_ws_floats": [adp],
     "nk_adafactor_tensor_bytes": [],
     "nk_gemm_sk_status": [],

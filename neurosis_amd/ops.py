@@ -524,6 +524,44 @@ def gelu(x: Tensor, quick: bool = False) -> Tensor:
     return y
 
 
+def leaky_relu_fwd(x: Tensor, slope: float = 0.2):
+    """(y, bwd); bwd(dy) -> dx"""
+    y = torch.empty_like(x)
+    call("nk_leaky_relu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), float(slope), _stream())
+
+    def bwd(dy: Tensor) -> Tensor:
+        dx = torch.empty_like(dy)
+        call("nk_leaky_relu_bwd", dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), float(slope), _stream())
+        return dx
+
+    return y, bwd
+
+
+def batchnorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], eps: float = 1e-5,
+                  momentum: float = 0.1, slope: float = 1.0):
+    """nn.BatchNorm2d in training mode on a token matrix [N*H*W, C] (batch statistics per channel), with the LeakyReLU that follows
+    it in the PatchGAN fused in (slope 1.0 = none).  Updates the running statistics in place.  bwd(dy) -> dx."""
+    _check2d(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("batchnorm: x must be dense")
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    nws = query("nk_batchnorm_ws_floats", M, Cc)
+    call("nk_batchnorm_fwd", x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(running_mean),
+         _p(running_var), _ws(nws, x.device).data_ptr(), M, Cc, float(eps), float(momentum), float(slope), _stream())
+
+    def bwd(dy: Tensor) -> Tensor:
+        dx = torch.empty_like(x)
+        call("nk_batchnorm_bwd", dy.data_ptr(), x.data_ptr(), y.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+             grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), _ws(nws, x.device).data_ptr(), M, Cc, float(slope), int(state.grad_accumulate),
+             _stream())
+        return dx
+
+    return y, bwd
+
+
 def silu_fwd(x: Tensor):
     y = torch.empty_like(x)
     call("nk_silu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), _stream())

@@ -1,0 +1,43 @@
+"""CPU oracle for the PatchGAN discriminator and its losses -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Functional fp32 restatement of `NLayerDiscriminator.forward` in training mode (modules/losses/patchgan/model.py:21-95; paths
+relative to /root/reference/src/neurosis/) over a state_dict with the reference's keys, and of the hinge / vanilla
+discriminator losses (modules/losses/functions.py:21-50).  Gradients come from torch autograd.  Pinned by
+tests/golden/patchgan_tiny.pt (tests/golden/make_golden.py::discriminator_case)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+def discriminator(sd: dict, x: Tensor, n_layers: int = 3, momentum: float = 0.1, eps: float = 1e-5, running: dict | None = None) -> Tensor:
+    """layers.0 conv(4x4, s2, p1)+bias -> LeakyReLU(0.2); for n = 1..n_layers: conv(4x4, stride 2 except the last, no bias) ->
+    BatchNorm2d (batch statistics; `running` receives the updated running_mean / running_var) -> LeakyReLU(0.2); final
+    conv(4x4, s1, p1)+bias to one channel."""
+    h = F.leaky_relu(F.conv2d(x, sd["layers.0.weight"], sd["layers.0.bias"], stride=2, padding=1), 0.2)
+    idx = 2
+    for n in range(1, n_layers + 1):
+        h = F.conv2d(h, sd[f"layers.{idx}.weight"], None, stride=2 if n < n_layers else 1, padding=1)
+        bn = f"layers.{idx + 1}"
+        mean = h.mean(dim=(0, 2, 3))
+        var = h.var(dim=(0, 2, 3), unbiased=False)
+        if running is not None:
+            count = h.numel() / h.shape[1]
+            src = running if bn + ".running_mean" in running else sd
+            running[bn + ".running_mean"] = (1 - momentum) * src[bn + ".running_mean"] + momentum * mean.detach()
+            running[bn + ".running_var"] = (1 - momentum) * src[bn + ".running_var"] + momentum * var.detach() * count / (count - 1)
+        h = (h - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + eps)
+        h = F.leaky_relu(h * sd[bn + ".weight"][None, :, None, None] + sd[bn + ".bias"][None, :, None, None], 0.2)
+        idx += 3
+    return F.conv2d(h, sd[f"layers.{idx}.weight"], sd[f"layers.{idx}.bias"], stride=1, padding=1)
+
+
+def disc_loss(kind: str, real: Tensor, fake: Tensor) -> Tensor:
+    if kind == "hinge":
+        return 0.5 * (F.relu(1.0 - real).mean() + F.relu(1.0 + fake).mean())
+    if kind == "vanilla":
+        return 0.5 * (F.softplus(-real).mean() + F.softplus(fake).mean())
+    raise ValueError(kind)

@@ -335,6 +335,61 @@ def vae_train_case(nmodel):
     (HERE / "vae_train_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
 
 
+DISC_TINY = dict(input_nc=3, ndf=8, n_layers=3)
+
+
+def disc_state_dict(shapes: dict) -> dict:
+    """synthetic discriminator weights: every float tensor from synth_tensor, BatchNorm running_var kept positive"""
+    sd = synth_state_dict({k: v for k, v in shapes.items() if not k.endswith("num_batches_tracked")})
+    for k in sd:
+        if k.endswith("running_var"):
+            sd[k] = sd[k].abs() + 0.5
+        elif k.replace(".weight", ".running_var") in sd and k.endswith(".weight"):
+            sd[k] = 1.0 + 0.1 * sd[k]          # BatchNorm scales near 1, as the reference's weights_init draws them (N(1, 0.02))
+    return sd
+
+
+def discriminator_case():
+    """The PatchGAN discriminator in training mode (modules/losses/patchgan/model.py) with the two discriminator losses
+    (modules/losses/functions.py:21-50) as GeneralLPIPSWithDiscriminator's optimizer_idx == 1 branch calls them
+    (discriminator_loss.py:303-320: D(real) then D(fake), both detached), and the generator's adversarial term
+    g_loss = -mean(D(fake)) (:268-270) with its gradient w.r.t. the fake image."""
+    from neurosis.modules.losses.functions import get_discr_loss_fn
+    from neurosis.modules.losses.patchgan.model import NLayerDiscriminator
+
+    disc = NLayerDiscriminator(**DISC_TINY).train()
+    shapes = {k: list(v.shape) for k, v in disc.state_dict().items()}
+    g = torch.Generator().manual_seed(404)
+    real = torch.rand(4, 3, 64, 64, generator=g) * 2 - 1
+    fake = (real + 0.3 * torch.randn(4, 3, 64, 64, generator=g)).clamp(-1, 1)
+    out = {"cfg": DISC_TINY, "real": real, "fake": fake, "cases": {}}
+    for kind in ("hinge", "vanilla"):
+        disc.load_state_dict(disc_state_dict(shapes), strict=False)
+        for b in disc.buffers():
+            if b.dtype == torch.int64:
+                b.zero_()
+        for p in disc.parameters():
+            p.grad = None
+        logits_real = disc(real)
+        logits_fake = disc(fake)
+        d_loss = get_discr_loss_fn(kind)(logits_real, logits_fake)
+        d_loss.backward()
+        grads = {k: p.grad.clone() for k, p in disc.named_parameters()}
+        buffers = {k: v.clone() for k, v in disc.state_dict().items() if "running" in k or "num_batches" in k}
+        out["cases"][kind] = dict(logits_real=logits_real.detach(), logits_fake=logits_fake.detach(), d_loss=d_loss.detach(), grads=grads, buffers=buffers)
+        print(f"discriminator {kind}: d_loss={float(d_loss.detach()):.5f} logits {tuple(logits_real.shape)}")
+    # generator side: gradient of -mean(D(fake)) w.r.t. the image (fresh buffers, as a generator step would see them)
+    disc.load_state_dict(disc_state_dict(shapes), strict=False)
+    for p in disc.parameters():
+        p.grad = None
+    img = fake.clone().requires_grad_(True)
+    g_loss = -disc(img).mean()
+    g_loss.backward()
+    out["generator"] = dict(g_loss=g_loss.detach(), d_image=img.grad.clone())
+    torch.save(out, HERE / "patchgan_tiny.pt")
+    (HERE / "patchgan_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
+
+
 def analytic_denoiser(x, sigma, c, *args, **kwargs):
     """A closed-form stand-in for denoiser(network, ...) so that sampler arithmetic can be pinned without a network:
     depends on x, on sigma and (through "vector") on the conditioning, so guidance has something to act on."""
@@ -600,7 +655,7 @@ def dataset_cases():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -623,3 +678,5 @@ if __name__ == "__main__":
         dataset_cases()
     if "vae_train" in which:
         vae_train_case(nmodel)
+    if "disc" in which:
+        discriminator_case()

@@ -170,6 +170,14 @@ def test_conv3x3_big_grid(ops):
     _conv_case(ops, 2, 256, 256, 64, 128, 3, 1, 1, rowvec=True, residual=True)
 
 
+def test_conv4x4_patchgan_shapes(ops):
+    # the PatchGAN discriminator's convolutions: 4x4 taps, stride 2 and stride 1, padding 1 (even kernel: asymmetric reach)
+    _conv_case(ops, 2, 32, 32, 8, 16, 4, 2, 1)
+    _conv_case(ops, 2, 16, 16, 64, 128, 4, 2, 1)
+    _conv_case(ops, 2, 8, 8, 32, 64, 4, 1, 1)
+    _conv_case(ops, 2, 7, 7, 64, 8, 4, 1, 1)
+
+
 def test_conv3x3_pad_channels(ops):
     # the 4-channel latent convs run with channels padded to 8 (zeros)
     _conv_case(ops, 2, 16, 16, 8, 320, 3, 1, 1)
