@@ -6,6 +6,7 @@ training step (row N2) is not built.
 """
 from __future__ import annotations
 
+import math
 from typing import Optional
 
 import torch
@@ -124,9 +125,22 @@ class AutoencodingEngine(nn.Module):
     live in one FlatParamStore across encoder and decoder."""
 
     def __init__(self, *, encoder: Encoder, decoder: Decoder, loss="l2", regularizer: Optional[nn.Module] = None, input_key: str = "image",
-                 regularization_weights: Optional[dict] = None, **kwargs):
+                 regularization_weights: Optional[dict] = None, discriminator: Optional[nn.Module] = None, disc_loss: str = "hinge", disc_start: int = 0,
+                 disc_factor: float = 1.0, disc_weight: float = 1.0, rec_weight: float = 1.0, logvar_init: float = 0.0, learn_logvar: bool = False,
+                 **kwargs):
         super().__init__()
         self.encoder, self.decoder = encoder, decoder
+        # adversarial part (GeneralLPIPSWithDiscriminator's arguments, discriminator_loss.py:23-40, with perceptual_weight = 0)
+        self.discriminator = discriminator
+        if discriminator is not None:
+            from ..modules.losses import get_discr_loss_fn
+
+            if learn_logvar:
+                raise NotImplementedError("learn_logvar is not built (the reference's default is a fixed logvar)")
+            self.disc_loss = get_discr_loss_fn(disc_loss)
+        self.disc_start, self.disc_factor, self.discriminator_weight = disc_start, disc_factor, disc_weight
+        self.rec_weight, self.logvar = rec_weight, float(logvar_init)
+        self.disc_store: Optional[FlatParamStore] = None
         self.regularization = regularizer if regularizer is not None else DiagonalGaussianRegularizer()
         if isinstance(loss, nn.MSELoss) or loss in ("l2", "mse"):
             self.rec_loss_type = "l2"
@@ -171,6 +185,8 @@ class AutoencodingEngine(nn.Module):
     # -- training ----------------------------------------------------------------------------------
     def setup_flat_params(self) -> FlatParamStore:
         self.store = FlatParamStore(self.get_autoencoder_params())
+        if self.discriminator is not None:
+            self.disc_store = FlatParamStore(list(self.discriminator.parameters()))
         ops.state.assume_zeroed = False
         if ops.state.wgrad_stream is None:
             ops.state.wgrad_stream = torch.cuda.Stream()
@@ -191,7 +207,11 @@ class AutoencodingEngine(nn.Module):
         out_img, b_dec = self.decoder.fwdb(Img(ops.nchw_to_tokens(z.contiguous(), (zc + 7) // 8 * 8), B, z.shape[2], z.shape[3]))
         xrec = ops.tokens_to_nchw(out_img.t, B, C, out_img.H, out_img.W, dtype=torch.float32)
         dev = x.device
-        if self.rec_loss_type == "l2":
+        adversarial = self.discriminator is not None
+        log = {}
+        if adversarial:
+            loss, d_out, log = self._generator_loss(x, xrec, out_img, b_dec)
+        elif self.rec_loss_type == "l2":
             # mean((xrec - x)^2) over everything = sum_b (1/B) * mean_chw: the edm loss kernel with c_out = 1, c_skip = 0, w = 1/B
             one, zero = torch.ones(B, device=dev), torch.zeros(B, device=dev)
             weight = torch.full((B,), 1.0 / B, device=dev)
@@ -199,27 +219,101 @@ class AutoencodingEngine(nn.Module):
             d_out = torch.empty_like(out_img.t)
             call("nk_edm_loss", out_img.t.data_ptr(), x.data_ptr(), x.data_ptr(), one.data_ptr(), zero.data_ptr(), weight.data_ptr(), per_sample.data_ptr(),
                  d_out.data_ptr(), B, C, H * W, out_img.C, 1.0, ops._stream())
-            rec = per_sample.sum()
+            loss = per_sample.sum()
         else:
             diff = xrec - x
-            rec = diff.abs().mean()
+            loss = diff.abs().mean()
             d_out = ops.nchw_to_tokens((torch.sign(diff) / diff.numel()).contiguous(), out_img.C)
-        loss = rec
         for key, w in self.regularization_weights.items():
             loss = loss + w * reg_log[key]
+        reg_log = {**reg_log, **log}
         dz = ops.tokens_to_nchw(b_dec(d_out), B, zc, z.shape[2], z.shape[3], dtype=torch.float32)
         d_moments = b_reg(dz, float(self.regularization_weights.get("kl_loss", 0.0)))
         b_enc(ops.nchw_to_tokens(d_moments.contiguous(), moments_img.C))
         ops.join_wgrad_stream()
         return loss, z, xrec, reg_log
 
+    def _generator_loss(self, x: torch.Tensor, xrec: torch.Tensor, out_img: Img, b_dec):
+        """The autoencoder's side of the adversarial loss with perceptual_weight = 0:
+            nll   = sum(rec_weight * rec(x, xrec) / exp(logvar) + logvar) / B                  (get_nll_loss, :219-233)
+            g     = -mean(D(xrec))                                                             (:268-270)
+            d_w   = clamp(||d nll / dW|| / (||d g / dW|| + 1e-4), 0, 1e4) * disc_weight         W = decoder.conv_out.weight (:205-217)
+            loss  = nll + disc_factor * d_w * g          (0 adversarial weight before disc_start)
+        The reference's forward for this branch does not run as written (it evaluates `weights > 0` with weights = None, and
+        sums the un-reduced p_rec_loss tensor into a loss that is then passed to backward()); this is the formula its terms
+        spell out -- the one of the taming-transformers / generative-models loss it was reworked from.
+        Returns (loss, d loss / d decoder-output tokens, log)."""
+        B, C, H, W = x.shape
+        diff = xrec - x
+        rec = diff * diff if self.rec_loss_type == "l2" else diff.abs()
+        inv_var = math.exp(-self.logvar)
+        nll = (rec * (self.rec_weight * inv_var) + self.logvar).sum() / B
+        d_nll = (2.0 * diff if self.rec_loss_type == "l2" else torch.sign(diff)) * (self.rec_weight * inv_var / B)
+        d_nll_tok = ops.nchw_to_tokens(d_nll.contiguous(), out_img.C)
+        active = self.global_step >= self.disc_start
+        log = {"nll_loss": nll.detach()}
+        if not active:
+            log.update(g_loss=torch.zeros((), device=x.device), d_weight=torch.zeros((), device=x.device))
+            return nll, d_nll_tok, log
+        logits, b_disc = self.discriminator.fwdb(out_img)
+        vals = ops.tokens_to_nchw(logits.t, B, 1, logits.H, logits.W, dtype=torch.float32)
+        g_loss = -vals.mean()
+        d_logits = torch.full_like(vals, -1.0 / vals.numel())
+        d_g_tok = b_disc(ops.nchw_to_tokens(d_logits, logits.C))       # also writes the discriminator's weight gradients: unused here,
+        ops.join_wgrad_stream()                                          # overwritten by its own step
+        d_weight = (b_dec.last_layer_grad_norm(d_nll_tok) / (b_dec.last_layer_grad_norm(d_g_tok) + 1e-4)).clamp(0.0, 1e4) * self.discriminator_weight
+        factor = d_weight * self.disc_factor
+        log.update(g_loss=g_loss.detach(), d_weight=d_weight.detach())
+        return nll + factor * g_loss, ops.add(d_nll_tok, ops.cast_bf16((d_g_tok.float() * factor).contiguous())), log
+
+    @torch.no_grad()
+    def discriminator_step_loss(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        """optimizer_idx == 1 of the reference's loss (discriminator_loss.py:303-320): d_loss = disc_factor * disc_loss(D(x), D(xrec))
+        with the reconstruction detached; forward + backward into the discriminator's gradients.  Returns (d_loss, log)."""
+        B, C, H, W = x.shape
+        x = x.float().contiguous()
+        _, xrec, _ = self._reconstruct(x, noise)
+        cpad = (C + 7) // 8 * 8
+        lr_img, b_real = self.discriminator.fwdb(Img(ops.nchw_to_tokens(x, cpad), B, H, W), need_dx=False)
+        lf_img, b_fake = self.discriminator.fwdb(Img(ops.nchw_to_tokens(xrec.contiguous(), cpad), B, H, W), need_dx=False)
+        real = ops.tokens_to_nchw(lr_img.t, B, 1, lr_img.H, lr_img.W, dtype=torch.float32)
+        fake = ops.tokens_to_nchw(lf_img.t, B, 1, lf_img.H, lf_img.W, dtype=torch.float32)
+        log = {"logits_real": real.mean(), "logits_fake": fake.mean()}
+        if self.global_step < self.disc_start:
+            return torch.zeros((), device=x.device), log
+        loss, d_real, d_fake = self.disc_loss.with_grad(real, fake)
+        ops.state.grad_accumulate = False
+        b_real(ops.nchw_to_tokens((d_real * self.disc_factor).contiguous(), lr_img.C))
+        ops.state.grad_accumulate = True            # the fake pass adds to the real pass's weight gradients
+        try:
+            b_fake(ops.nchw_to_tokens((d_fake * self.disc_factor).contiguous(), lf_img.C))
+        finally:
+            ops.state.grad_accumulate = False
+        ops.join_wgrad_stream()
+        return loss * self.disc_factor, log
+
+    def _reconstruct(self, x: torch.Tensor, noise: Optional[torch.Tensor]):
+        """forward only: (z, xrec, reg_log) with the posterior sampled (or `noise` injected)"""
+        moments = self.encoder(x)
+        z, reg_log, _ = self.regularization.regularize(moments, noise)
+        return z, self.decoder(z), reg_log
+
     def training_step(self, batch: dict, batch_idx: int = 0, lr: float = 4.5e-6, betas=(0.5, 0.9), weight_decay: float = 0.0, noise=None) -> torch.Tensor:
-        """autoencoder.py:280-293 with one optimizer (no discriminator): gradients are overwritten by the backward, then one
-        fused AdamW step over the flat buffers."""
+        """autoencoder.py:280-293: with a discriminator the two optimizers alternate by batch index (the autoencoder's until
+        disc_start); gradients are overwritten by each backward, then one fused AdamW step over that optimizer's flat buffers."""
         if self.store is None:
             raise RuntimeError("call setup_flat_params() first")
-        loss, _, _, reg_log = self.loss_and_backward(self.get_input(batch), noise)
-        self.store.adamw_step(lr, betas, 1e-8, weight_decay)
+        n_opts = 2 if self.discriminator is not None else 1
+        optimizer_idx = batch_idx % n_opts if self.global_step >= self.disc_start else 0
+        x = self.get_input(batch)
+        if optimizer_idx == 0:
+            loss, _, _, log = self.loss_and_backward(x, noise)
+            self.store.adamw_step(lr, betas, 1e-8, weight_decay)
+            self.last_log = {"train/loss/rec": loss.detach(), **{f"train/{k}": v.detach() for k, v in log.items()}}
+        else:
+            loss, log = self.discriminator_step_loss(x, noise)
+            if self.global_step >= self.disc_start:
+                self.disc_store.adamw_step(lr, betas, 1e-8, weight_decay)
+            self.last_log = {"train/loss/disc": loss.detach(), **{f"train/{k}": v.detach() for k, v in log.items()}}
         self.global_step += 1
-        self.last_log = {"train/loss/rec": loss.detach(), **{f"train/{k}": v.detach() for k, v in reg_log.items()}}
         return loss

@@ -416,6 +416,15 @@ class Decoder(nn.Module):
             tape.clear()
             return dh
 
+        def last_layer_grad_norm(dout: Tensor) -> Tensor:
+            """|| d<dout, image> / d conv_out.weight ||  (device scalar): the quantity the adversarial loss balances its two
+            terms with (GeneralLPIPSWithDiscriminator.calculate_adaptive_weight, discriminator_loss.py:205-217).  Runs only the
+            last convolution's weight-gradient kernel; call before `bwd`, which overwrites the gradient."""
+            b_out(dout)
+            ops.join_wgrad_stream()
+            return self.conv_out.weight.grad.float().norm()
+
+        bwd.last_layer_grad_norm = last_layer_grad_norm
         return out, bwd
 
     @torch.no_grad()

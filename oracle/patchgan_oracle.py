@@ -41,3 +41,28 @@ def disc_loss(kind: str, real: Tensor, fake: Tensor) -> Tensor:
     if kind == "vanilla":
         return 0.5 * (F.softplus(-real).mean() + F.softplus(fake).mean())
     raise ValueError(kind)
+
+
+def generator_adversarial_loss(enc_sd: dict, dec_sd: dict, disc_sd: dict, dd: dict, x: Tensor, noise: Tensor, rec_weight: float = 1.0, logvar: float = 0.0,
+                               disc_factor: float = 1.0, disc_weight: float = 1.0, n_layers: int = 3):
+    """The autoencoder's side of GeneralLPIPSWithDiscriminator with perceptual_weight = 0 (discriminator_loss.py:205-233,
+    247-286), as its terms spell it out -- NOTE: the reference's own forward raises for this branch (`weights > 0` with
+    weights = None at :298, and the loss it builds at :276 is an un-reduced tensor), so this half is NOT pinned by reference
+    fixtures; it follows the taming-transformers / generative-models formula the reference was reworked from:
+        nll = sum(rec_weight * (x - xrec)^2 / exp(logvar) + logvar) / B ;  g = -mean(D(xrec))
+        d_w = clamp(||grad_W nll|| / (||grad_W g|| + 1e-4), 0, 1e4) * disc_weight,  W = decoder.conv_out.weight
+        loss = nll + disc_factor * d_w * g
+    `dec_sd` tensors must require grad.  Returns (loss, nll, g, d_w, xrec)."""
+    from oracle import sdxl_oracle as O
+
+    moments = O.vae_moments(enc_sd, dd, x)
+    mean, lv = torch.chunk(moments, 2, dim=1)
+    z = mean + torch.exp(0.5 * lv.clamp(-30.0, 20.0)) * noise
+    xrec = O.vae_decode(dec_sd, dd, z)
+    nll = ((x - xrec) ** 2 * (rec_weight / float(torch.exp(torch.tensor(logvar)))) + logvar).sum() / x.shape[0]
+    g = -discriminator(disc_sd, xrec, n_layers).mean()
+    last = dec_sd["conv_out.weight"]
+    nll_grad = torch.autograd.grad(nll, last, retain_graph=True)[0]
+    g_grad = torch.autograd.grad(g, last, retain_graph=True)[0]
+    d_w = (nll_grad.norm() / (g_grad.norm() + 1e-4)).clamp(0.0, 1e4).detach() * disc_weight
+    return nll + disc_factor * d_w * g, nll, g, d_w, xrec
