@@ -62,10 +62,35 @@ class VPreconditioning(DenoiserPreconditioning):
 class EDMPreconditioning(DenoiserPreconditioning):
     """Karras et al. 2022, table 1 (reference :60-77)."""
 
-    def __init__(self, sigma_data: float = 0.5):
+    def __init__(self, sigma_data: float = 1.0):
         self.sigma_data = sigma_data
 
     def scalings(self, sigma: Tensor) -> Scalings:
         var = self.sigma_data ** 2
         inv = _inv_norm(sigma, var)
         return var / (sigma.square() + var), sigma * self.sigma_data * inv, inv, sigma.log() * 0.25
+
+
+class VPreconditioningWithEDMcNoise(VPreconditioning):
+    """v-prediction with the EDM noise conditioning c_noise = ln(sigma) / 4 (reference :55-57)."""
+
+    def scalings(self, sigma: Tensor) -> Scalings:
+        c_skip, c_out, c_in, _ = super().scalings(sigma)
+        return c_skip, c_out, c_in, sigma.log() * 0.25
+
+
+class RectifiedFlowXLPreconditioning(DenoiserPreconditioning):
+    """Rectified flow in the sigma = t / (1 - t) parametrisation (reference :77-90): the input is rescaled to unit variance
+    for the interpolant (1 - t) x + t eps, the network is conditioned on 1000 t."""
+
+    def scalings(self, sigma: Tensor) -> Scalings:
+        t = sigma / (1.0 + sigma)
+        signal = 1.0 / (1.0 + sigma)
+        return torch.ones_like(sigma), sigma.neg(), signal / (signal**2.0 + t**2.0) ** 0.5, 1000.0 * t
+
+
+class RectifiedFlowComfyPreconditioning(DenoiserPreconditioning):
+    """Rectified flow with sigma = t itself (reference :93-105)."""
+
+    def scalings(self, sigma: Tensor) -> Scalings:
+        return torch.ones_like(sigma), sigma.neg(), (sigma**2.0 + (1.0 - sigma) ** 2.0) ** -0.5, 1000.0 * sigma

@@ -63,3 +63,63 @@ class LegacyDDPMDiscretization(Discretization):
             abar = abar[generate_roughly_equally_spaced_steps(n, self.num_timesteps).copy()]
         table = ((1 - abar) / abar) ** 0.5
         return table.flip(0).to(device, dtype=torch.float32)
+
+
+class EDMcSimpleDiscretization(Discretization):
+    """n levels picked at equal strides from the top of a fixed num_sigmas-entry log-uniform table, then a literal 0.0
+    (reference :60-83; the base class appends ANOTHER zero, as there)."""
+
+    def __init__(self, sigma_min: float = 0.001, sigma_max: float = 1000.0, num_sigmas: int = 1000):
+        super().__init__()
+        self.sigma_min, self.sigma_max, self.num_sigmas = sigma_min, sigma_max, num_sigmas
+
+    def get_sigmas(self, n: int, device="cpu") -> Tensor:
+        table = torch.linspace(math.log(self.sigma_min), math.log(self.sigma_max), self.num_sigmas, dtype=torch.float32).exp()
+        stride = len(table) / n
+        picked = [float(table[-(1 + int(i * stride))]) for i in range(n)]
+        return torch.tensor(picked + [0.0]).to(device)
+
+
+class RectifiedFlowDiscretization(Discretization):
+    """t uniform in [start_shift, 1 - end_shift], sigma = t / (1 - t), descending (reference :86-95)"""
+
+    as_ratio = True
+
+    def __init__(self, start_shift: float = 0.0, end_shift: float = 0.001, do_append_zero: bool = False):
+        super().__init__(do_append_zero=do_append_zero)
+        self.start_shift, self.end_shift = start_shift, end_shift
+
+    def get_sigmas(self, n: int, device="cpu") -> Tensor:
+        t = torch.linspace(self.start_shift, 1 - self.end_shift, n, dtype=torch.float64)
+        return (t / (1.0 - t) if self.as_ratio else t).flip(0).to(device, dtype=torch.float32)
+
+
+class RectifiedFlowComfyDiscretization(RectifiedFlowDiscretization):
+    """sigma = t (reference :98-106)"""
+
+    as_ratio = False
+
+
+class TanZeroSNRDiscretization(Discretization):
+    """sigma = scale * tan(angle), angle uniform in [start_shift, pi/2 - end_shift] (fp64), descending (reference :109-124)"""
+
+    def __init__(self, start_shift: float = 0.001, end_shift: float = 0.001, scale: float = 1.0):
+        super().__init__()
+        self.start_shift, self.end_shift, self.scale = start_shift, end_shift, scale
+
+    def get_sigmas(self, n: int, device="cpu") -> Tensor:
+        half_pi = torch.acos(torch.zeros(1, dtype=torch.float64))[0]
+        angles = torch.linspace(self.start_shift, half_pi - self.end_shift, n, dtype=torch.float64)
+        return torch.tan(angles).mul(self.scale).flip(0).to(device, dtype=torch.float32)
+
+
+class EDMDiscretization(Discretization):
+    """Karras et al. (2022) eq. 5, sigma_max first (reference :127-146)"""
+
+    def __init__(self, sigma_min: float = 0.002, sigma_max: float = 80.0, rho: float = 7.0):
+        super().__init__()
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+
+    def get_sigmas(self, n: int, device="cpu") -> Tensor:
+        hi, lo = self.sigma_max ** (1 / self.rho), self.sigma_min ** (1 / self.rho)
+        return (hi + torch.linspace(0, 1, n, device=device, dtype=torch.float32) * (lo - hi)) ** self.rho

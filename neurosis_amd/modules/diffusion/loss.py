@@ -1,9 +1,12 @@
 """StandardDiffusionLoss: mirror of neurosis.modules.diffusion.loss (loss.py:20-157).
 
-When the network is an OpenAIWrapper around this package's UNetModel, the "edm" objective runs fused:
+When the network is an OpenAIWrapper around this package's UNetModel, the l2 loss runs fused for both objectives:
 noising + input scaling (nk_edm_prepare), the UNet as one explicit forward/backward chain of HIP kernels,
 and output scaling + per-sample weighted MSE + its gradient (nk_edm_loss) -- one autograd node for the whole
-loss.  Any other network takes the reference's generic (unfused) route through Denoiser.forward.
+loss.  "edm": z_t = x + sigma eps, target x, D = c_skip z_t + c_out F.  "rf" (rectified flow): z_t = (1 - sigma) x + sigma eps,
+target eps, the raw network output F (the same two kernels: the prepare kernel is handed (1 - sigma) x, the loss kernel
+c_out = 1, c_skip = 0 and the noise as target).  Any other network, and the l1 loss, take the reference's generic route
+through Denoiser.forward.
 """
 from __future__ import annotations
 
@@ -53,20 +56,20 @@ class StandardDiffusionLoss(DiffusionLoss):
         self.loss_weighting = loss_weighting
         self.snr_gamma = snr_gamma
         self.objective_type = str(objective_type).lower()
-        lt = str(loss_type).lower()
-        if lt not in ("l2", "mse"):
-            raise NotImplementedError("only the L2 objective (configs' default) is on the MI355X path")
-        self.loss_type = "l2"
-        if self.objective_type != "edm":
-            raise NotImplementedError("only objective_type='edm' (the SD/SDXL configs) is on the MI355X path")
+        lt = {"mse": "l2", "mae": "l1"}.get(str(loss_type).lower(), str(loss_type).lower())
+        if lt not in ("l1", "l2"):
+            raise ValueError(f"Unknown loss type {loss_type}")
+        self.loss_type = lt
+        if self.objective_type not in ("edm", "rf"):
+            raise ValueError(f"Unknown objective type: '{objective_type}'")
         if not isinstance(input_keys, list):
             input_keys = [input_keys]
         self.input_keys = set(input_keys)
 
     # -- fused HIP route ---------------------------------------------------------------------------
     @staticmethod
-    def fused_edm(unet: UNetModel, denoiser: Denoiser, weighting, inputs: Tensor, sigmas: Tensor, noise: Tensor, cond: dict):
-        """loss[B] (fp32) for the edm objective; differentiable w.r.t. the UNet parameters.
+    def fused_edm(unet: UNetModel, denoiser: Denoiser, weighting, inputs: Tensor, sigmas: Tensor, noise: Tensor, cond: dict, objective: str = "edm"):
+        """loss[B] (fp32) for the edm or rf objective with the l2 loss; differentiable w.r.t. the UNet parameters.
         inputs / noise: fp32 NCHW latents; sigmas: [B] fp32 on the same device."""
         B, Cc, H, W = inputs.shape
         dev = inputs.device
@@ -76,6 +79,12 @@ class StandardDiffusionLoss(DiffusionLoss):
         sig = sigmas.float().contiguous()
         x = inputs.float().contiguous()
         eps = noise.float().contiguous()
+        target = x
+        if objective == "rf":
+            # z_t = (1 - sigma) x + sigma eps; the network's raw output is compared with the noise
+            x = (x * (1.0 - sig).reshape(B, 1, 1, 1)).contiguous()
+            target = eps
+            c_out, c_skip = torch.ones_like(c_out), torch.zeros_like(c_skip)
         context, y = cond.get("crossattn", None), cond.get("vector", None)
         cpad = (Cc + 7) // 8 * 8
         params = [p for p in unet.parameters() if p.requires_grad]
@@ -86,7 +95,7 @@ class StandardDiffusionLoss(DiffusionLoss):
             call("nk_edm_prepare", x.data_ptr(), eps.data_ptr(), sig.data_ptr(), c_in.data_ptr(), zt.data_ptr(), net_in.data_ptr(), B, Cc, H * W, cpad, ops._stream())
             out, unet_bwd = unet.fwd(Img(net_in, B, H, W), c_noise, None if context is None else as_tokens(context), None if y is None else as_tokens(y))
             loss = torch.empty(B, dtype=torch.float32, device=dev)
-            call("nk_edm_loss", out.t.data_ptr(), zt.data_ptr(), x.data_ptr(), c_out.data_ptr(), c_skip.data_ptr(), w.data_ptr(), loss.data_ptr(), None,
+            call("nk_edm_loss", out.t.data_ptr(), zt.data_ptr(), target.data_ptr(), c_out.data_ptr(), c_skip.data_ptr(), w.data_ptr(), loss.data_ptr(), None,
                  B, Cc, H * W, out.C, 1.0, ops._stream())
 
             def bwd(dloss: Tensor):
@@ -94,7 +103,7 @@ class StandardDiffusionLoss(DiffusionLoss):
                 wg = (w * dloss.float()).contiguous()
                 dnet = torch.empty_like(out.t)
                 scratch = torch.empty(B, dtype=torch.float32, device=dev)
-                call("nk_edm_loss", out.t.data_ptr(), zt.data_ptr(), x.data_ptr(), c_out.data_ptr(), c_skip.data_ptr(), wg.data_ptr(), scratch.data_ptr(),
+                call("nk_edm_loss", out.t.data_ptr(), zt.data_ptr(), target.data_ptr(), c_out.data_ptr(), c_skip.data_ptr(), wg.data_ptr(), scratch.data_ptr(),
                      dnet.data_ptr(), B, Cc, H * W, out.C, 1.0, ops._stream())
                 unet_bwd(dnet)
                 return ()
@@ -116,18 +125,23 @@ class StandardDiffusionLoss(DiffusionLoss):
         if noise is None:
             noise = torch.randn_like(inputs)
         noise = self.apply_noise_offset(noise, inputs)
-        unet = network.fused_unet(inputs, cond, extra_inputs) if isinstance(network, OpenAIWrapper) else None
+        unet = network.fused_unet(inputs, cond, extra_inputs) if isinstance(network, OpenAIWrapper) and self.loss_type == "l2" else None
         if unet is not None:
-            loss = self.fused_edm(unet, denoiser, self.loss_weighting, inputs, sigmas, noise, cond)
+            loss = self.fused_edm(unet, denoiser, self.loss_weighting, inputs, sigmas, noise, cond, self.objective_type)
         else:
             sigmas_bc = append_dims(sigmas, inputs.ndim)
-            z_t = inputs + sigmas_bc * noise
-            d_out = denoiser(network, z_t, sigmas, cond, "D", **extra_inputs)
-            loss = self.get_loss(d_out, inputs, self.loss_weighting(sigmas))
+            if self.objective_type == "rf":
+                z_t = (1.0 - sigmas_bc) * inputs + sigmas_bc * noise
+                loss = self.get_loss(denoiser(network, z_t, sigmas, cond, "F", **extra_inputs), noise, self.loss_weighting(sigmas))
+            else:
+                z_t = inputs + sigmas_bc * noise
+                loss = self.get_loss(denoiser(network, z_t, sigmas, cond, "D", **extra_inputs), inputs, self.loss_weighting(sigmas))
         if return_dict:
             return loss, {"sigmas": sigmas, "t": t}
         return loss
 
     def get_loss(self, outputs: Tensor, target: Tensor, weight: Tensor) -> Tensor:
-        """loss.py:153-157 with BatchMSELoss (losses/functions.py:81-94): per-sample mean, then the weight."""
-        return ((outputs.float() - target.float()) ** 2).flatten(1).mean(1) * weight.float()
+        """loss.py:153-157 with BatchMSELoss / BatchL1Loss (losses/functions.py:65-94): per-sample mean, then the weight."""
+        diff = outputs.float() - target.float()
+        per_element = diff * diff if self.loss_type == "l2" else diff.abs()
+        return per_element.flatten(1).mean(1) * weight.float()

@@ -19,7 +19,7 @@ import torch
 from torch import Tensor
 
 from ...guidance import Guider, IdentityGuider
-from ..discretization import Discretization
+from ..discretization import Discretization, RectifiedFlowComfyDiscretization
 from .utils import _per_sample, get_ancestral_step, linear_multistep_coeff, to_d, to_neg_log_sigma, to_sigma
 
 logger = logging.getLogger(__name__)
@@ -41,7 +41,8 @@ class BaseDiffusionSampler:
         self.verbose = verbose
         self.device = torch.device(device)
         self.rf_safeguard = rf_safeguard
-        if rf_safeguard:
+        self._comfy_rf = isinstance(discretization, RectifiedFlowComfyDiscretization)
+        if rf_safeguard and not self._comfy_rf:
             logger.warning("RF safeguard is only available for ComfyRF! Continuing without it.")
         self._host_levels: Optional[tuple] = None     # (sigma_i, sigma_{i+1}) as floats while the driver loop runs
 
@@ -51,7 +52,8 @@ class BaseDiffusionSampler:
         if steps is None:
             raise ValueError(f"Step count must be set at init or call time! {self.num_steps=}")
         sigmas = self.discretization(steps)
-        x *= torch.sqrt(1.0 + sigmas[0] ** 2.0)       # unit-variance noise -> the variance of the first level (in place)
+        # unit-variance noise -> the scale of the first level, in place (rectified flow with sigma = t: x_t = (1 - t) x0 + t eps)
+        x *= sigmas[0] if self._comfy_rf else torch.sqrt(1.0 + sigmas[0] ** 2.0)
         return x, x.new_ones([x.shape[0]]), sigmas, len(sigmas), cond, cond if uc is None else uc
 
     def get_sigma_gen(self, num_sigmas: int):
@@ -68,7 +70,14 @@ class BaseDiffusionSampler:
         fused = getattr(denoiser, "guided", None)
         if fused is not None and denoiser.supports(x, self.guider, cond):
             return fused(x, sigma, cond, uc, self.guider)
-        return self.guider(denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc)), sigma)
+        denoised = self.guider(denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc)), sigma)
+        if self._comfy_rf and self.rf_safeguard:
+            # reference :78-89: samples whose implied x0 has a standard deviation outside [0.5, 1.5] are renormalised
+            x0 = denoised / (1.0 - _per_sample(sigma, x))
+            std = x0.std(dim=tuple(range(1, denoised.dim())))
+            off = (std < 0.5) | (std > 1.5)
+            denoised[off] /= std[off].view(-1, *[1] * (denoised.dim() - 1))
+        return denoised
 
     def _level_is_zero(self, level: Tensor, which: int) -> bool:
         """reference: torch.sum(level) < 1e-14.  Inside the driver loop the answer comes from the host table (no sync)."""

@@ -390,6 +390,71 @@ def discriminator_case():
     (HERE / "patchgan_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
 
 
+GLUE_SIGMAS = [0.002, 0.0292, 0.35, 0.9, 1.0, 2.7, 14.6, 80.0]
+GLUE_T = [0.0, 0.0004, 0.1, 0.37, 0.5, 0.93, 0.9995]
+GLUE_CLASSES = {
+    "preconditioning": {"EpsPreconditioning": {}, "VPreconditioning": {}, "VPreconditioningWithEDMcNoise": {}, "EDMPreconditioning": {},
+                        "EDMPreconditioning/0.5": dict(sigma_data=0.5), "RectifiedFlowXLPreconditioning": {}, "RectifiedFlowComfyPreconditioning": {}},
+    "weighting": {"UnitWeighting": {}, "EpsWeighting": {}, "EDMWeighting": {}, "EDMWeighting/0.5": dict(sigma_data=0.5), "RectifiedFlowWeighting": {},
+                  "RectifiedFlowWeighting/ms": dict(m=0.3, s=1.7), "RectifiedFlowComfyWeighting": {}, "RectifiedFlowComfyWeighting/ms": dict(m=-0.2, s=0.8)},
+    "generator": {"EDMSigmaGenerator": {}, "CosineScheduleSigmaGenerator": {}, "TanScheduleSigmaGenerator": {}, "TanScheduleSigmaGenerator/noclip": dict(clip=False, scale=2.0),
+                  "RectifiedFlowSigmaGenerator": {}, "RectifiedFlowComfySigmaGenerator": {}, "RectifiedFlowComfySigmaGenerator/shift": dict(start_shift=0.01, end_shift=0.02)},
+    "discretization": {"EDMcDiscretization": {}, "EDMcSimpleDiscretization": {}, "RectifiedFlowDiscretization": {}, "RectifiedFlowComfyDiscretization": {},
+                       "RectifiedFlowDiscretization/zero": dict(do_append_zero=True), "TanZeroSNRDiscretization": {}, "EDMDiscretization": {},
+                       "LegacyDDPMDiscretization": {}},
+}
+
+
+def glue_class_cases(nd):
+    """Every preconditioning / weighting / sigma-generator / discretisation class of rows A4-A5 on fixed inputs, plus the
+    rectified-flow objective of StandardDiffusionLoss (loss.py:128-137) on the tiny SDXL-style UNet with injected sigma / noise."""
+    import neurosis.modules.diffusion.denoiser_preconditioning as npre
+    import neurosis.modules.diffusion.denoiser_weighting as nw
+    import neurosis.modules.diffusion.discretization as ndisc
+    import neurosis.modules.diffusion.sampling.sigma_generators as ng
+
+    sig = torch.tensor(GLUE_SIGMAS)
+    t = torch.tensor(GLUE_T, dtype=torch.float64)
+    out = {k: {} for k in GLUE_CLASSES}
+    for name, kw in GLUE_CLASSES["preconditioning"].items():
+        out["preconditioning"][name] = [v.clone() for v in getattr(npre, name.split("/")[0])(**kw)(sig)]
+    comfy_sig = torch.tensor([0.001, 0.1, 0.37, 0.5, 0.93, 0.999])
+    for name, kw in GLUE_CLASSES["weighting"].items():
+        out["weighting"][name] = getattr(nw, name.split("/")[0])(**kw)(comfy_sig if "Comfy" in name else sig)
+    out["weighting"]["MinSNRGamma/eps"] = nw.MinSNRGammaModifier(nw.EpsWeighting(), gamma=5)(sig)
+    out["weighting"]["MinSNRGamma/v"] = nw.MinSNRGammaModifier(nw.EDMWeighting(0.5), gamma=3, v_pred=True)(sig)
+    for name, kw in GLUE_CLASSES["generator"].items():
+        gen = getattr(ng, name.split("/")[0])(**kw)
+        out["generator"][name] = gen(len(t), t.float() if "Cosine" in name else t)
+    out["generator"]["CosineScheduleSigmaGenerator/shift"] = ng.CosineScheduleSigmaGenerator()(len(t), t.float(), shift=2, return_logSNR=True)
+    spaced = ndisc.generate_roughly_equally_spaced_steps
+    ndisc.generate_roughly_equally_spaced_steps = lambda n, m: np.ascontiguousarray(spaced(n, m))
+    for name, kw in GLUE_CLASSES["discretization"].items():
+        disc = getattr(ndisc, name.split("/")[0])(**kw)
+        out["discretization"][name] = [disc(n).detach().clone() for n in (1000, 10)] + [disc(10, flip=True).detach().clone()]
+
+    # rectified-flow objective
+    torch.manual_seed(0)
+    net = nd.UNetModel(**UNET_TINY).eval()
+    shapes = json.loads((HERE / "unet_sdxl_tiny_keys.json").read_text())
+    net.load_state_dict(synth_state_dict(shapes))
+    fx = torch.load(HERE / "unet_sdxl_tiny.pt", weights_only=False)
+    sigma = torch.tensor([0.35, 0.8])
+    denoiser = nd.Denoiser(preconditioning=npre.RectifiedFlowComfyPreconditioning())
+    weighting = nw.RectifiedFlowComfyWeighting()
+    cond = {"crossattn": fx["context"], "vector": fx["y"]}
+    s_bc = sigma[:, None, None, None]
+    z_t = (1.0 - s_bc) * fx["x"] + s_bc * fx["noise"]
+    eps_out = denoiser(nd.OpenAIWrapper(net), z_t, sigma, cond, "F")
+    loss = ((eps_out.float() - fx["noise"].float()) ** 2).flatten(1).mean(1) * weighting(sigma).float()
+    loss.mean().backward()
+    out["rf"] = dict(sigma=sigma, z_t=z_t.detach(), F_out=eps_out.detach(), loss=loss.detach(),
+                     grads={k: p.grad.detach().clone() for k, p in net.named_parameters() if k in GRAD_KEYS[:6]},
+                     grad_norms={k: float(p.grad.norm()) for k, p in net.named_parameters()})
+    torch.save(out, HERE / "glue_classes.pt")
+    print("glue classes:", {k: len(v) for k, v in out.items()}, "rf loss", loss.tolist())
+
+
 def analytic_denoiser(x, sigma, c, *args, **kwargs):
     """A closed-form stand-in for denoiser(network, ...) so that sampler arithmetic can be pinned without a network:
     depends on x, on sigma and (through "vector") on the conditioning, so guidance has something to act on."""
@@ -655,7 +720,7 @@ def dataset_cases():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -680,3 +745,5 @@ if __name__ == "__main__":
         vae_train_case(nmodel)
     if "disc" in which:
         discriminator_case()
+    if "glue_classes" in which:
+        glue_class_cases(nd)

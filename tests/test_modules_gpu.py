@@ -237,3 +237,30 @@ def test_general_conditioner_against_reference_golden():
         GeneralConditioner([])
     with pytest.raises(ValueError):
         GeneralConditioner([torch.nn.Linear(2, 2)])
+
+
+def test_rectified_flow_objective_fused_against_reference():
+    """StandardDiffusionLoss(objective_type="rf") on the fused HIP route (z_t = (1 - sigma) x + sigma eps, target eps, raw network
+    output) against the reference's formula evaluated with its own classes (tests/golden/glue_classes.pt["rf"])."""
+    import neurosis_amd.modules.diffusion as D
+
+    fx, net, st = _build_unet("unet_sdxl_tiny", True)
+    rf = torch.load(G / "glue_classes.pt", weights_only=False)["rf"]
+    den = D.Denoiser(preconditioning=D.RectifiedFlowComfyPreconditioning())
+    lossfn = D.StandardDiffusionLoss(sigma_generator=D.RectifiedFlowComfySigmaGenerator(), loss_weighting=D.RectifiedFlowComfyWeighting(), objective_type="rf")
+    cond = {"crossattn": fx["context"].cuda(), "vector": fx["y"].cuda()}
+    loss = lossfn._forward(D.OpenAIWrapper(net), den, cond, fx["x"].cuda(), {}, sigmas=rf["sigma"].cuda(), noise=fx["noise"].cuda())
+    assert rel_err(loss, rf["loss"]) <= 1e-2, (loss.tolist(), rf["loss"].tolist())
+    loss.mean().backward()
+    grads = dict(net.named_parameters())
+    for k, g in rf["grads"].items():
+        assert cosine(grads[k].grad, g) >= 0.99, (k, cosine(grads[k].grad, g))
+    gmax = max(rf["grad_norms"].values())      # analytically-zero gradients (a projection in front of a one-channel-per-group GroupNorm) are
+    bad = [(k, float(grads[k].grad.float().norm()), n) for k, n in rf["grad_norms"].items()      # rounding noise on the bf16 path: absolute floor
+           if abs(float(grads[k].grad.float().norm()) - n) > 5e-2 * n + 1e-3 * gmax]
+    assert not bad, bad[:8]
+    with torch.no_grad():
+        s = rf["sigma"].cuda()
+        c_in = (s**2 + (1 - s) ** 2) ** -0.5
+        f = net(rf["z_t"].cuda() * c_in[:, None, None, None], 1000.0 * s, fx["context"].cuda(), fx["y"].cuda())
+    assert rel_err(f, rf["F_out"]) <= 3e-2 and cosine(f, rf["F_out"]) >= 0.999
