@@ -60,12 +60,39 @@ class DiffusionEngine(nn.Module):
         if first_stage_model is not None:
             self._init_first_stage(first_stage_model)
         self.global_step = 0
+        self._ckpt_path = ckpt_path
         # optimizer_step() runs on its own stream and is joined right before the next UNet forward (see optimizer_step)
         self.overlap_optimizer = os.environ.get("NK_OPT_OVERLAP", "1") != "0"
         self._optimizer_stream: Optional[torch.cuda.Stream] = None
         self._optimizer_in_flight = False
         self.store: Optional[FlatParamStore] = None
         self.last_log: dict = {}
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path)
+
+    def init_from_ckpt(self, path) -> tuple:
+        """models/diffusion.py:127-144: restore from a .safetensors file or a Lightning checkpoint (its "state_dict"), non-strict;
+        `first_stage_model.*` keys of a full SDXL checkpoint are expected leftovers (the VAE lives under vae_encoder / vae_decoder
+        here as in the reference).  Returns (missing, unexpected) after that filtering."""
+        from pathlib import Path
+
+        path = Path(path)
+        if path.suffix == ".safetensors":
+            from safetensors.torch import load_file
+
+            sd = load_file(str(path))
+        elif path.suffix in (".ckpt", ".pt", ".pth"):
+            sd = torch.load(path, map_location="cpu", weights_only=False)
+            sd = sd.get("state_dict", sd)
+        else:
+            raise NotImplementedError(f"Unknown checkpoint extension {path.suffix}")
+        self.join_optimizer()
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        unexpected = [k for k in unexpected if not k.startswith("first_stage_model")]
+        missing = [k for k in missing if not k.startswith("vae_") and "._orig_mod." not in k]
+        if self.store is not None:
+            self.store.refresh()
+        return missing, unexpected
 
     def _init_first_stage(self, model: AutoencoderKL) -> None:
         """models/diffusion.py:146-164: keep the encoder, move quant_conv onto it (the reference needs

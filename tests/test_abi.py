@@ -37,3 +37,27 @@ def test_argument_counts_match_header():
         assert m, name
         n = len([a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"])
         assert n == len(argtypes), f"{name}: header has {n} parameters, binding {len(argtypes)}"
+
+
+def test_engine_restores_from_safetensors_checkpoint(tmp_path):
+    """DiffusionEngine.init_from_ckpt (reference models/diffusion.py:127-144): non-strict restore, `first_stage_model.*` leftovers
+    of a full checkpoint ignored, UNet keys under model.diffusion_model.*"""
+    import torch
+    from safetensors.torch import save_file
+
+    import neurosis_amd.modules.diffusion as D
+    from neurosis_amd.models.diffusion import DiffusionEngine
+
+    cfg = dict(in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[2], channel_mult=[1, 2], num_head_channels=16,
+               use_linear_in_transformer=True, transformer_depth=1, context_dim=32, use_checkpoint=False)
+    torch.manual_seed(0)
+    src = DiffusionEngine(D.UNetModel(**cfg), D.Denoiser(D.EpsPreconditioning()), None)
+    sd = {k: v.contiguous() for k, v in src.state_dict().items()}
+    sd["first_stage_model.encoder.conv_in.weight"] = torch.zeros(3)
+    sd["some.other.key"] = torch.zeros(1)
+    save_file(sd, str(tmp_path / "m.safetensors"))
+    torch.manual_seed(1)
+    dst = DiffusionEngine(D.UNetModel(**cfg), D.Denoiser(D.EpsPreconditioning()), None, ckpt_path=tmp_path / "m.safetensors")
+    assert all(torch.equal(a, b) for a, b in zip(src.model.state_dict().values(), dst.model.state_dict().values()))
+    missing, unexpected = dst.init_from_ckpt(tmp_path / "m.safetensors")
+    assert missing == [] and unexpected == ["some.other.key"]
