@@ -23,7 +23,8 @@ __global__ void leaky_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restric
     *(uint4_t*)(y + i * 8) = pack8(f);
   }
 }
-// dx = dy where the OUTPUT is >= 0 (same sign as the input for slope > 0), else dy * slope
+// dx = dy where the OUTPUT is > 0, else dy * slope (the output has the input's sign for slope > 0, and is 0 exactly where a
+// ReLU -- slope 0 -- blocked it; torch takes the `slope` branch at 0 as well)
 __global__ void leaky_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, bf16_t* __restrict__ dx, long n8,
                                  float slope) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -31,7 +32,7 @@ __global__ void leaky_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __
     unpack8(*(const uint4_t*)(y + i * 8), f);
     unpack8(*(const uint4_t*)(dy + i * 8), g);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = f[e] >= 0.f ? g[e] : g[e] * slope;
+    for (int e = 0; e < 8; ++e) g[e] = f[e] > 0.f ? g[e] : g[e] * slope;
     *(uint4_t*)(dx + i * 8) = pack8(g);
   }
 }
@@ -40,12 +41,12 @@ static int ew_grid(long n) {
   return (int)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
 }
 extern "C" int nk_leaky_relu_fwd(const void* x, void* y, long n, float slope, void* stream) {
-  NK_CHECK_ARG(x && y && n > 0 && (n & 7) == 0 && slope > 0.f);
+  NK_CHECK_ARG(x && y && n > 0 && (n & 7) == 0 && slope >= 0.f);
   hipLaunchKernelGGL(leaky_fwd_kernel, dim3(ew_grid(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n >> 3, slope);
   return nk_check_launch("leaky_relu_fwd");
 }
 extern "C" int nk_leaky_relu_bwd(const void* dy, const void* y, void* dx, long n, float slope, void* stream) {
-  NK_CHECK_ARG(dy && y && dx && n > 0 && (n & 7) == 0 && slope > 0.f);
+  NK_CHECK_ARG(dy && y && dx && n > 0 && (n & 7) == 0 && slope >= 0.f);
   hipLaunchKernelGGL(leaky_bwd_kernel, dim3(ew_grid(n >> 3)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)y,
                      (bf16_t*)dx, n >> 3, slope);
   return nk_check_launch("leaky_relu_bwd");
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16_t* __restric
         if (slope != 1.f) {
           unpack8(*(const uint4_t*)(y + r * C + chunk * 8), o);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] = o[e] >= 0.f ? a[e] : a[e] * slope;
+          for (int e = 0; e < 8; ++e) a[e] = o[e] > 0.f ? a[e] : a[e] * slope;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) s0[e] += a[e], s1[e] += a[e] * (b[e] - mu[e]) * rs[e];
@@ -168,7 +169,7 @@ __global__ void bn_bwd_dx_kernel(const bf16_t* __restrict__ dy, const bf16_t* __
     if (slope != 1.f) {
       unpack8(*(const uint4_t*)(y + i * 8), o);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = o[e] >= 0.f ? g[e] : g[e] * slope;
+      for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * slope;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -214,4 +215,165 @@ extern "C" int nk_batchnorm_bwd(const void* dy, const void* x, const void* y, co
   hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
                      (const bf16_t*)y, mean, rstd, gamma, sums, (bf16_t*)dx, M, C, slope);
   return nk_check_launch("bn_bwd_dx");
+}
+
+
+// =====================================================================================================
+// LPIPS pieces (modules/losses/perceptual.py:64-228 over a VGG16 trunk): 2x2 max-pool and the per-layer distance.
+// =====================================================================================================
+// y[n][ho][wo][c] = max over the 2x2 window (H, W even).  One thread per 8 channels of an output pixel.
+__global__ void maxpool2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, chunks = C >> 3;
+  const long total = (long)N * Ho * Wo * chunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks) * 8;
+    long pix = i / chunks;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho), n = (int)(pix / Ho);
+    const bf16_t* base = x + (((long)n * H + 2 * ho) * W + 2 * wo) * C + ch;
+    float a[8], b[8], c[8], d[8];
+    unpack8(*(const uint4_t*)base, a);
+    unpack8(*(const uint4_t*)(base + C), b);
+    unpack8(*(const uint4_t*)(base + (long)W * C), c);
+    unpack8(*(const uint4_t*)(base + (long)W * C + C), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+    *(uint4_t*)(y + i * 8) = pack8(a);
+  }
+}
+// dx: the window's gradient goes to its FIRST maximal element in scan order (as torch's max_pool2d); the rest get 0
+__global__ void maxpool2_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, bf16_t* __restrict__ dx, int N, int H,
+                                    int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, chunks = C >> 3;
+  const long total = (long)N * Ho * Wo * chunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks) * 8;
+    long pix = i / chunks;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho), n = (int)(pix / Ho);
+    const long o00 = (((long)n * H + 2 * ho) * W + 2 * wo) * C + ch;
+    const long offs[4] = {o00, o00 + C, o00 + (long)W * C, o00 + (long)W * C + C};
+    float v[4][8], g[8], out[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) unpack8(*(const uint4_t*)(x + offs[k]), v[k]);
+    unpack8(*(const uint4_t*)(dy + i * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int best = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) best = v[k][e] > v[best][e] ? k : best;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[k][e] = k == best ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(uint4_t*)(dx + offs[k]) = pack8(out[k]);
+  }
+}
+extern "C" int nk_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  NK_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (H & 1) == 0 && (W & 1) == 0);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid((long)N * (H / 2) * (W / 2) * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)y, N, H, W, C);
+  return nk_check_launch("maxpool2x2_fwd");
+}
+extern "C" int nk_maxpool2x2_bwd(const void* dy, const void* x, void* dx, int N, int H, int W, int C, void* stream) {
+  NK_CHECK_ARG(dy && x && dx && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (H & 1) == 0 && (W & 1) == 0);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid((long)N * (H / 2) * (W / 2) * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, N, H, W, C);
+  return nk_check_launch("maxpool2x2_bwd");
+}
+
+// One LPIPS layer: per pixel, unit-normalise both feature vectors over the channels (x / (||x|| + eps)), square the difference,
+// weight the channels with the layer's 1x1 "lin" convolution and average over the pixels of each image:
+//   out[n] (+)= mean_p sum_c w[c] (a_c - u_c)^2,   a = f0 / (||f0|| + eps),  u = f1 / (||f1|| + eps)
+// One wavefront per pixel (lanes stride the channels), 4 pixels per workgroup; per-workgroup partials summed in a fixed order.
+#define LP_PIX 4
+__global__ __launch_bounds__(256) void lpips_layer_fwd_kernel(const bf16_t* __restrict__ f0, const bf16_t* __restrict__ f1,
+                                                              const float* __restrict__ w, float* __restrict__ part, int HW, int C,
+                                                              float eps) {
+  __shared__ float red[LP_PIX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * LP_PIX + wave;
+  float d = 0.f;
+  if (p < HW) {
+    const bf16_t* a = f0 + ((long)n * HW + p) * C;
+    const bf16_t* b = f1 + ((long)n * HW + p) * C;
+    float na = 0.f, nb = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float x = bf2f(a[c]), y = bf2f(b[c]);
+      na += x * x;
+      nb += y * y;
+    }
+    na = 1.f / (sqrtf(wave_sum(na)) + eps);
+    nb = 1.f / (sqrtf(wave_sum(nb)) + eps);
+    for (int c = lane; c < C; c += 64) {
+      const float t = bf2f(a[c]) * na - bf2f(b[c]) * nb;
+      d += w[c] * t * t;
+    }
+    d = wave_sum(d);
+  }
+  if (lane == 0) red[wave] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(long)n * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void lpips_layer_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int nblk, int HW, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int i = 0; i < nblk; ++i) s += part[(long)n * nblk + i];
+  s /= (float)HW;
+  out[n] = accumulate ? out[n] + s : s;
+}
+// d out[n] / d f1, times upstream[n]:  g_c = -2 w_c (a_c - u_c) / HW ;  df1_k = g_k * r - (sum_c g_c f1_c) * f1_k * r^2 / ||f1||,
+// r = 1 / (||f1|| + eps)
+__global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(const bf16_t* __restrict__ f0, const bf16_t* __restrict__ f1,
+                                                              const float* __restrict__ w, const float* __restrict__ upstream,
+                                                              bf16_t* __restrict__ df1, int HW, int C, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * LP_PIX + wave;
+  if (p >= HW) return;
+  const bf16_t* a = f0 + ((long)n * HW + p) * C;
+  const bf16_t* b = f1 + ((long)n * HW + p) * C;
+  bf16_t* o = df1 + ((long)n * HW + p) * C;
+  float na = 0.f, nb = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float x = bf2f(a[c]), y = bf2f(b[c]);
+    na += x * x;
+    nb += y * y;
+  }
+  const float norm_b = sqrtf(wave_sum(nb));
+  const float ra = 1.f / (sqrtf(wave_sum(na)) + eps), rb = 1.f / (norm_b + eps);
+  const float scale = -2.f * upstream[n] / (float)HW;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float y = bf2f(b[c]);
+    dot += scale * w[c] * (bf2f(a[c]) * ra - y * rb) * y;
+  }
+  dot = wave_sum(dot);
+  const float back = norm_b > 0.f ? dot * rb * rb / norm_b : 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float y = bf2f(b[c]);
+    o[c] = f2bf(scale * w[c] * (bf2f(a[c]) * ra - y * rb) * rb - back * y);
+  }
+}
+extern "C" long nk_lpips_layer_ws_floats(int N, int HW) { return (long)N * ((HW + LP_PIX - 1) / LP_PIX) + 64; }
+extern "C" int nk_lpips_layer_fwd(const void* f0, const void* f1, const float* w, float* out, float* ws, int N, int HW, int C, float eps,
+                                  int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(f0 && f1 && w && out && ws && N > 0 && N <= 65535 && HW > 0 && C > 0);
+  const int nblk = (HW + LP_PIX - 1) / LP_PIX;
+  hipLaunchKernelGGL(lpips_layer_fwd_kernel, dim3(nblk, N), dim3(256), 0, stream, (const bf16_t*)f0, (const bf16_t*)f1, w, ws, HW, C, eps);
+  if (int e = nk_check_launch("lpips_layer_fwd")) return e;
+  hipLaunchKernelGGL(lpips_layer_reduce_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, ws, out, N, nblk, HW, accumulate);
+  return nk_check_launch("lpips_layer_reduce");
+}
+extern "C" int nk_lpips_layer_bwd(const void* f0, const void* f1, const float* w, const float* upstream, void* df1, int N, int HW, int C,
+                                  float eps, void* stream) {
+  NK_CHECK_ARG(f0 && f1 && w && upstream && df1 && N > 0 && N <= 65535 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(lpips_layer_bwd_kernel, dim3((HW + LP_PIX - 1) / LP_PIX, N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)f0,
+                     (const bf16_t*)f1, w, upstream, (bf16_t*)df1, HW, C, eps);
+  return nk_check_launch("lpips_layer_bwd");
 }

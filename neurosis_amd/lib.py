@@ -57,6 +57,10 @@ SIGNATURES: dict[str, list] = {
     "nk_gelu_fwd": [vp, vp, i64, i32, vp],
     "nk_leaky_relu_fwd": [vp, vp, i64, f32, vp],
     "nk_leaky_relu_bwd": [vp, vp, vp, i64, f32, vp],
+    "nk_maxpool2x2_fwd": [vp, vp, i32, i32, i32, i32, vp],
+    "nk_maxpool2x2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "nk_lpips_layer_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+    "nk_lpips_layer_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "nk_batchnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, vp],
     "nk_batchnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
     "nk_silu_bwd": [vp, vp, vp, i64, vp],
@@ -87,6 +91,7 @@ SIZE_QUERIES: dict[str, list] = {
     "nk_layernorm_ws_floats": [i32, i32],
     "nk_colsum_ws_floats": [i64, i32],
     "nk_batchnorm_ws_floats": [i64, i32],
+    "nk_lpips_layer_ws_floats": [i32, i32],
     "nk_attention_bwd_ws_floats": [adp],
     "nk_adafactor_tensor_bytes": [],
     "nk_gemm_sk_status": [],

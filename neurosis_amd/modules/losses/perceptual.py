@@ -1,0 +1,177 @@
+"""LPIPS perceptual distance (`neurosis.modules.losses.perceptual`, :64-228; Zhang et al. 2018, v0.1) over a VGG16 trunk.
+
+    d(x, y) = sum_layers mean_pixels sum_c w_c (unit(f_x)_c - unit(f_y)_c)^2,   f = trunk features after relu1_2 ... relu5_3
+
+The reference takes the trunk from torchvision (`create_vgg_extractor`, extractors.py:11-20) and the calibrated `lin` weights
+from its package data; here the trunk is the same 13 convolutions under torchvision's parameter names (`pnet.features.N.*`) on
+the implicit-GEMM tile engine, ReLU and 2x2 max-pool as HIP kernels, and each layer's normalise / difference / 1x1 lin / spatial
+mean is ONE kernel (`nk_lpips_layer_fwd`) instead of six feature-map-sized passes.  `fwdb` also returns the backward w.r.t. the
+SECOND image (the reconstruction): the trunk is frozen, so its convolutions only pass gradients through (no weight gradients).
+
+Weights: there is no hub access here.  `lin_weights` takes a state dict / .safetensors path with the `linN.model.1.weight`
+tensors (the reference ships them as neurosis/data/lpips/vgg_lpips_v0.1.safetensors; when that package is importable they are
+found automatically); the trunk's ImageNet weights load through `load_state_dict` (torchvision's vgg16 keys) -- without them the
+trunk is random, which `pnet_rand=True` makes explicit.  The AlexNet trunk (stride-4 11x11 convolution, overlapping 3x3 pools) is
+not built.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from ... import ops
+from ...nn import Conv2d
+from ...ops import BF16, Img
+
+VGG16_PLAN = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)      # torchvision cfg "D" up to relu5_3
+VGG_TAPS = {3: "relu1", 8: "relu2", 15: "relu3", 22: "relu4", 29: "relu5"}                               # features.N -> name
+VGG_CHANNELS = (64, 128, 256, 512, 512)
+
+
+class _Trunk(nn.Module):
+    """torchvision.models.vgg16().features[:30] by position: Conv2d at the convolution slots, placeholders elsewhere"""
+
+    def __init__(self):
+        super().__init__()
+        layers, cin = [], 3
+        for item in VGG16_PLAN:
+            if item == "M":
+                layers.append(nn.Identity())                      # MaxPool2d(2, 2)
+            else:
+                layers += [Conv2d(cin, item, kernel_size=3, stride=1, padding=1), nn.Identity()]      # Conv2d, ReLU
+                cin = item
+        self.features = nn.ModuleList(layers)
+        self.kinds = ["pool" if item == "M" else None for item in VGG16_PLAN]
+
+    def run(self, x: Img, keep_tape: bool):
+        """(taps: {name: Img}, tape: [(kind, bwd, tap name or None)])"""
+        taps, tape, h, i = {}, [], x, 0
+        n_layers = len(self.features)
+        while i < n_layers:
+            layer = self.features[i]
+            if isinstance(layer, Conv2d):
+                h, b_conv = layer.fwd(h, need_dx=keep_tape)
+                act, b_act = ops.leaky_relu_fwd(h.t, 0.0)
+                h = Img(act, h.N, h.H, h.W)
+                name = VGG_TAPS.get(i + 1)
+                if name is not None:
+                    taps[name] = h
+                if keep_tape:
+                    tape.append((b_conv, b_act, name))
+                i += 2
+            else:
+                h, b_pool = ops.maxpool2x2_fwd(h)
+                if keep_tape:
+                    tape.append((None, b_pool, None))
+                i += 1
+        return taps, tape
+
+
+class NetLinLayer(nn.Module):
+    """a 1x1 convolution to one channel without bias (reference :198-212); only its weight vector is used here"""
+
+    def __init__(self, chn_in: int, chn_out: int = 1, use_dropout: bool = False):
+        super().__init__()
+        self.model = nn.Sequential(nn.Dropout() if use_dropout else nn.Identity(), nn.Conv2d(chn_in, chn_out, 1, stride=1, padding=0, bias=False))
+
+
+class ScalingLayer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("shift", torch.Tensor([-0.030, -0.088, -0.188])[None, :, None, None])
+        self.register_buffer("scale", torch.Tensor([0.458, 0.448, 0.450])[None, :, None, None])
+
+    def forward(self, inp: Tensor) -> Tensor:
+        return (inp - self.shift) / self.scale
+
+
+class LPIPS(nn.Module):
+    def __init__(self, pnet_type: str = "vgg", pretrained: bool = True, lpips: bool = True, pnet_rand: bool = False, pnet_tune: bool = False,
+                 use_dropout: bool = False, spatial: bool = False, freeze: bool = True, verbose: bool = False, lin_weights=None):
+        super().__init__()
+        if "alex" in pnet_type:
+            raise NotImplementedError("LPIPS over the AlexNet trunk is not built (stride-4 11x11 convolution, overlapping 3x3 pools); use pnet_type='vgg'")
+        if "vgg" not in pnet_type:
+            raise ValueError(f"unknown trunk {pnet_type!r}")
+        if pnet_tune or spatial or not lpips:
+            raise NotImplementedError("pnet_tune / spatial / lpips=False are not used by the autoencoder loss and are not built")
+        self.pnet_type, self.pnet_tune, self.pnet_rand, self.lpips, self.spatial = "vgg", pnet_tune, pnet_rand, lpips, spatial
+        self.scaling_layer = ScalingLayer()
+        self.chns, self.L = list(VGG_CHANNELS), len(VGG_CHANNELS)
+        self.pnet_keys = list(VGG_TAPS.values())
+        self.pnet = _Trunk()
+        self.lin0, self.lin1, self.lin2, self.lin3, self.lin4 = (NetLinLayer(c, use_dropout=use_dropout) for c in self.chns)
+        self.lins = nn.ModuleDict(dict(zip(self.pnet_keys, (self.lin0, self.lin1, self.lin2, self.lin3, self.lin4))))
+        if pretrained:
+            self._load_pretrained(lin_weights)
+        if freeze:
+            self.requires_grad_(False)
+
+    def _load_pretrained(self, source) -> None:
+        if source is None:
+            try:
+                from neurosis.data import lpips_checkpoint        # the reference package, when it is installed next to this one
+
+                with lpips_checkpoint("vgg") as state_dict:
+                    source = state_dict
+            except Exception as err:
+                raise RuntimeError("LPIPS(pretrained=True) needs the calibrated lin weights: pass lin_weights= (a state dict or the path of "
+                                   "vgg_lpips_v0.1.safetensors), or pretrained=False") from err
+        if not isinstance(source, dict):
+            from safetensors.torch import load_file
+
+            source = load_file(str(source))
+        self.load_state_dict({k: v for k, v in source.items() if k.startswith("lin")}, strict=False)
+
+    def _lin_vectors(self):
+        return [getattr(self, f"lin{i}").model[1].weight.detach().float().reshape(-1).contiguous() for i in range(self.L)]
+
+    def _scaled_tokens(self, img: Tensor) -> Img:
+        """fp32 NCHW image in [-1, 1] -> ScalingLayer -> channels-last bf16 tokens (3 channels padded to 8)"""
+        B, C, H, W = img.shape
+        return Img(ops.nchw_to_tokens(self.scaling_layer(img.float()).contiguous(), 8), B, H, W)
+
+    def fwdb(self, x: Tensor, y_tokens: Img):
+        """x: fp32 NCHW reference image; y_tokens: the other image as UNSCALED bf16 tokens [B*H*W, 8] (e.g. the decoder's output).
+        Returns (distance [B] fp32, bwd) with bwd(upstream [B] fp32) -> d sum_b upstream_b * distance_b / d y_tokens."""
+        B = x.shape[0]
+        dev = x.device
+        shift8 = torch.zeros(8, device=dev)
+        scale8 = torch.ones(8, device=dev)
+        shift8[:3], scale8[:3] = self.scaling_layer.shift.reshape(-1), self.scaling_layer.scale.reshape(-1)
+        y_scaled = ops.cast_bf16(((y_tokens.t.float() - shift8) / scale8).contiguous())      # (padding channels: (0 - 0) / 1)
+        taps_x, _ = self.pnet.run(self._scaled_tokens(x), keep_tape=False)
+        taps_y, tape = self.pnet.run(Img(y_scaled, y_tokens.N, y_tokens.H, y_tokens.W), keep_tape=True)
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+        layer_bwd = {}
+        for i, (name, w) in enumerate(zip(self.pnet_keys, self._lin_vectors())):
+            layer_bwd[name] = ops.lpips_layer(taps_x[name], taps_y[name], w, out, accumulate=i > 0)
+
+        def bwd(upstream: Tensor) -> Tensor:
+            up = upstream.float().contiguous()
+            d = None
+            for b_conv, b_other, name in reversed(tape):
+                if b_conv is None:                         # pool
+                    d = b_other(d)
+                    continue
+                if name is not None:                       # a tapped activation: the layer distance's own gradient joins in
+                    g = layer_bwd[name](up)
+                    d = g if d is None else ops.add(d, g)
+                d = b_conv(b_other(d))[0].t
+            tape.clear()
+            return ops.cast_bf16((d.float() / scale8).contiguous())
+
+        return out, bwd
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, y: Tensor, retPerLayer: bool = False, normalize: bool = False) -> Tensor:
+        """[B, 1, 1, 1] fp32, as the reference's default (lpips=True, spatial=False) path"""
+        if retPerLayer:
+            raise NotImplementedError("retPerLayer is not built")
+        if normalize:
+            x, y = x.mul(2.0).add(-1.0), y.mul(2.0).add(-1.0)
+        B, C, H, W = y.shape
+        out, _ = self.fwdb(x, Img(ops.nchw_to_tokens(y.float().contiguous(), 8), B, H, W))
+        return out.reshape(B, 1, 1, 1)

@@ -109,19 +109,19 @@ class Conv2d(nn.Module):
 
     def _padded_params(self):
         """(weight, bias) stand-ins with channels padded to multiples of 8 (tiny tensors, rebuilt per param epoch)."""
-        stamp = (ops._param_stamp(self.weight), None if self.bias is None else ops._param_stamp(self.bias))
+        stamp = (ops._param_stamp(self.weight), None if self.bias is None else ops._param_stamp(self.bias), self.weight.requires_grad)
         if self._pad_cache is not None and self._pad_cache[0] == stamp and self._pad_cache[1].device == self.weight.device:
             return self._pad_cache[1], self._pad_cache[2]
         ci, co, k = _pad8(self.in_channels), _pad8(self.out_channels), self.kernel_size
         with torch.no_grad():
             w = torch.zeros(co, k, k, ci, device=self.weight.device)
             w[: self.out_channels, :, :, : self.in_channels] = self.weight.detach().permute(0, 2, 3, 1)
-            wp = nn.Parameter(w.permute(0, 3, 1, 2), requires_grad=False)
+            wp = nn.Parameter(w.permute(0, 3, 1, 2), requires_grad=self.weight.requires_grad)   # (frozen convs skip their weight gradient)
             bp = None
             if self.bias is not None:
                 b = torch.zeros(co, device=self.weight.device)
                 b[: self.out_channels] = self.bias.detach()
-                bp = nn.Parameter(b, requires_grad=False)
+                bp = nn.Parameter(b, requires_grad=self.weight.requires_grad)
         self._pad_cache = (stamp, wp, bp)
         return wp, bp
 
@@ -141,6 +141,8 @@ class Conv2d(nn.Module):
                 res = b(dy)
             finally:
                 ops.state.grad_accumulate = acc
+            if not self.weight.requires_grad:
+                return res
             ops.join_wgrad_stream()
             with torch.no_grad():  # fold the padded gradient back (a few thousand elements)
                 g = wp.grad[: self.out_channels, : self.in_channels]

@@ -422,7 +422,8 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
             if bias is not None:
                 colsum(dy, grad_flat(bias), acc)
 
-        on_wgrad_stream(wg, dy, x.t)
+        if weight.requires_grad:          # frozen convolutions (the LPIPS trunk) only pass the gradient through
+            on_wgrad_stream(wg, dy, x.t)
         drow = None
         if rowvec is not None:
             drow32 = torch.empty(x.N, Cout, dtype=torch.float32, device=dy.device)
@@ -535,6 +536,33 @@ def leaky_relu_fwd(x: Tensor, slope: float = 0.2):
         return dx
 
     return y, bwd
+
+
+def maxpool2x2_fwd(x: Img):
+    """2x2 / stride 2 max pooling on channels-last tokens.  (y Img, bwd); bwd(dy tokens) -> dx tokens"""
+    y = torch.empty(x.N * (x.H // 2) * (x.W // 2), x.C, dtype=BF16, device=x.t.device)
+    call("nk_maxpool2x2_fwd", x.t.data_ptr(), y.data_ptr(), x.N, x.H, x.W, x.C, _stream())
+
+    def bwd(dy: Tensor) -> Tensor:
+        dx = torch.empty_like(x.t)
+        call("nk_maxpool2x2_bwd", dy.data_ptr(), x.t.data_ptr(), dx.data_ptr(), x.N, x.H, x.W, x.C, _stream())
+        return dx
+
+    return Img(y, x.N, x.H // 2, x.W // 2), bwd
+
+
+def lpips_layer(f0: Img, f1: Img, w: Tensor, out: Tensor, accumulate: bool, eps: float = 1e-10):
+    """out[n] (+)= LPIPS distance of one feature layer (see nk_lpips_layer_fwd); returns bwd(upstream[N]) -> d/d f1 tokens"""
+    N, HW, Cc = f0.N, f0.H * f0.W, f0.C
+    ws = _ws(query("nk_lpips_layer_ws_floats", N, HW), f0.t.device)
+    call("nk_lpips_layer_fwd", f0.t.data_ptr(), f1.t.data_ptr(), w.data_ptr(), out.data_ptr(), ws.data_ptr(), N, HW, Cc, float(eps), int(accumulate), _stream())
+
+    def bwd(upstream: Tensor) -> Tensor:
+        d = torch.empty_like(f1.t)
+        call("nk_lpips_layer_bwd", f0.t.data_ptr(), f1.t.data_ptr(), w.data_ptr(), upstream.data_ptr(), d.data_ptr(), N, HW, Cc, float(eps), _stream())
+        return d
+
+    return bwd
 
 
 def batchnorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor], eps: float = 1e-5,

@@ -455,6 +455,64 @@ def glue_class_cases(nd):
     print("glue classes:", {k: len(v) for k, v in out.items()}, "rf loss", loss.tolist())
 
 
+VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)
+
+
+class _VGG16Taps(torch.nn.Module):
+    """torchvision is not installed here: vgg16().features[:30] as plain torch modules under torchvision's parameter names, returning
+    the five activations the reference taps through create_feature_extractor (perceptual.py:45-60): features.3/8/15/22/29."""
+
+    def __init__(self):
+        super().__init__()
+        nn, layers, cin = torch.nn, [], 3
+        for item in VGG16_CFG:
+            if item == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, item, 3, padding=1), nn.ReLU(inplace=False)]
+                cin = item
+        self.features = nn.Sequential(*layers)
+
+    def forward(self, x):
+        out, names = {}, {3: "relu1", 8: "relu2", 15: "relu3", 22: "relu4", 29: "relu5"}
+        for i, layer in enumerate(self.features):
+            x = layer(x)
+            if i in names:
+                out[names[i]] = x
+        return out
+
+
+def lpips_case():
+    """The reference's LPIPS.forward (scaling layer, normalize_tensor, calibrated lin layers from its package data, spatial average)
+    over the VGG16 stand-in above with synthetic trunk weights, and its gradient w.r.t. the second image."""
+    import neurosis.modules.losses.perceptual as nper
+
+    trunk = _VGG16Taps().eval()
+    shapes = {f"pnet.{k}": list(v.shape) for k, v in trunk.state_dict().items()}
+    trunk.load_state_dict({k[len("pnet."):]: v * 1.6 for k, v in synth_state_dict(shapes).items()})       # (x1.6: keeps ReLU activations from dying out)
+    lp = nper.LPIPS.__new__(nper.LPIPS)
+    torch.nn.Module.__init__(lp)
+    lp.pnet_type, lp.lpips, lp.spatial, lp.pnet = "vgg", True, False, trunk
+    lp.pnet_conf = nper.PNET_CONFIG["vgg"]
+    lp.chns, lp.out_type = lp.pnet_conf["channels"], lp.pnet_conf["out_type"]
+    lp.L, lp.pnet_keys = len(lp.chns), list(lp.pnet_conf["features"].values())
+    lp.scaling_layer = nper.ScalingLayer()
+    lins = [nper.NetLinLayer(c) for c in lp.chns]
+    lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4 = lins
+    lp.lins = torch.nn.ModuleDict(dict(zip(lp.pnet_keys, lins)))
+    lp._load_pretrained("vgg")
+    lp.requires_grad_(False)
+    g = torch.Generator().manual_seed(909)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    y = (x + 0.25 * torch.randn(2, 3, 64, 64, generator=g)).clamp(-1, 1).requires_grad_(True)
+    dist = lp(x, y)
+    (dist.reshape(-1) * torch.tensor([1.0, 0.5])).sum().backward()
+    lin = {k: v.clone() for k, v in lp.state_dict().items() if k.startswith("lin") and not k.startswith("lins")}
+    torch.save(dict(x=x, y=y.detach(), distance=dist.detach(), upstream=torch.tensor([1.0, 0.5]), d_y=y.grad.clone(), lin=lin), HERE / "lpips_vgg_tiny.pt")
+    (HERE / "lpips_vgg_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
+    print("lpips:", dist.reshape(-1).tolist(), "grad norm", float(y.grad.norm()))
+
+
 def analytic_denoiser(x, sigma, c, *args, **kwargs):
     """A closed-form stand-in for denoiser(network, ...) so that sampler arithmetic can be pinned without a network:
     depends on x, on sigma and (through "vector") on the conditioning, so guidance has something to act on."""
@@ -720,7 +778,7 @@ def dataset_cases():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes", "lpips"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -747,3 +805,5 @@ if __name__ == "__main__":
         discriminator_case()
     if "glue_classes" in which:
         glue_class_cases(nd)
+    if "lpips" in which:
+        lpips_case()
