@@ -127,11 +127,13 @@ class AutoencodingEngine(nn.Module):
     def __init__(self, *, encoder: Encoder, decoder: Decoder, loss="l2", regularizer: Optional[nn.Module] = None, input_key: str = "image",
                  regularization_weights: Optional[dict] = None, discriminator: Optional[nn.Module] = None, disc_loss: str = "hinge", disc_start: int = 0,
                  disc_factor: float = 1.0, disc_weight: float = 1.0, rec_weight: float = 1.0, logvar_init: float = 0.0, learn_logvar: bool = False,
-                 **kwargs):
+                 perceptual_loss: Optional[nn.Module] = None, perceptual_weight: float = 1.0, **kwargs):
         super().__init__()
         self.encoder, self.decoder = encoder, decoder
         # adversarial part (GeneralLPIPSWithDiscriminator's arguments, discriminator_loss.py:23-40, with perceptual_weight = 0)
         self.discriminator = discriminator
+        self.perceptual_loss = perceptual_loss            # neurosis_amd.modules.losses.LPIPS (frozen), or None
+        self.perceptual_weight = perceptual_weight if perceptual_loss is not None else 0.0
         if discriminator is not None:
             from ..modules.losses import get_discr_loss_fn
 
@@ -207,7 +209,7 @@ class AutoencodingEngine(nn.Module):
         out_img, b_dec = self.decoder.fwdb(Img(ops.nchw_to_tokens(z.contiguous(), (zc + 7) // 8 * 8), B, z.shape[2], z.shape[3]))
         xrec = ops.tokens_to_nchw(out_img.t, B, C, out_img.H, out_img.W, dtype=torch.float32)
         dev = x.device
-        adversarial = self.discriminator is not None
+        adversarial = self.discriminator is not None or self.perceptual_loss is not None
         log = {}
         if adversarial:
             loss, d_out, log = self._generator_loss(x, xrec, out_img, b_dec)
@@ -239,6 +241,8 @@ class AutoencodingEngine(nn.Module):
             g     = -mean(D(xrec))                                                             (:268-270)
             d_w   = clamp(||d nll / dW|| / (||d g / dW|| + 1e-4), 0, 1e4) * disc_weight         W = decoder.conv_out.weight (:205-217)
             loss  = nll + disc_factor * d_w * g          (0 adversarial weight before disc_start)
+        With a perceptual loss, rec(x, xrec) becomes rec_weight * rec + perceptual_weight * LPIPS(x, xrec) (the per-sample distance
+        broadcast over the image, :254-259).
         The reference's forward for this branch does not run as written (it evaluates `weights > 0` with weights = None, and
         sums the un-reduced p_rec_loss tensor into a loss that is then passed to backward()); this is the formula its terms
         spell out -- the one of the taming-transformers / generative-models loss it was reworked from.
@@ -250,8 +254,17 @@ class AutoencodingEngine(nn.Module):
         nll = (rec * (self.rec_weight * inv_var) + self.logvar).sum() / B
         d_nll = (2.0 * diff if self.rec_loss_type == "l2" else torch.sign(diff)) * (self.rec_weight * inv_var / B)
         d_nll_tok = ops.nchw_to_tokens(d_nll.contiguous(), out_img.C)
-        active = self.global_step >= self.disc_start
-        log = {"nll_loss": nll.detach()}
+        log = {}
+        if self.perceptual_loss is not None and self.perceptual_weight > 0:
+            # p_rec_loss = rec_weight * rec + perceptual_weight * p_loss[b] broadcast over the image (:258-259): every element of
+            # sample b carries the LPIPS distance once, so nll gains perceptual_weight * C*H*W * p_loss[b] / exp(logvar) / B
+            p_loss, b_lpips = self.perceptual_loss.fwdb(x, out_img)
+            per_sample = self.perceptual_weight * (C * H * W) * inv_var / B
+            nll = nll + per_sample * p_loss.sum()
+            d_nll_tok = ops.add(d_nll_tok, b_lpips(torch.full((B,), per_sample, device=x.device)))
+            log["p_loss"] = p_loss.mean().detach()
+        active = self.discriminator is not None and self.global_step >= self.disc_start
+        log["nll_loss"] = nll.detach()
         if not active:
             log.update(g_loss=torch.zeros((), device=x.device), d_weight=torch.zeros((), device=x.device))
             return nll, d_nll_tok, log

@@ -44,7 +44,7 @@ def disc_loss(kind: str, real: Tensor, fake: Tensor) -> Tensor:
 
 
 def generator_adversarial_loss(enc_sd: dict, dec_sd: dict, disc_sd: dict, dd: dict, x: Tensor, noise: Tensor, rec_weight: float = 1.0, logvar: float = 0.0,
-                               disc_factor: float = 1.0, disc_weight: float = 1.0, n_layers: int = 3):
+                               disc_factor: float = 1.0, disc_weight: float = 1.0, n_layers: int = 3, lpips=None, perceptual_weight: float = 1.0):
     """The autoencoder's side of GeneralLPIPSWithDiscriminator with perceptual_weight = 0 (discriminator_loss.py:205-233,
     247-286), as its terms spell it out -- NOTE: the reference's own forward raises for this branch (`weights > 0` with
     weights = None at :298, and the loss it builds at :276 is an un-reduced tensor), so this half is NOT pinned by reference
@@ -59,7 +59,12 @@ def generator_adversarial_loss(enc_sd: dict, dec_sd: dict, disc_sd: dict, dd: di
     mean, lv = torch.chunk(moments, 2, dim=1)
     z = mean + torch.exp(0.5 * lv.clamp(-30.0, 20.0)) * noise
     xrec = O.vae_decode(dec_sd, dd, z)
-    nll = ((x - xrec) ** 2 * (rec_weight / float(torch.exp(torch.tensor(logvar)))) + logvar).sum() / x.shape[0]
+    p_rec = (x - xrec) ** 2 * rec_weight
+    if lpips is not None:        # (trunk weights, lin weights): p_rec_loss = rec_weight * rec + perceptual_weight * p_loss, broadcast (:254-259)
+        from oracle import lpips_oracle as LO
+
+        p_rec = p_rec + perceptual_weight * LO.lpips(lpips[0], lpips[1], x, xrec)
+    nll = (p_rec / float(torch.exp(torch.tensor(logvar))) + logvar).sum() / x.shape[0]
     g = -discriminator(disc_sd, xrec, n_layers).mean()
     last = dec_sd["conv_out.weight"]
     nll_grad = torch.autograd.grad(nll, last, retain_graph=True)[0]

@@ -124,7 +124,7 @@ def _gan_engine(**kw):
     disc.load_state_dict(dsd, strict=False)
     eng = AutoencodingEngine(encoder=Encoder(**fx["cfg"]), decoder=Decoder(**fx["cfg"]), loss="l2", regularizer=DiagonalGaussianRegularizer(sample=True),
                              discriminator=disc, **kw)
-    eng.load_state_dict({**sd, **{f"discriminator.{k}": v for k, v in eng.discriminator.state_dict().items()}})
+    eng.load_state_dict({**eng.state_dict(), **sd})           # (discriminator / perceptual weights as constructed)
     eng = eng.cuda().train()
     eng.setup_flat_params()
     return fx, sd, dsd, eng
@@ -179,3 +179,30 @@ def test_alternating_training_steps_and_discriminator_update():
     for i in range(2, 8):
         eng.training_step(x, i, lr=1e-3, noise=noise)
     assert torch.isfinite(eng.store.master).all() and torch.isfinite(eng.disc_store.master).all()
+
+
+def test_perceptual_term_in_the_generator_step_vs_oracle():
+    """rec + LPIPS + adversarial term: the full autoencoder-side loss of GeneralLPIPSWithDiscriminator (perceptual_weight > 0)
+    against the oracle's autograd restatement; the LPIPS trunk and lin weights are the fixture's."""
+    from neurosis_amd.modules.losses import LPIPS
+    from oracle import patchgan_oracle as PO
+    from tests.test_lpips_cpu import trunk_weights
+
+    lfx = torch.load(G / "lpips_vgg_tiny.pt", weights_only=False)
+    lp = LPIPS(pnet_type="vgg", lin_weights=lfx["lin"])
+    lp.load_state_dict(trunk_weights(), strict=False)
+    fx, sd, dsd, eng = _gan_engine(disc_factor=0.5, perceptual_loss=lp.cuda(), perceptual_weight=0.8, logvar_init=0.1)
+    case = fx["cases"]["rec_only"]
+    enc = {k[len("encoder."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    dec = {k[len("decoder."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    loss_ref, nll_ref, g_ref, dw_ref, _ = PO.generator_adversarial_loss(enc, dec, dsd, fx["cfg"], fx["x"], case["noise"], logvar=0.1, disc_factor=0.5,
+                                                                        lpips=(trunk_weights(), lfx["lin"]), perceptual_weight=0.8)
+    loss_ref.backward()
+    loss, _, _, log = eng.loss_and_backward(fx["x"].cuda(), noise=case["noise"].cuda())
+    assert abs(float(log["nll_loss"]) - float(nll_ref)) <= 1e-2 * abs(float(nll_ref))
+    assert abs(float(log["d_weight"]) - float(dw_ref)) <= 0.1 * float(dw_ref) and float(log["p_loss"]) > 0
+    assert abs(float(loss) - float(loss_ref)) <= 2e-2 * abs(float(loss_ref))
+    grads = dict(eng.named_parameters())
+    for key, ref in (("decoder.conv_out.weight", dec["conv_out.weight"]), ("decoder.conv_in.weight", dec["conv_in.weight"]), ("encoder.conv_in.weight", enc["conv_in.weight"])):
+        assert cosine(grads[key].grad, ref.grad) >= 0.98, (key, cosine(grads[key].grad, ref.grad))
+    assert all(p.grad is None for p in lp.parameters())            # the frozen trunk collects no weight gradients
