@@ -80,8 +80,8 @@ class NetLinLayer(nn.Module):
 class ScalingLayer(nn.Module):
     def __init__(self):
         super().__init__()
-        self.register_buffer("shift", torch.Tensor([-0.030, -0.088, -0.188])[None, :, None, None])
-        self.register_buffer("scale", torch.Tensor([0.458, 0.448, 0.450])[None, :, None, None])
+        self.register_buffer("shift", torch.tensor([-0.030, -0.088, -0.188])[None, :, None, None])
+        self.register_buffer("scale", torch.tensor([0.458, 0.448, 0.450])[None, :, None, None])
 
     def forward(self, inp: Tensor) -> Tensor:
         return (inp - self.shift) / self.scale
