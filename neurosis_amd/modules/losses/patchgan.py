@@ -31,6 +31,10 @@ def weights_init(m: nn.Module) -> None:
         nn.init.constant_(m.bias.data, 0.0)
 
 
+def _no_backward(_):
+    raise RuntimeError("the discriminator was run in eval mode (running BatchNorm statistics): no backward through it")
+
+
 class NLayerDiscriminator(nn.Module):
     def __init__(self, input_nc: int = 3, ndf: int = 64, n_layers: int = 3, use_actnorm: bool = False):
         super().__init__()
@@ -65,7 +69,13 @@ class NLayerDiscriminator(nn.Module):
             if isinstance(nxt, nn.BatchNorm2d):
                 if self.training:
                     nxt.num_batches_tracked += 1
-                t, b_bn = ops.batchnorm_fwd(h.t, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var, nxt.eps, nxt.momentum, SLOPE)
+                    t, b_bn = ops.batchnorm_fwd(h.t, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var, nxt.eps, nxt.momentum, SLOPE)
+                else:
+                    # evaluation (logging): the running statistics as a per-channel affine map -- a handful of [M, C] torch ops, no
+                    # gradients (nothing trains through an eval-mode discriminator)
+                    scale = nxt.weight.detach() * torch.rsqrt(nxt.running_var + nxt.eps)
+                    t = torch.nn.functional.leaky_relu(h.t.float() * scale + (nxt.bias.detach() - nxt.running_mean * scale), SLOPE).to(h.t.dtype)
+                    b_bn = _no_backward
                 h = Img(t, h.N, h.H, h.W)
                 tape.append(b_bn)
                 i += 3
@@ -87,10 +97,8 @@ class NLayerDiscriminator(nn.Module):
         return h, bwd
 
     def forward(self, x: Tensor) -> Tensor:
-        """NCHW image -> NCHW logits [B, 1, h, w] (fp32); autograd through `x` and the parameters is supported via fwdb by
-        AutoencodingEngine, not here: this entry point is for evaluation / logging."""
-        if not self.training:
-            raise NotImplementedError("eval-mode BatchNorm (running statistics) is not needed by the training path and not built")
+        """NCHW image -> NCHW logits [B, 1, h, w] (fp32), batch statistics in train mode, running statistics in eval mode.  This entry
+        point is for evaluation / logging (the reference's loss.log_images); training goes through fwdb (AutoencodingEngine)."""
         with torch.no_grad():
             B, C, H, W = x.shape
             logits, _ = self.fwdb(Img(ops.nchw_to_tokens(x.float().contiguous(), (C + 7) // 8 * 8), B, H, W), need_dx=False)

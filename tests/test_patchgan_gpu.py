@@ -132,3 +132,22 @@ def test_generator_term_input_gradient():
     want = fx["generator"]["d_image"]
     assert cosine(got, want) >= 0.99 and float((got.cpu() - want).norm() / want.norm()) <= 0.13
     assert disc(fx["fake"].cuda()).shape == (4, 1, 6, 6)
+
+
+def test_eval_mode_uses_running_statistics():
+    from oracle import patchgan_oracle as PO  # noqa: F401  (same formula as torch's eval-mode batch_norm below)
+
+    fx, disc = _disc()
+    disc.eval()
+    got = disc(fx["real"].cuda())
+    shapes = json.loads((G / "patchgan_tiny_keys.json").read_text())
+    sd = disc_state_dict(shapes)
+    h = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(fx["real"], sd["layers.0.weight"], sd["layers.0.bias"], stride=2, padding=1), 0.2)
+    for idx, stride in ((2, 2), (5, 2), (8, 1)):
+        h = torch.nn.functional.conv2d(h, sd[f"layers.{idx}.weight"], None, stride=stride, padding=1)
+        bn = f"layers.{idx + 1}"
+        h = torch.nn.functional.batch_norm(h, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"], training=False)
+        h = torch.nn.functional.leaky_relu(h, 0.2)
+    want = torch.nn.functional.conv2d(h, sd["layers.11.weight"], sd["layers.11.bias"], stride=1, padding=1)
+    assert got.shape == want.shape and rel_err(got, want) <= 3e-2 and cosine(got, want) >= 0.999
+    assert int(disc.layers[3].num_batches_tracked) == 0
