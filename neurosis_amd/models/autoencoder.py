@@ -137,11 +137,13 @@ class AutoencodingEngine(nn.Module):
         if discriminator is not None:
             from ..modules.losses import get_discr_loss_fn
 
-            if learn_logvar:
-                raise NotImplementedError("learn_logvar is not built (the reference's default is a fixed logvar)")
             self.disc_loss = get_discr_loss_fn(disc_loss)
         self.disc_start, self.disc_factor, self.discriminator_weight = disc_start, disc_factor, disc_weight
-        self.rec_weight, self.logvar = rec_weight, float(logvar_init)
+        self.rec_weight = rec_weight
+        # the output log-variance of the nll (discriminator_loss.py:56-58): a scalar parameter, trained with the autoencoder when
+        # learn_logvar (get_trainable_autoencoder_parameters, :90-93)
+        self.logvar = nn.Parameter(torch.ones(size=()) * logvar_init, requires_grad=learn_logvar)
+        self.learn_logvar = learn_logvar
         self.disc_store: Optional[FlatParamStore] = None
         self.regularization = regularizer if regularizer is not None else DiagonalGaussianRegularizer()
         if isinstance(loss, nn.MSELoss) or loss in ("l2", "mse"):
@@ -161,7 +163,7 @@ class AutoencodingEngine(nn.Module):
         return batch[self.input_key]
 
     def get_autoencoder_params(self, decoder_only: bool = False) -> list:
-        params = list(self.decoder.parameters())
+        params = ([self.logvar] if self.learn_logvar else []) + list(self.decoder.parameters())
         return params if decoder_only else params + list(self.encoder.parameters())
 
     def get_last_layer(self):
@@ -250,8 +252,10 @@ class AutoencodingEngine(nn.Module):
         B, C, H, W = x.shape
         diff = xrec - x
         rec = diff * diff if self.rec_loss_type == "l2" else diff.abs()
-        inv_var = math.exp(-self.logvar)
-        nll = (rec * (self.rec_weight * inv_var) + self.logvar).sum() / B
+        lv = self.logvar.detach().float()
+        inv_var = torch.exp(-lv)                    # (device scalars: no host sync)
+        weighted_rec = (rec * self.rec_weight).sum()
+        nll = (weighted_rec * inv_var + lv * rec.numel()) / B
         d_nll = (2.0 * diff if self.rec_loss_type == "l2" else torch.sign(diff)) * (self.rec_weight * inv_var / B)
         d_nll_tok = ops.nchw_to_tokens(d_nll.contiguous(), out_img.C)
         log = {}
@@ -261,8 +265,14 @@ class AutoencodingEngine(nn.Module):
             p_loss, b_lpips = self.perceptual_loss.fwdb(x, out_img)
             per_sample = self.perceptual_weight * (C * H * W) * inv_var / B
             nll = nll + per_sample * p_loss.sum()
-            d_nll_tok = ops.add(d_nll_tok, b_lpips(torch.full((B,), per_sample, device=x.device)))
+            weighted_rec = weighted_rec + self.perceptual_weight * (C * H * W) * p_loss.sum()
+            d_nll_tok = ops.add(d_nll_tok, b_lpips(per_sample.expand(B).contiguous()))
             log["p_loss"] = p_loss.mean().detach()
+        if self.learn_logvar:
+            # d nll / d logvar = (-sum(p_rec) / exp(logvar) + numel) / B; the adversarial term does not depend on it
+            g = ((rec.numel() - weighted_rec * inv_var) / B).reshape(())
+            flat = ops.grad_flat(self.logvar)
+            flat.copy_(g.reshape(flat.shape)) if not ops.state.grad_accumulate else flat.add_(g.reshape(flat.shape))
         active = self.discriminator is not None and self.global_step >= self.disc_start
         log["nll_loss"] = nll.detach()
         if not active:

@@ -26,7 +26,7 @@ def _engine(loss="l2", **kw):
     fx = torch.load(G / "vae_train_tiny.pt", weights_only=False)
     sd = synth_state_dict(json.loads((G / "vae_train_tiny_keys.json").read_text()))
     eng = AutoencodingEngine(encoder=Encoder(**fx["cfg"]), decoder=Decoder(**fx["cfg"]), loss=loss, regularizer=DiagonalGaussianRegularizer(sample=True), **kw)
-    eng.load_state_dict(sd)
+    eng.load_state_dict({**eng.state_dict(), **sd})
     eng = eng.cuda()
     eng.setup_flat_params()
     return fx, eng
@@ -206,3 +206,21 @@ def test_perceptual_term_in_the_generator_step_vs_oracle():
     for key, ref in (("decoder.conv_out.weight", dec["conv_out.weight"]), ("decoder.conv_in.weight", dec["conv_in.weight"]), ("encoder.conv_in.weight", enc["conv_in.weight"])):
         assert cosine(grads[key].grad, ref.grad) >= 0.98, (key, cosine(grads[key].grad, ref.grad))
     assert all(p.grad is None for p in lp.parameters())            # the frozen trunk collects no weight gradients
+
+
+def test_learned_logvar_gradient_and_update():
+    """learn_logvar: d nll / d logvar = (numel - sum(rec_weight * rec) / exp(logvar)) / B, trained with the autoencoder's optimizer"""
+    fx, sd, dsd, eng = _gan_engine(learn_logvar=True, logvar_init=0.3, rec_weight=1.2, disc_start=1000)
+    assert any(p is eng.logvar for p in eng.store.params)
+    x = fx["x"].cuda()
+    noise = fx["cases"]["rec_only"]["noise"].cuda()
+    loss, _, xrec, log = eng.loss_and_backward(x, noise=noise)
+    rec = ((xrec - x) ** 2 * 1.2).sum()
+    B = x.shape[0]
+    want_nll = (rec / torch.exp(torch.tensor(0.3)) + 0.3 * x.numel()) / B
+    assert abs(float(log["nll_loss"]) - float(want_nll)) <= 1e-4 * abs(float(want_nll))
+    want_grad = (x.numel() - rec / torch.exp(torch.tensor(0.3))) / B
+    assert abs(float(eng.logvar.grad) - float(want_grad)) <= 1e-4 * abs(float(want_grad))
+    before = float(eng.logvar)
+    eng.training_step({"image": x}, 0, lr=1e-2, noise=noise)
+    assert float(eng.logvar) != before
