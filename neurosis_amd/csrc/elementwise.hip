@@ -303,30 +303,40 @@ extern "C" int nk_cast_bf16_to_f32(const void* src, float* dst, long n, void* st
 // thread keeps four rows' loads in flight, and with 64 rows per split even M = 4096 gives hundreds of blocks (the
 // earlier one-row-at-a-time layout ran at 1-2 TB/s: 12 ms of GPU time per step for bias gradients alone).
 #define CS_ROWS 64
+// rows per workgroup: 64 up to 65 536 rows (the UNet's token counts), then as many as keeps the second stage at <= 1 024 partial rows
+// (the autoencoder's 2 M-row feature maps gave it 32 768 rows to walk: 80 us per bias gradient)
+static int colsum_rows(long M) {
+  long rows = CS_ROWS;
+  while ((M + rows - 1) / rows > 1024) rows *= 2;
+  return (int)rows;
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ dy, float* __restrict__ part, long M, int N,
-                                                             long ld) {
+                                                             long ld, int rows_per_block) {
   __shared__ float ps[16][16 * 8 + 4];  // [row lane][chunk lane * 8 + e], combined in a fixed order (bitwise reproducible)
   const int tid = threadIdx.x;
   const int cx = tid & 15, ry = tid >> 4;
   const int chunk = blockIdx.y * 16 + cx;
   const bool cok = chunk < (N >> 3);
-  const long row_lo = (long)blockIdx.x * CS_ROWS;
+  const long row_lo = (long)blockIdx.x * rows_per_block;
+  const long row_hi = row_lo + rows_per_block < M ? row_lo + rows_per_block : M;
   float s[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = 0.f;
   if (cok) {
-    uint4_t v[4];
+    for (long base = row_lo + ry; base < row_hi; base += 64) {      // four rows' loads in flight per pass
+      uint4_t v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long r = row_lo + ry + 16 * i;
-      v[i] = r < M ? *(const uint4_t*)(dy + r * ld + chunk * 8) : (uint4_t){0u, 0u, 0u, 0u};
-    }
+      for (int i = 0; i < 4; ++i) {
+        const long r = base + 16 * i;
+        v[i] = r < row_hi ? *(const uint4_t*)(dy + r * ld + chunk * 8) : (uint4_t){0u, 0u, 0u, 0u};
+      }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float f[8];
-      unpack8(v[i], f);
+      for (int i = 0; i < 4; ++i) {
+        float f[8];
+        unpack8(v[i], f);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += f[e];
+        for (int e = 0; e < 8; ++e) s[e] += f[e];
+      }
     }
   }
 #pragma unroll
@@ -359,13 +369,13 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
     out[c] = accumulate ? out[c] + a : a;
   }
 }
-static int colsum_split(long M) { return (int)((M + CS_ROWS - 1) / CS_ROWS); }
+static int colsum_split(long M) { const int rows = colsum_rows(M); return (int)((M + rows - 1) / rows); }
 extern "C" long nk_colsum_ws_floats(long M, int N) { return (long)colsum_split(M) * N + 64; }
 extern "C" int nk_colsum(const void* dy, float* out, float* ws, long M, int N, long ld, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(dy && out && ws && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0);
   const int nsplit = colsum_split(M);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nsplit, (N + 127) / 128), dim3(256), 0, stream, (const bf16_t*)dy, ws, M, N, ld);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nsplit, (N + 127) / 128), dim3(256), 0, stream, (const bf16_t*)dy, ws, M, N, ld, colsum_rows(M));
   if (int e = nk_check_launch("colsum_partial")) return e;
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, stream, ws, out, nsplit, N, accumulate);
   return nk_check_launch("colsum_reduce");
