@@ -1,7 +1,7 @@
 """LPIPS on the GPU: max-pool / ReLU / layer-distance kernels against their formulas, and the product's
 LPIPS (VGG16 trunk on the tile engine, fused layer distance, backward to the second image) against the reference's LPIPS.forward
-(tests/golden/lpips_vgg_tiny.pt).  Tolerances: kernels 1e-2; distance 3e-2 relative; image gradient cosine >= 0.98 and relative
-L2 error <= 0.2 (13 bf16 convolutions and 13 ReLU kinks deep, gradient magnitudes ~1e-5)."""
+(tests/golden/lpips_vgg_tiny.pt).  Tolerances: kernels 1e-2; distance 5e-3 relative (measured 9e-4); image gradient cosine >= 0.98 and relative
+L2 error <= 0.2 (measured 0.988 / 0.15: 13 bf16 convolutions and 13 ReLU kinks deep, gradient magnitudes ~1e-5)."""
 import json
 from pathlib import Path
 
@@ -78,7 +78,7 @@ def test_lpips_against_reference():
 
     fx, lp = _lpips()
     dist = lp(fx["x"].cuda(), fx["y"].cuda())
-    assert dist.shape == fx["distance"].shape and rel_err(dist, fx["distance"]) <= 3e-2, (dist.reshape(-1).tolist(), fx["distance"].reshape(-1).tolist())
+    assert dist.shape == fx["distance"].shape and rel_err(dist, fx["distance"]) <= 5e-3, (dist.reshape(-1).tolist(), fx["distance"].reshape(-1).tolist())
     B, C, H, W = fx["y"].shape
     out, bwd = lp.fwdb(fx["x"].cuda(), Img(ops.nchw_to_tokens(fx["y"].cuda().contiguous(), 8), B, H, W))
     d_tok = bwd(fx["upstream"].cuda())
