@@ -1168,13 +1168,19 @@ static_assert(BIG_SMEM_BYTES >= BIG_BM * CS_LD * 4, "big epilogue staging must f
 // 16 waves as 4 x 4, 64 x 32 per wave (the same wave tile, fragment reads and 4 waves per SIMD as the 128x128 kernel at two
 // workgroups per CU) -- but ONE 256x128 workgroup per CU: 48 KiB instead of 64 KiB through the 64 B/clk texture path per
 // 2 x (128x128x64) of MFMA work, and a 3-stage ring (two slabs in flight) in the LDS the second workgroup would have used.
-template <int AMODE, int OUT_F32>
-__global__ __launch_bounds__(BIG_NT, 4) void nk_gemm_big_kernel(const NkGemmParams p) {
+// NW = 8 (NK_GEMM_BIG=8): the same tile with 8 waves as 4 x 2, 64 x 64 per wave -- 8 fragment reads per 16 MFMAs instead of 6 per 8
+// (a third less LDS traffic per FLOP), 2 waves per SIMD, 6 DMA pieces per wave and slab.  Measured (tools/vs_library.py):
+// 813 TFLOP/s at 65536 x 1280 x 1280 against 861 for NW = 16 and 848 for the default 128 x 128 kernel -- LDS read traffic is
+// not what limits this loop either; the feed (bytes in flight per CU between HBM/L2 and LDS) is.
+template <int AMODE, int OUT_F32, int NW = 16>
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void nk_gemm_big_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NJ = NW == 16 ? 2 : 4;          // 16-column fragments per wave
+  constexpr int NPA = NW == 16 ? 2 : 4, NPB = NW == 16 ? 1 : 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;            // 0..15
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wave = tid >> 6;
+  const int wm = NW == 16 ? wave >> 2 : wave >> 1, wn = NW == 16 ? wave & 3 : wave & 1;
 
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
@@ -1195,16 +1201,16 @@ __global__ __launch_bounds__(BIG_NT, 4) void nk_gemm_big_kernel(const NkGemmPara
   const int kend = p.K;
   const int nk = (p.K + BK - 1) / BK;
 
-  OperandDMA<AMODE, 2> opa;   // 16 waves x 2 pieces x 8 rows = 256 rows
-  OperandDMA<OP_KC, 1> opb;   // 16 waves x 1 piece  x 8 rows = 128 rows
+  OperandDMA<AMODE, NPA> opa;   // NW waves x NPA pieces x 8 rows = 256 rows
+  OperandDMA<OP_KC, NPB> opb;   // NW waves x NPB pieces x 8 rows = 128 rows
   opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
   opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
 
-  float4_t acc[4][2];
+  float4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int t = 0; t < BIG_NSTAGE - 1; ++t)
@@ -1215,17 +1221,21 @@ __global__ __launch_bounds__(BIG_NT, 4) void nk_gemm_big_kernel(const NkGemmPara
   int cur_stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // this wave issued 3 pieces per slab, in order; slab kt has landed once at most the 3 pieces of slab kt+1 remain
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt + 1 < nk) {
+      if constexpr (NW == 16) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();   // every wave's share of slab kt is in LDS; every wave is done reading stage (kt-1)%3
     const char* cur = smem + cur_stage * BIG_STAGE_BYTES;
-    bf16x8_t af[2][4], bfr[2][2];
+    bf16x8_t af[2][4], bfr[2][NJ];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[ks][i] = OperandDMA<OP_KC>::frag(cur, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[ks][j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * 32 + j * 16, ks, lane);
+      for (int j = 0; j < NJ; ++j) bfr[ks][j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * (NJ * 16) + j * 16, ks, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 2 < nk) {
@@ -1239,12 +1249,12 @@ __global__ __launch_bounds__(BIG_NT, 4) void nk_gemm_big_kernel(const NkGemmPara
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
     if (++cur_stage == BIG_NSTAGE) cur_stage = 0;
   }
   __syncthreads();
-  nk_gemm_epilogue<OUT_F32, BIG_BM, BIG_NT, 2>(p, smem, acc, m0, n0, tid, lane, wm, wn);
+  nk_gemm_epilogue<OUT_F32, BIG_BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1255,7 +1265,7 @@ static bool use_big(const NkGemmParams& p, int amode, int bmode, int out_f32, in
   // every SDXL shape (e.g. 16384x5120x640: 653 vs 717 TFLOP/s), so it is not dispatched by default; kept as the base of
   // the 256x256 variant planned next.
   static int dis = -1;
-  if (dis < 0) { const char* e = getenv("NK_GEMM_BIG"); dis = (e && e[0] == '1') ? 0 : 1; }
+  if (dis < 0) { const char* e = getenv("NK_GEMM_BIG"); dis = (e && (e[0] == '1' || e[0] == '8')) ? 0 : 1; }
   if (dis || p.nbatch || out_f32 || splitk != 1 || bmode != OP_KC || !(amode == OP_KC || amode == OP_KCG)) return false;
   long tiles = (long)((p.M + BIG_BM - 1) / BIG_BM) * ((p.N + BN - 1) / BN);
   return tiles >= 256 && p.K >= 4 * BK;
@@ -1264,13 +1274,19 @@ static bool use_big(const NkGemmParams& p, int amode, int bmode, int out_f32, in
 template <int AMODE>
 static int launch_big(const NkGemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = nk_gemm_big_kernel<AMODE, 0>;
+  static int nw = 0;
+  auto kern = nk_gemm_big_kernel<AMODE, 0, 16>;
+  auto kern8 = nk_gemm_big_kernel<AMODE, 0, 8>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_SMEM_BYTES);
+    const char* e = getenv("NK_GEMM_BIG");
+    nw = (e && e[0] == '8') ? 8 : 16;
     attr_set = true;
   }
   dim3 grid(((p.M + BIG_BM - 1) / BIG_BM) * ((p.N + BN - 1) / BN), 1, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(BIG_NT), BIG_SMEM_BYTES, stream, p);
+  if (nw == 8) hipLaunchKernelGGL(kern8, grid, dim3(512), BIG_SMEM_BYTES, stream, p);
+  else hipLaunchKernelGGL(kern, grid, dim3(BIG_NT), BIG_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_big_kernel");
 }
 
