@@ -1315,6 +1315,8 @@ static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
   if (const char* e = getenv("NK_GEMM_NW")) nw = atoi(e);
   int ring = 1;
   if (const char* e = getenv("NK_GEMM_RING")) ring = atoi(e);
+  // (the ring at one workgroup per CU on LARGE grids was measured too: 723 vs 830 TFLOP/s at 65536 x 1280 x 1280 -- three slabs in
+  // flight do not make up for two waves per SIMD meeting at a barrier every k-step)
   if (ring && !use_v1() && nw == 8 && !p.nbatch && (long)ntm * ntn * splitk <= 256) {
     auto kernr = nk_gemm_ring_kernel<AMODE, BMODE, OUT_F32>;
     static bool rattr = false;
