@@ -877,12 +877,11 @@ __device__ __forceinline__ void sk_decode(const NkGemmParams& p, int t, int ntm,
 // accumulators -> global, fused bias / rowvec / residual.  acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)]
 //                                                                           [n0 + wn*32 + j*16 + (lane>>4)*4 + r]
 template <int OUT_F32>
-__device__ __forceinline__ void sk_epilogue(const NkGemmParams& p, void* Cv, float4_t (&acc)[4][2], int m0, int n0, int lane,
-                                            int wm, int wn) {
+__device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* Cv, float4_t (&acc)[4][2], int mbase, int nbase, int lane) {
   const int g = lane >> 4;
   // after the row swap: lanes g=0 hold columns 0-7 of the wave's 32, g=1 16-23, g=2 8-15, g=3 24-31
-  const int n = n0 + wn * 32 + (g & 1) * 16 + (g >> 1) * 8;
-  const int mrow = m0 + wm * 64 + (lane & 15);
+  const int n = nbase + (g & 1) * 16 + (g >> 1) * 8;
+  const int mrow = mbase + (lane & 15);
   const bool n_ok = n < p.N;
   float bias[8];
 #pragma unroll
@@ -950,6 +949,11 @@ __device__ __forceinline__ void sk_epilogue(const NkGemmParams& p, void* Cv, flo
       }
     }
   }
+}
+template <int OUT_F32>
+__device__ __forceinline__ void sk_epilogue(const NkGemmParams& p, void* Cv, float4_t (&acc)[4][2], int m0, int n0, int lane,
+                                            int wm, int wn) {
+  reg_epilogue_64x32<OUT_F32>(p, Cv, acc, m0 + wm * 64, n0 + wn * 32, lane);
 }
 
 // Partial tiles travel between workgroups (possibly on different XCDs, i.e. different L2s) with agent-scope (sc1)
@@ -1257,6 +1261,104 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void nk_gemm_big_kernel(
   nk_gemm_epilogue<OUT_F32, BIG_BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
+// =============================================================================================
+// "XL" variant (default for large k-contiguous GEMMs; NK_GEMM_XL=0 turns it off): 256 x 256 x 64 tiles, 16 waves as 4 x 4 with 64 x 64 per wave, one workgroup per CU,
+// two 64 KiB LDS-DMA stages, register-direct epilogue.  The point is bytes per FLOP through the texture -> LDS path, which is
+// what bounds the 128 x 128 kernel: half of its 32 B per 1 Ki MAC.  k-contiguous operands, bf16 output.
+// Fragments are read one k sub-step at a time (64 accumulator + 32 fragment registers at 4 waves per SIMD).
+// =============================================================================================
+#define XL_BM 256
+#define XL_BN 256
+#define XL_STAGE_BYTES 65536
+#define XL_SMEM_BYTES (2 * XL_STAGE_BYTES)
+template <int AMODE>
+__global__ __launch_bounds__(1024, 4) void nk_gemm_xl_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + XL_BN - 1) / XL_BN, ntm = (p.M + XL_BM - 1) / XL_BM;
+  constexpr int GM = 4;
+  const int per_group = GM * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GM;
+  const int gm = min(GM, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int m0 = (first_m + (in_group - nt * gm)) * XL_BM, n0 = nt * XL_BN;
+  const int kend = p.K, nk = (p.K + BK - 1) / BK;
+
+  OperandDMA<AMODE, 2> opa;   // 16 waves x 2 pieces x 8 rows = 256 rows
+  OperandDMA<OP_KC, 2> opb;
+  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+  float4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  opa.start(0);          // running source pointers: a k-step costs one 64-bit add per piece instead of the row * ld products
+  opb.start(0);
+  if (nk > 0) {
+    opa.issue_next(kend, smem, p.ga, p.tw);
+    opb.issue_next(kend, smem + 32768, p.gb, p.tw);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slab kt has landed (this wave's share) ...
+    __syncthreads();                                    // ... for every wave, and everyone is done with the other stage
+    const char* cur = smem + (kt & 1) * XL_STAGE_BYTES;
+    if (kt + 1 < nk) {
+      char* nxt = smem + ((kt + 1) & 1) * XL_STAGE_BYTES;
+      opa.issue_next(kend, nxt, p.ga, p.tw);
+      opb.issue_next(kend, nxt + 32768, p.gb, p.tw);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = OperandDMA<OP_KC>::frag(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float4_t pair[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pair[i][0] = acc[i][2 * half]; pair[i][1] = acc[i][2 * half + 1]; }
+    reg_epilogue_64x32<0>(p, p.C, pair, m0 + wm * 64, n0 + wn * 64 + half * 32, lane);
+  }
+}
+
+static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("NK_GEMM_XL"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on || p.nbatch || out_f32 || splitk != 1 || bmode != OP_KC || !(amode == OP_KC || amode == OP_KCG)) return false;
+  const long ntn = (p.N + XL_BN - 1) / XL_BN;
+  const long tiles = (long)((p.M + XL_BM - 1) / XL_BM) * ntn;
+  // at least ~one workgroup per CU, and no more than 12 % of the last column tile wasted (N = 320 / 640 would idle 37 % / 17 %)
+  return tiles >= 224 && ntn * XL_BN * 100 <= (long)p.N * 112 && p.K >= 4 * BK;
+}
+template <int AMODE>
+static int launch_xl(const NkGemmParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = nk_gemm_xl_kernel<AMODE>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(((p.M + XL_BM - 1) / XL_BM) * ((p.N + XL_BN - 1) / XL_BN), 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(1024), XL_SMEM_BYTES, stream, p);
+  return nk_check_launch("nk_gemm_xl_kernel");
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1501,6 +1603,8 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
     p.accumulate = splitk > 1 ? 1 : 0;
   }
 
+  if (use_xl(p, amode, bmode, out_f32, splitk))
+    return amode == OP_KC ? launch_xl<OP_KC>(p, stream) : launch_xl<OP_KCG>(p, stream);
   if (use_big(p, amode, bmode, out_f32, splitk))
     return amode == OP_KC ? launch_big<OP_KC>(p, stream) : launch_big<OP_KCG>(p, stream);
 

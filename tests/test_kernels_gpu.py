@@ -37,7 +37,7 @@ def rnd(*shape, scale=1.0, seed=None):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 320), (308, 640, 2048), (4, 1280, 320), (1000, 72, 136), (16384, 640, 640),
-                                   (32768, 2048, 320), (16300, 4104, 264)])  # the last two take the 256x128 ring kernel (>= 512 tiles)
+                                   (32768, 2048, 320), (16300, 4104, 264), (4000, 3600, 328)])  # the last three take the 256x256 kernel (ragged M, N and K)
 def test_linear_fwd(ops, M, N, K):
     x, w, b, r = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N), rnd(M, N)
     ref = x @ w.t() + b + r
@@ -168,6 +168,11 @@ def test_conv3x3_real_channels(ops):
 def test_conv3x3_big_grid(ops):
     # 131072 output pixels x 128 channels = 512 tiles of 256x128: the ring kernel with the gather loader
     _conv_case(ops, 2, 256, 256, 64, 128, 3, 1, 1, rowvec=True, residual=True)
+
+
+def test_conv3x3_wide_output(ops):
+    # 8192 output pixels x 1920 channels = 256 tiles of 256x256 (the last column tile half empty): the 256x256 kernel with the gather loader
+    _conv_case(ops, 2, 64, 64, 64, 1920, 3, 1, 1, rowvec=True, residual=True)
 
 
 def test_conv4x4_patchgan_shapes(ops):
