@@ -303,6 +303,86 @@ extern "C" int nk_maxpool2x2_bwd(const void* dy, const void* x, void* dx, int N,
   return nk_check_launch("maxpool2x2_bwd");
 }
 
+// General k x k / stride s max pooling without padding (floor mode), for the AlexNet trunk's overlapping 3x3 / 2 pools.
+// Forward: one thread per 8 channels of an output pixel.  Backward GATHERS: one thread per 8 channels of an INPUT pixel walks the
+// (at most ceil(k/s)^2) windows that contain it, re-derives each window's first maximal element in scan order (torch's max_pool2d
+// tie rule) and adds that window's gradient when the element is this pixel -- overlapping windows need no atomics this way.
+__global__ void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, int k, int s, int Ho,
+                                   int Wo) {
+  const int chunks = C >> 3;
+  const long total = (long)N * Ho * Wo * chunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks) * 8;
+    long pix = i / chunks;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho), n = (int)(pix / Ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int kh = 0; kh < k; ++kh)
+      for (int kw = 0; kw < k; ++kw) {
+        float v[8];
+        unpack8(*(const uint4_t*)(x + (((long)n * H + ho * s + kh) * W + wo * s + kw) * C + ch), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    *(uint4_t*)(y + i * 8) = pack8(m);
+  }
+}
+__global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, bf16_t* __restrict__ dx, int N, int H,
+                                   int W, int C, int k, int s, int Ho, int Wo) {
+  const int chunks = C >> 3;
+  const long total = (long)N * H * W * chunks;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks) * 8;
+    long pix = i / chunks;
+    const int w = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H), n = (int)(pix / H);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    const int ho_lo = h - k + 1 > 0 ? (h - k + s) / s : 0, ho_hi = min(h / s, Ho - 1);
+    const int wo_lo = w - k + 1 > 0 ? (w - k + s) / s : 0, wo_hi = min(w / s, Wo - 1);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        float best[8];
+        int arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
+        for (int kh = 0; kh < k; ++kh)
+          for (int kw = 0; kw < k; ++kw) {
+            float v[8];
+            unpack8(*(const uint4_t*)(x + (((long)n * H + ho * s + kh) * W + wo * s + kw) * C + ch), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = kh * k + kw; }
+          }
+        const int mine = (h - ho * s) * k + (w - wo * s);
+        float d[8];
+        unpack8(*(const uint4_t*)(dy + (((long)n * Ho + ho) * Wo + wo) * C + ch), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += arg[e] == mine ? d[e] : 0.f;
+      }
+    *(uint4_t*)(dx + i * 8) = pack8(g);
+  }
+}
+extern "C" int nk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int s, void* stream) {
+  NK_CHECK_ARG(x && y && N > 0 && C > 0 && (C & 7) == 0 && k > 0 && s > 0 && H >= k && W >= k);
+  const int Ho = (H - k) / s + 1, Wo = (W - k) / s + 1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, N, H, W, C, k, s, Ho, Wo);
+  return nk_check_launch("maxpool_fwd");
+}
+extern "C" int nk_maxpool_bwd(const void* dy, const void* x, void* dx, int N, int H, int W, int C, int k, int s, void* stream) {
+  NK_CHECK_ARG(dy && x && dx && N > 0 && C > 0 && (C & 7) == 0 && k > 0 && s > 0 && H >= k && W >= k);
+  const int Ho = (H - k) / s + 1, Wo = (W - k) / s + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)x, (bf16_t*)dx, N, H, W, C, k, s, Ho, Wo);
+  return nk_check_launch("maxpool_bwd");
+}
+
 // One LPIPS layer: per pixel, unit-normalise both feature vectors over the channels (x / (||x|| + eps)), square the difference,
 // weight the channels with the layer's 1x1 "lin" convolution and average over the pixels of each image:
 //   out[n] (+)= mean_p sum_c w[c] (a_c - u_c)^2,   a = f0 / (||f0|| + eps),  u = f1 / (||f1|| + eps)

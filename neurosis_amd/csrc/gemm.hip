@@ -53,9 +53,9 @@ __device__ __forceinline__ long gather_offset(const NkGather& g, int n, int bh, 
   int hn = bh + kh * g.ks;
   int wn = bw + kw * g.ks;
   bool ok = (hn >= 0) & (wn >= 0);
-  if (g.need_even) ok &= (((hn | wn) & 1) == 0);
-  int h = hn, w = wn;
-  if (g.div == 2) { h >>= 1; w >>= 1; }
+  ok &= (((hn | wn) & g.need_even) == 0);     // need_even: div - 1 (a transposed gather lands on every div-th position only)
+  const int sh = g.div >> 1;                   // div is 1, 2 or 4
+  int h = hn >> sh, w = wn >> sh;
   ok &= (h < g.H) & (w < g.W);
   valid = valid && ok;
   return (((long)n * g.H + h) * g.W + w) * g.C + c;
@@ -503,6 +503,15 @@ struct OperandDMA {
   // issue this thread's NP LDS-DMA loads of k-tile [k0, k0+BK) into the operand image at `img`
   __device__ __forceinline__ void issue(int k0, int kend, char* img, const NkGather& g, const NkTapW& tw) const {
     const bf16_t* src[NP];
+    sources(k0, kend, src, g, tw);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) fire(i, src[i], img);
+  }
+  // piece i of this wave: 64 lanes x 16 B from per-lane sources, 1 KiB linear in the operand image
+  __device__ __forceinline__ void fire(int i, const bf16_t* s, char* img) const {
+    __builtin_amdgcn_global_load_lds((nk_gptr)s, (nk_lptr)(img + (wave * NP + i) * 1024), 16, 0, 0);
+  }
+  __device__ __forceinline__ void sources(int k0, int kend, const bf16_t* (&src)[NP], const NkGather& g, const NkTapW& tw) const {
     const bf16_t* zp = (const bf16_t*)nk_zero_page;
     if constexpr (MODE == OP_KC) {
       int k = k0 + kc_chunk() * 8;
@@ -556,9 +565,6 @@ struct OperandDMA {
         src[i] = ok ? P + off : zp;
       }
     }
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave * NP + i) * 1024), 16, 0, 0);
   }
 
   // ---- running form (stream-K kernel): the k position and, for the plain strided modes, this thread's source pointers
@@ -576,10 +582,9 @@ struct OperandDMA {
       for (int i = 0; i < NP; ++i) rp[i] = P + (long)(k_begin + mc_k(i)) * ld + r0 + mc_chunk(mc_var(i)) * 8;
     }
   }
-  __device__ __forceinline__ void issue_next(int kend, char* img, const NkGather& g, const NkTapW& tw) {
+  __device__ __forceinline__ void next_sources(int kend, const bf16_t* (&src)[NP], const NkGather& g, const NkTapW& tw) {
     if constexpr (MODE == OP_KC || MODE == OP_MC) {
       const bf16_t* zp = (const bf16_t*)nk_zero_page;
-      const bf16_t* src[NP];
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         bool ok;
@@ -588,13 +593,16 @@ struct OperandDMA {
         src[i] = ok ? rp[i] : zp;
         rp[i] += MODE == OP_KC ? (long)BK : (long)BK * ld;   // (ld is wave-uniform: a scalar multiply)
       }
-#pragma unroll
-      for (int i = 0; i < NP; ++i)
-        __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave * NP + i) * 1024), 16, 0, 0);
     } else {
-      issue(kcur, kend, img, g, tw);
+      sources(kcur, kend, src, g, tw);
     }
     kcur += BK;
+  }
+  __device__ __forceinline__ void issue_next(int kend, char* img, const NkGather& g, const NkTapW& tw) {
+    const bf16_t* src[NP];
+    next_sources(kend, src, g, tw);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) fire(i, src[i], img);
   }
 
   static __device__ __forceinline__ bf16x8_t frag(const char* img, int sub, int ks, int lane) {
@@ -1271,11 +1279,14 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void nk_gemm_big_kernel(
 #define XL_BN 256
 #define XL_STAGE_BYTES 65536
 #define XL_SMEM_BYTES (2 * XL_STAGE_BYTES)
-template <int AMODE>
-__global__ __launch_bounds__(1024, 4) void nk_gemm_xl_kernel(const NkGemmParams p) {
+// WM x WN is the per-wave tile: 64 x 64 (16 waves, 4 per SIMD), 128 x 64 (8 waves, 2 per SIMD) or 128 x 128 (4 waves, 1 per SIMD).
+// Larger wave tiles read fewer fragment bytes from LDS per MFMA (0.5 / 0.375 / 0.25 KiB) at the price of fewer waves to hide them.
+template <int AMODE, int WM, int WN>
+__global__ __launch_bounds__((XL_BM / WM) * (XL_BN / WN) * 64, (XL_BM / WM) * (XL_BN / WN) / 4) void nk_gemm_xl_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WCOLS = XL_BN / WN, NWAVES = (XL_BM / WM) * WCOLS, NP = 32 / NWAVES, MI = WM / 16, NJ = WN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WCOLS, wn = wave % WCOLS;
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -1290,15 +1301,15 @@ __global__ __launch_bounds__(1024, 4) void nk_gemm_xl_kernel(const NkGemmParams 
   const int m0 = (first_m + (in_group - nt * gm)) * XL_BM, n0 = nt * XL_BN;
   const int kend = p.K, nk = (p.K + BK - 1) / BK;
 
-  OperandDMA<AMODE, 2> opa;   // 16 waves x 2 pieces x 8 rows = 256 rows
-  OperandDMA<OP_KC, 2> opb;
+  OperandDMA<AMODE, NP> opa;   // NWAVES x NP pieces x 8 rows = 256 rows
+  OperandDMA<OP_KC, NP> opb;
   opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
   opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
-  float4_t acc[4][4];
+  float4_t acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
   opa.start(0);          // running source pointers: a k-step costs one 64-bit add per piece instead of the row * ld products
   opb.start(0);
   if (nk > 0) {
@@ -1316,25 +1327,154 @@ __global__ __launch_bounds__(1024, 4) void nk_gemm_xl_kernel(const NkGemmParams 
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], bfr[4];
+      bf16x8_t af[MI], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = OperandDMA<OP_KC>::frag(cur, wm * 64 + i * 16, ks, lane);
+      for (int i = 0; i < MI; ++i) af[i] = OperandDMA<OP_KC>::frag(cur, wm * WM + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * 64 + j * 16, ks, lane);
+      for (int j = 0; j < NJ; ++j) bfr[j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * WN + j * 16, ks, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)   // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
+        for (int j = 0; j < NJ; ++j)   // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    float4_t pair[4][2];
+  for (int ib = 0; ib < MI / 4; ++ib)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { pair[i][0] = acc[i][2 * half]; pair[i][1] = acc[i][2 * half + 1]; }
-    reg_epilogue_64x32<0>(p, p.C, pair, m0 + wm * 64, n0 + wn * 64 + half * 32, lane);
+    for (int half = 0; half < NJ / 2; ++half) {
+      float4_t pair[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pair[i][0] = acc[ib * 4 + i][2 * half]; pair[i][1] = acc[ib * 4 + i][2 * half + 1]; }
+      reg_epilogue_64x32<0>(p, p.C, pair, m0 + wm * WM + ib * 64, n0 + wn * WN + half * 32, lane);
+    }
+}
+
+// Software-pipelined form of the 8-wave shape (128 x 64 per wave): a slab is four phases of 16 MFMAs -- (k sub-step, half of the
+// wave's rows) -- and the fragments of phase n + 1 are read from LDS while phase n's MFMAs run, ACROSS the slab boundary too: the
+// barrier sits in front of the last phase, whose MFMAs then cover the first fragment reads of the next slab (in the plain form all
+// waves leave the barrier together and queue on LDS with nothing to multiply).
+template <int AMODE>
+__global__ __launch_bounds__(512, 2) void nk_gemm_xlp_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + XL_BN - 1) / XL_BN, ntm = (p.M + XL_BM - 1) / XL_BM;
+  constexpr int GM = 4;
+  const int per_group = GM * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GM;
+  const int gm = min(GM, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int m0 = (first_m + (in_group - nt * gm)) * XL_BM, n0 = nt * XL_BN;
+  const int kend = p.K, nk = (p.K + BK - 1) / BK;
+
+  OperandDMA<AMODE, NP> opa;
+  OperandDMA<OP_KC, NP> opb;
+  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+  float4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  // Fragment reads are inline asm with hand-counted s_waitcnt lgkmcnt: hipcc waits lgkmcnt(0) in front of every MFMA group, which
+  // would drain the reads just issued for the NEXT phase.  LDS reads return in order, so "all but the youngest n" is exact.  The
+  // sched_barriers keep the MFMAs behind the waits (the compiler believes an asm's outputs are ready at once).
+  bf16x8_t a0[4], a1[4], b0[4], b1[4];
+  typedef __attribute__((address_space(3))) const char* lds_c;
+  const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
+  const unsigned x0 = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4);              // 16-byte slot of k sub-step 0; sub-step 1 is x0 ^ 64
+  const unsigned arow = lds0 + (unsigned)(wm * 128 + (lane & 15)) * 128u;
+  const unsigned brow = lds0 + 32768u + (unsigned)(wn * 64 + (lane & 15)) * 128u;
+  const unsigned a_k0 = arow + x0, a_k1 = arow + (x0 ^ 64u), b_k0 = brow + x0, b_k1 = brow + (x0 ^ 64u);
+#define XLP_RD4(f, addr, OFF)                                                                                  \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[0]) : "v"(addr), "n"((OFF)));                          \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[1]) : "v"(addr), "n"((OFF) + 2048));                   \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[2]) : "v"(addr), "n"((OFF) + 4096));                   \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[3]) : "v"(addr), "n"((OFF) + 6144))
+#define XLP_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+  auto mm = [&](int h, const bf16x8_t (&a)[4], const bf16x8_t (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[h * 4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  opa.start(0);
+  opb.start(0);
+  if (nk > 0) {
+    opa.issue_next(kend, smem, p.ga, p.tw);
+    opb.issue_next(kend, smem + 32768, p.gb, p.tw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nk > 1) {
+      opa.issue_next(kend, smem + XL_STAGE_BYTES, p.ga, p.tw);
+      opb.issue_next(kend, smem + XL_STAGE_BYTES + 32768, p.gb, p.tw);
+    }
+    XLP_RD4(a0, a_k0, 0);
+    XLP_RD4(b0, b_k0, 0);
   }
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned so = (unsigned)(kt & 1) * XL_STAGE_BYTES, sn = so ^ XL_STAGE_BYTES;
+    const unsigned ca0 = a_k0 + so, ca1 = a_k1 + so, cb1 = b_k1 + so, na0 = a_k0 + sn, nb0 = b_k0 + sn;
+    __builtin_amdgcn_sched_barrier(0);
+    XLP_RD4(a1, ca0, 8192);        // (k0, rows 64..127)
+    XLP_WAIT(4);                   // a0, b0 are in
+    mm(0, a0, b0);
+    XLP_RD4(a0, ca1, 0);           // (k1, rows 0..63)
+    XLP_RD4(b1, cb1, 0);
+    XLP_WAIT(8);                   // a1
+    mm(1, a1, b0);
+    XLP_RD4(a1, ca1, 8192);        // (k1, rows 64..127)
+    XLP_WAIT(4);                   // a0, b1
+    mm(0, a0, b1);
+    // every fragment of slab kt is in registers (its stage may be overwritten) and slab kt + 1 has landed -- for this wave; the
+    // barrier makes both true for the workgroup.  (On the last slab the reads below fetch a stale stage and are never used.)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // slab kt + 2 goes into the stage just freed, one 1 KiB piece behind every second MFMA of the last phase: issued in a
+    // burst right after the barrier the pieces of all waves queue on the CU's one address path with no MFMA in flight.
+    // (Past the end the sources are the zero page and the stage is never read: no branch.)
+    char* cur = smem + (kt & 1) * XL_STAGE_BYTES;
+    const bf16_t* sa[NP];
+    const bf16_t* sb[NP];
+    opa.next_sources(kend, sa, p.ga, p.tw);
+    opb.next_sources(kend, sb, p.gb, p.tw);
+    __builtin_amdgcn_sched_barrier(0);
+    XLP_RD4(a0, na0, 0);
+    XLP_RD4(b0, nb0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[4 + i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      opa.fire(i, sa[i], cur);
+      opb.fire(i, sb[i], cur + 32768);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef XLP_RD4
+#undef XLP_WAIT
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4_t pair[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pair[i][0] = acc[ib * 4 + i][2 * half]; pair[i][1] = acc[ib * 4 + i][2 * half + 1]; }
+      reg_epilogue_64x32<0>(p, p.C, pair, m0 + wm * 128 + ib * 64, n0 + wn * 64 + half * 32, lane);
+    }
 }
 
 static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
@@ -1346,17 +1486,33 @@ static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int
   // at least ~one workgroup per CU, and no more than 12 % of the last column tile wasted (N = 320 / 640 would idle 37 % / 17 %)
   return tiles >= 224 && ntn * XL_BN * 100 <= (long)p.N * 112 && p.K >= 4 * BK;
 }
-template <int AMODE>
-static int launch_xl(const NkGemmParams& p, hipStream_t stream) {
+template <int AMODE, int WM, int WN>
+static int launch_xl_as(const NkGemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = nk_gemm_xl_kernel<AMODE>;
+  auto kern = nk_gemm_xl_kernel<AMODE, WM, WN>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES);
     attr_set = true;
   }
   dim3 grid(((p.M + XL_BM - 1) / XL_BM) * ((p.N + XL_BN - 1) / XL_BN), 1, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(1024), XL_SMEM_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3((XL_BM / WM) * (XL_BN / WN) * 64), XL_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_xl_kernel");
+}
+template <int AMODE>
+static int launch_xl(const NkGemmParams& p, hipStream_t stream) {
+  static int shape = -1;   // NK_GEMM_XL_WAVES = 16 (default) | 8 | 4
+  if (shape < 0) { const char* e = getenv("NK_GEMM_XL_WAVES"); shape = e ? atoi(e) : 16; }
+  if (shape == 9) {
+    static bool pattr = false;
+    auto kern = nk_gemm_xlp_kernel<AMODE>;
+    if (!pattr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES); pattr = true; }
+    dim3 grid(((p.M + XL_BM - 1) / XL_BM) * ((p.N + XL_BN - 1) / XL_BN), 1, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), XL_SMEM_BYTES, stream, p);
+    return nk_check_launch("nk_gemm_xlp_kernel");
+  }
+  if (shape == 8) return launch_xl_as<AMODE, 128, 64>(p, stream);
+  if (shape == 4) return launch_xl_as<AMODE, 128, 128>(p, stream);
+  return launch_xl_as<AMODE, 64, 64>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -76,7 +76,7 @@ extern "C" int nk_linear_wgrad_batched(const void* const* dy, const void* const*
 static int check_conv(const NkConvDesc* d) {
   NK_CHECK_ARG(d != nullptr);
   NK_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0);
-  NK_CHECK_ARG(d->KH > 0 && d->KW > 0 && (d->stride == 1 || d->stride == 2));
+  NK_CHECK_ARG(d->KH > 0 && d->KW > 0 && (d->stride == 1 || d->stride == 2 || d->stride == 4));
   NK_CHECK_ARG((d->Cin & 7) == 0 && (d->Cout & 7) == 0);
   NK_CHECK_ARG(!(d->upsample && d->stride != 1));
   const int Hin = d->upsample ? 2 * d->H : d->H, Win = d->upsample ? 2 * d->W : d->W;
@@ -132,7 +132,7 @@ extern "C" int nk_conv2d_dgrad(const NkConvDesc* d, const void* dy, const void* 
   g.Ho = Hin; g.Wo = Win; g.KW = d->KW;
   g.rs = 1; g.ks = -1;
   g.off_h = d->pad_t; g.off_w = d->pad_l;
-  g.div = d->stride; g.need_even = d->stride == 2;
+  g.div = d->stride; g.need_even = d->stride - 1;
   g.fWo = make_fastdiv(Win); g.fHoWo = make_fastdiv(Hin * Win);
   g.fC = make_fastdiv(d->Cout); g.fKW = make_fastdiv(d->KW);
   p.A = (const bf16_t*)dy; p.ga = g;
