@@ -173,12 +173,17 @@ int nk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, void*
 int nk_batchnorm_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd, void* dx,
                      float* dgamma, float* dbeta, float* ws, long M, int C, float slope, int accumulate, void* stream);
 
-/* LPIPS pieces (modules/losses/perceptual.py:64-228 over a VGG16 trunk).  ReLU = nk_leaky_relu_* with slope 0.
+/* LPIPS pieces (modules/losses/perceptual.py:64-228 over the AlexNet or VGG16 trunk of extractors.py:11-30).
+ * ReLU = nk_leaky_relu_* with slope 0.
  * maxpool2x2: tokens [N][H][W][C] -> [N][H/2][W/2][C]; the backward routes each window's gradient to its first maximum.
+ * maxpool: k x k windows at stride s, no padding, floor mode (nn.MaxPool2d(k, s); AlexNet's 3 x 3 / 2): [N][H][W][C] ->
+ * [N][(H-k)/s+1][(W-k)/s+1][C]; overlapping windows' gradients add up in the backward.
  * lpips_layer: out[n] (+)= mean_p sum_c w[c] (f0/(|f0|+eps) - f1/(|f1|+eps))^2 over a layer's features [N][HW][C] (normalize_tensor,
  * NetLinLayer, spatial_average: perceptual.py:215-224,198-212); the backward returns upstream[n] * d out[n] / d f1. */
 int nk_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, void* stream);
 int nk_maxpool2x2_bwd(const void* dy, const void* x, void* dx, int N, int H, int W, int C, void* stream);
+int nk_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int s, void* stream);
+int nk_maxpool_bwd(const void* dy, const void* x, void* dx, int N, int H, int W, int C, int k, int s, void* stream);
 long nk_lpips_layer_ws_floats(int N, int HW);
 int nk_lpips_layer_fwd(const void* f0, const void* f1, const float* w, float* out, float* ws, int N, int HW, int C, float eps,
                        int accumulate, void* stream);

@@ -59,6 +59,8 @@ SIGNATURES: dict[str, list] = {
     "nk_leaky_relu_bwd": [vp, vp, vp, i64, f32, vp],
     "nk_maxpool2x2_fwd": [vp, vp, i32, i32, i32, i32, vp],
     "nk_maxpool2x2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "nk_maxpool_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "nk_maxpool_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "nk_lpips_layer_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "nk_lpips_layer_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "nk_batchnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, vp],

@@ -1,18 +1,19 @@
-"""LPIPS perceptual distance (`neurosis.modules.losses.perceptual`, :64-228; Zhang et al. 2018, v0.1) over a VGG16 trunk.
+"""LPIPS perceptual distance (`neurosis.modules.losses.perceptual`, :64-228; Zhang et al. 2018, v0.1) over the AlexNet (the
+reference's default) or the VGG16 trunk.
 
-    d(x, y) = sum_layers mean_pixels sum_c w_c (unit(f_x)_c - unit(f_y)_c)^2,   f = trunk features after relu1_2 ... relu5_3
+    d(x, y) = sum_layers mean_pixels sum_c w_c (unit(f_x)_c - unit(f_y)_c)^2,   f = the trunk's five tapped ReLU outputs
 
-The reference takes the trunk from torchvision (`create_vgg_extractor`, extractors.py:11-20) and the calibrated `lin` weights
-from its package data; here the trunk is the same 13 convolutions under torchvision's parameter names (`pnet.features.N.*`) on
-the implicit-GEMM tile engine, ReLU and 2x2 max-pool as HIP kernels, and each layer's normalise / difference / 1x1 lin / spatial
-mean is ONE kernel (`nk_lpips_layer_fwd`) instead of six feature-map-sized passes.  `fwdb` also returns the backward w.r.t. the
-SECOND image (the reconstruction): the trunk is frozen, so its convolutions only pass gradients through (no weight gradients).
+The reference takes the trunk from torchvision (`create_alexnet_extractor` / `create_vgg_extractor`, extractors.py:11-30) and the
+calibrated `lin` weights from its package data; here the trunk is the same convolutions under torchvision's parameter names
+(`pnet.features.N.*`) on the implicit-GEMM tile engine (AlexNet's 11x11 / stride 4 and 5x5 convolutions included), ReLU and max-pool
+(2x2 / 2 for VGG, overlapping 3x3 / 2 for AlexNet) as HIP kernels, and each layer's normalise / difference / 1x1 lin / spatial mean
+is ONE kernel (`nk_lpips_layer_fwd`) instead of six feature-map-sized passes.  `fwdb` also returns the backward w.r.t. the SECOND
+image (the reconstruction): the trunk is frozen, so its convolutions only pass gradients through (no weight gradients).
 
 Weights: there is no hub access here.  `lin_weights` takes a state dict / .safetensors path with the `linN.model.1.weight`
-tensors (the reference ships them as neurosis/data/lpips/vgg_lpips_v0.1.safetensors; when that package is importable they are
-found automatically); the trunk's ImageNet weights load through `load_state_dict` (torchvision's vgg16 keys) -- without them the
-trunk is random, which `pnet_rand=True` makes explicit.  The AlexNet trunk (stride-4 11x11 convolution, overlapping 3x3 pools) is
-not built.
+tensors (the reference ships them as neurosis/data/lpips/{alex,vgg}_lpips_v0.1.safetensors; when that package is importable they
+are found automatically); the trunk's ImageNet weights load through `load_state_dict` (torchvision's alexnet / vgg16 keys) --
+without them the trunk is random, which `pnet_rand=True` makes explicit.
 """
 from __future__ import annotations
 
@@ -25,44 +26,53 @@ from ... import ops
 from ...nn import Conv2d
 from ...ops import BF16, Img
 
-VGG16_PLAN = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)      # torchvision cfg "D" up to relu5_3
-VGG_TAPS = {3: "relu1", 8: "relu2", 15: "relu3", 22: "relu4", 29: "relu5"}                               # features.N -> name
-VGG_CHANNELS = (64, 128, 256, 512, 512)
+# torchvision layer lists by position in `.features`: ("conv", out channels, kernel, stride, padding) | "relu" | ("pool", kernel, stride)
+VGG16_PLAN = tuple(item for c in (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)
+                   for item in ((("pool", 2, 2),) if c == "M" else (("conv", c, 3, 1, 1), "relu")))[:30]      # cfg "D" up to relu5_3
+ALEX_PLAN = (("conv", 64, 11, 4, 2), "relu", ("pool", 3, 2), ("conv", 192, 5, 1, 2), "relu", ("pool", 3, 2),
+             ("conv", 384, 3, 1, 1), "relu", ("conv", 256, 3, 1, 1), "relu", ("conv", 256, 3, 1, 1), "relu")   # alexnet().features[:12]
+# the reference's PNET_CONFIG (perceptual.py:35-60): channels of the five taps and the features.N each is taken at
+PNET_CONFIG = {
+    "alex": {"channels": (64, 192, 384, 256, 256), "taps": {1: "relu1", 4: "relu2", 7: "relu3", 9: "relu4", 11: "relu5"}, "plan": ALEX_PLAN},
+    "vgg": {"channels": (64, 128, 256, 512, 512), "taps": {3: "relu1", 8: "relu2", 15: "relu3", 22: "relu4", 29: "relu5"}, "plan": VGG16_PLAN},
+}
+VGG_TAPS, VGG_CHANNELS = PNET_CONFIG["vgg"]["taps"], PNET_CONFIG["vgg"]["channels"]
 
 
 class _Trunk(nn.Module):
-    """torchvision.models.vgg16().features[:30] by position: Conv2d at the convolution slots, placeholders elsewhere"""
+    """torchvision's alexnet().features / vgg16().features by position: Conv2d at the convolution slots (so the state-dict keys are
+    torchvision's `features.N.weight / bias`), placeholders at the ReLU and pooling slots."""
 
-    def __init__(self):
+    def __init__(self, plan, taps):
         super().__init__()
         layers, cin = [], 3
-        for item in VGG16_PLAN:
-            if item == "M":
-                layers.append(nn.Identity())                      # MaxPool2d(2, 2)
+        for item in plan:
+            if item != "relu" and item[0] == "conv":
+                _, cout, k, stride, pad = item
+                layers.append(Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad))
+                cin = cout
             else:
-                layers += [Conv2d(cin, item, kernel_size=3, stride=1, padding=1), nn.Identity()]      # Conv2d, ReLU
-                cin = item
+                layers.append(nn.Identity())                      # ReLU / MaxPool2d
         self.features = nn.ModuleList(layers)
-        self.kinds = ["pool" if item == "M" else None for item in VGG16_PLAN]
+        self.plan, self.taps = tuple(plan), dict(taps)
 
     def run(self, x: Img, keep_tape: bool):
-        """(taps: {name: Img}, tape: [(kind, bwd, tap name or None)])"""
+        """(taps: {name: Img}, tape: [(conv bwd | None, relu / pool bwd, tap name or None)])"""
         taps, tape, h, i = {}, [], x, 0
-        n_layers = len(self.features)
-        while i < n_layers:
-            layer = self.features[i]
-            if isinstance(layer, Conv2d):
-                h, b_conv = layer.fwd(h, need_dx=keep_tape)
+        while i < len(self.plan):
+            item = self.plan[i]
+            if item != "relu" and item[0] == "conv":              # a convolution and the ReLU behind it
+                h, b_conv = self.features[i].fwd(h, need_dx=keep_tape)
                 act, b_act = ops.leaky_relu_fwd(h.t, 0.0)
                 h = Img(act, h.N, h.H, h.W)
-                name = VGG_TAPS.get(i + 1)
+                name = self.taps.get(i + 1)
                 if name is not None:
                     taps[name] = h
                 if keep_tape:
                     tape.append((b_conv, b_act, name))
                 i += 2
             else:
-                h, b_pool = ops.maxpool2x2_fwd(h)
+                h, b_pool = ops.maxpool_fwd(h, item[1], item[2])
                 if keep_tape:
                     tape.append((None, b_pool, None))
                 i += 1
@@ -88,20 +98,23 @@ class ScalingLayer(nn.Module):
 
 
 class LPIPS(nn.Module):
-    def __init__(self, pnet_type: str = "vgg", pretrained: bool = True, lpips: bool = True, pnet_rand: bool = False, pnet_tune: bool = False,
+    def __init__(self, pnet_type: str = "alex", pretrained: bool = True, lpips: bool = True, pnet_rand: bool = False, pnet_tune: bool = False,
                  use_dropout: bool = False, spatial: bool = False, freeze: bool = True, verbose: bool = False, lin_weights=None):
         super().__init__()
+        if "vgg" in pnet_type:
+            pnet_type = "vgg"
         if "alex" in pnet_type:
-            raise NotImplementedError("LPIPS over the AlexNet trunk is not built (stride-4 11x11 convolution, overlapping 3x3 pools); use pnet_type='vgg'")
-        if "vgg" not in pnet_type:
-            raise ValueError(f"unknown trunk {pnet_type!r}")
+            pnet_type = "alex"
+        if pnet_type not in PNET_CONFIG:
+            raise KeyError(pnet_type)
         if pnet_tune or spatial or not lpips:
             raise NotImplementedError("pnet_tune / spatial / lpips=False are not used by the autoencoder loss and are not built")
-        self.pnet_type, self.pnet_tune, self.pnet_rand, self.lpips, self.spatial = "vgg", pnet_tune, pnet_rand, lpips, spatial
+        conf = PNET_CONFIG[pnet_type]
+        self.pnet_type, self.pnet_tune, self.pnet_rand, self.lpips, self.spatial = pnet_type, pnet_tune, pnet_rand, lpips, spatial
         self.scaling_layer = ScalingLayer()
-        self.chns, self.L = list(VGG_CHANNELS), len(VGG_CHANNELS)
-        self.pnet_keys = list(VGG_TAPS.values())
-        self.pnet = _Trunk()
+        self.chns, self.L = list(conf["channels"]), len(conf["channels"])
+        self.pnet_keys = list(conf["taps"].values())
+        self.pnet = _Trunk(conf["plan"], conf["taps"])
         self.lin0, self.lin1, self.lin2, self.lin3, self.lin4 = (NetLinLayer(c, use_dropout=use_dropout) for c in self.chns)
         self.lins = nn.ModuleDict(dict(zip(self.pnet_keys, (self.lin0, self.lin1, self.lin2, self.lin3, self.lin4))))
         if pretrained:
@@ -114,11 +127,11 @@ class LPIPS(nn.Module):
             try:
                 from neurosis.data import lpips_checkpoint        # the reference package, when it is installed next to this one
 
-                with lpips_checkpoint("vgg") as state_dict:
+                with lpips_checkpoint(self.pnet_type) as state_dict:
                     source = state_dict
             except Exception as err:
                 raise RuntimeError("LPIPS(pretrained=True) needs the calibrated lin weights: pass lin_weights= (a state dict or the path of "
-                                   "vgg_lpips_v0.1.safetensors), or pretrained=False") from err
+                                   "{alex,vgg}_lpips_v0.1.safetensors), or pretrained=False") from err
         if not isinstance(source, dict):
             from safetensors.torch import load_file
 

@@ -551,6 +551,22 @@ def maxpool2x2_fwd(x: Img):
     return Img(y, x.N, x.H // 2, x.W // 2), bwd
 
 
+def maxpool_fwd(x: Img, kernel_size: int, stride: int):
+    """nn.MaxPool2d(kernel_size, stride) (no padding, floor mode) on channels-last tokens.  (y Img, bwd); bwd(dy tokens) -> dx tokens"""
+    if kernel_size == 2 and stride == 2 and x.H % 2 == 0 and x.W % 2 == 0:
+        return maxpool2x2_fwd(x)
+    Ho, Wo = (x.H - kernel_size) // stride + 1, (x.W - kernel_size) // stride + 1
+    y = torch.empty(x.N * Ho * Wo, x.C, dtype=BF16, device=x.t.device)
+    call("nk_maxpool_fwd", x.t.data_ptr(), y.data_ptr(), x.N, x.H, x.W, x.C, kernel_size, stride, _stream())
+
+    def bwd(dy: Tensor) -> Tensor:
+        dx = torch.empty_like(x.t)
+        call("nk_maxpool_bwd", dy.data_ptr(), x.t.data_ptr(), dx.data_ptr(), x.N, x.H, x.W, x.C, kernel_size, stride, _stream())
+        return dx
+
+    return Img(y, x.N, Ho, Wo), bwd
+
+
 def lpips_layer(f0: Img, f1: Img, w: Tensor, out: Tensor, accumulate: bool, eps: float = 1e-10):
     """out[n] (+)= LPIPS distance of one feature layer (see nk_lpips_layer_fwd); returns bwd(upstream[N]) -> d/d f1 tokens"""
     N, HW, Cc = f0.N, f0.H * f0.W, f0.C

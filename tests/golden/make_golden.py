@@ -482,35 +482,57 @@ class _VGG16Taps(torch.nn.Module):
         return out
 
 
+class _AlexTaps(torch.nn.Module):
+    """alexnet().features[:12] as plain torch modules under torchvision's parameter names, returning the five activations the
+    reference taps (perceptual.py:36-44): features.1/4/7/9/11."""
+
+    def __init__(self):
+        super().__init__()
+        nn = torch.nn
+        self.features = nn.Sequential(
+            nn.Conv2d(3, 64, 11, stride=4, padding=2), nn.ReLU(inplace=False), nn.MaxPool2d(3, 2),
+            nn.Conv2d(64, 192, 5, padding=2), nn.ReLU(inplace=False), nn.MaxPool2d(3, 2),
+            nn.Conv2d(192, 384, 3, padding=1), nn.ReLU(inplace=False), nn.Conv2d(384, 256, 3, padding=1), nn.ReLU(inplace=False),
+            nn.Conv2d(256, 256, 3, padding=1), nn.ReLU(inplace=False))
+
+    def forward(self, x):
+        out, names = {}, {1: "relu1", 4: "relu2", 7: "relu3", 9: "relu4", 11: "relu5"}
+        for i, layer in enumerate(self.features):
+            x = layer(x)
+            if i in names:
+                out[names[i]] = x
+        return out
+
+
 def lpips_case():
     """The reference's LPIPS.forward (scaling layer, normalize_tensor, calibrated lin layers from its package data, spatial average)
-    over the VGG16 stand-in above with synthetic trunk weights, and its gradient w.r.t. the second image."""
+    over the VGG16 / AlexNet stand-ins above with synthetic trunk weights, and its gradient w.r.t. the second image."""
     import neurosis.modules.losses.perceptual as nper
 
-    trunk = _VGG16Taps().eval()
-    shapes = {f"pnet.{k}": list(v.shape) for k, v in trunk.state_dict().items()}
-    trunk.load_state_dict({k[len("pnet."):]: v * 1.6 for k, v in synth_state_dict(shapes).items()})       # (x1.6: keeps ReLU activations from dying out)
-    lp = nper.LPIPS.__new__(nper.LPIPS)
-    torch.nn.Module.__init__(lp)
-    lp.pnet_type, lp.lpips, lp.spatial, lp.pnet = "vgg", True, False, trunk
-    lp.pnet_conf = nper.PNET_CONFIG["vgg"]
-    lp.chns, lp.out_type = lp.pnet_conf["channels"], lp.pnet_conf["out_type"]
-    lp.L, lp.pnet_keys = len(lp.chns), list(lp.pnet_conf["features"].values())
-    lp.scaling_layer = nper.ScalingLayer()
-    lins = [nper.NetLinLayer(c) for c in lp.chns]
-    lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4 = lins
-    lp.lins = torch.nn.ModuleDict(dict(zip(lp.pnet_keys, lins)))
-    lp._load_pretrained("vgg")
-    lp.requires_grad_(False)
-    g = torch.Generator().manual_seed(909)
-    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
-    y = (x + 0.25 * torch.randn(2, 3, 64, 64, generator=g)).clamp(-1, 1).requires_grad_(True)
-    dist = lp(x, y)
-    (dist.reshape(-1) * torch.tensor([1.0, 0.5])).sum().backward()
-    lin = {k: v.clone() for k, v in lp.state_dict().items() if k.startswith("lin") and not k.startswith("lins")}
-    torch.save(dict(x=x, y=y.detach(), distance=dist.detach(), upstream=torch.tensor([1.0, 0.5]), d_y=y.grad.clone(), lin=lin), HERE / "lpips_vgg_tiny.pt")
-    (HERE / "lpips_vgg_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
-    print("lpips:", dist.reshape(-1).tolist(), "grad norm", float(y.grad.norm()))
+    for kind, trunk, gain, hw, seed in (("vgg", _VGG16Taps().eval(), 1.6, (64, 64), 909), ("alex", _AlexTaps().eval(), 1.6, (96, 80), 910)):
+        shapes = {f"pnet.{k}": list(v.shape) for k, v in trunk.state_dict().items()}
+        trunk.load_state_dict({k[len("pnet."):]: v * gain for k, v in synth_state_dict(shapes).items()})   # (gain: keeps ReLU activations from dying out)
+        lp = nper.LPIPS.__new__(nper.LPIPS)
+        torch.nn.Module.__init__(lp)
+        lp.pnet_type, lp.lpips, lp.spatial, lp.pnet = kind, True, False, trunk
+        lp.pnet_conf = nper.PNET_CONFIG[kind]
+        lp.chns, lp.out_type = lp.pnet_conf["channels"], lp.pnet_conf["out_type"]
+        lp.L, lp.pnet_keys = len(lp.chns), list(lp.pnet_conf["features"].values())
+        lp.scaling_layer = nper.ScalingLayer()
+        lins = [nper.NetLinLayer(c) for c in lp.chns]
+        lp.lin0, lp.lin1, lp.lin2, lp.lin3, lp.lin4 = lins
+        lp.lins = torch.nn.ModuleDict(dict(zip(lp.pnet_keys, lins)))
+        lp._load_pretrained(kind)
+        lp.requires_grad_(False)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(2, 3, *hw, generator=g) * 2 - 1
+        y = (x + 0.25 * torch.randn(2, 3, *hw, generator=g)).clamp(-1, 1).requires_grad_(True)
+        dist = lp(x, y)
+        (dist.reshape(-1) * torch.tensor([1.0, 0.5])).sum().backward()
+        lin = {k: v.clone() for k, v in lp.state_dict().items() if k.startswith("lin") and not k.startswith("lins")}
+        torch.save(dict(x=x, y=y.detach(), distance=dist.detach(), upstream=torch.tensor([1.0, 0.5]), d_y=y.grad.clone(), lin=lin), HERE / f"lpips_{kind}_tiny.pt")
+        (HERE / f"lpips_{kind}_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
+        print(f"lpips[{kind}]:", dist.reshape(-1).tolist(), "grad norm", float(y.grad.norm()))
 
 
 def analytic_denoiser(x, sigma, c, *args, **kwargs):

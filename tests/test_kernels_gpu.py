@@ -183,6 +183,12 @@ def test_conv4x4_patchgan_shapes(ops):
     _conv_case(ops, 2, 7, 7, 64, 8, 4, 1, 1)
 
 
+def test_conv_alexnet_shapes(ops):
+    # the LPIPS AlexNet trunk: 11x11 / stride 4 / padding 2 on the (padded) image, and 5x5 / padding 2
+    _conv_case(ops, 2, 35, 31, 8, 64, 11, 4, 2)
+    _conv_case(ops, 2, 9, 7, 64, 192, 5, 1, 2)
+
+
 def test_conv3x3_pad_channels(ops):
     # the 4-channel latent convs run with channels padded to 8 (zeros)
     _conv_case(ops, 2, 16, 16, 8, 320, 3, 1, 1)

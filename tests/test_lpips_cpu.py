@@ -2,6 +2,7 @@
 import json
 from pathlib import Path
 
+import pytest
 import torch
 
 from oracle import lpips_oracle as LO
@@ -11,15 +12,16 @@ from tests.util import rel_err
 G = Path(__file__).resolve().parent / "golden"
 
 
-def trunk_weights():
-    shapes = json.loads((G / "lpips_vgg_tiny_keys.json").read_text())
+def trunk_weights(kind="vgg"):
+    shapes = json.loads((G / f"lpips_{kind}_tiny_keys.json").read_text())
     return {k: v * 1.6 for k, v in synth_state_dict(shapes).items()}
 
 
-def test_lpips_oracle_distance_and_gradient():
-    fx = torch.load(G / "lpips_vgg_tiny.pt", weights_only=False)
+@pytest.mark.parametrize("kind", ["vgg", "alex"])
+def test_lpips_oracle_distance_and_gradient(kind):
+    fx = torch.load(G / f"lpips_{kind}_tiny.pt", weights_only=False)
     y = fx["y"].clone().requires_grad_(True)
-    dist = LO.lpips(trunk_weights(), fx["lin"], fx["x"], y)
+    dist = LO.lpips(trunk_weights(kind), fx["lin"], fx["x"], y, trunk=kind)
     assert dist.shape == fx["distance"].shape and rel_err(dist, fx["distance"]) < 1e-5
     (dist.reshape(-1) * fx["upstream"]).sum().backward()
     assert rel_err(y.grad, fx["d_y"]) < 1e-4

@@ -1,6 +1,6 @@
 """LPIPS on the GPU: max-pool / ReLU / layer-distance kernels against their formulas, and the product's
-LPIPS (VGG16 trunk on the tile engine, fused layer distance, backward to the second image) against the reference's LPIPS.forward
-(tests/golden/lpips_vgg_tiny.pt).  Tolerances: kernels 1e-2; distance 5e-3 relative (measured 9e-4); image gradient cosine >= 0.98 and relative
+LPIPS (AlexNet / VGG16 trunk on the tile engine, fused layer distance, backward to the second image) against the reference's LPIPS.forward
+(tests/golden/lpips_{vgg,alex}_tiny.pt).  Tolerances: kernels 1e-2; distance 5e-3 relative (measured 9e-4); image gradient cosine >= 0.98 and relative
 L2 error <= 0.2 (measured 0.988 / 0.15: 13 bf16 convolutions and 13 ReLU kinks deep, gradient magnitudes ~1e-5)."""
 import json
 from pathlib import Path
@@ -31,6 +31,17 @@ def test_maxpool_and_relu_kernels():
     y, bwd = ops.maxpool2x2_fwd(Img(tok(x), N, H, W))
     assert torch.equal(y.t.float().cpu(), tok(ref.detach().to(torch.bfloat16)).float().cpu())
     assert torch.equal(bwd(tok(dy)).float().cpu(), tok(xr.grad.to(torch.bfloat16)).float().cpu())
+    # AlexNet's overlapping 3x3 / 2 pool (odd and even extents; values quantised so that ties occur and the first-maximum rule matters)
+    for Hh, Ww in ((15, 11), (8, 6)):
+        xq = (torch.randn(N, C, Hh, Ww, generator=g) * 2).round().div(2).to(torch.bfloat16)
+        xr = xq.float().requires_grad_(True)
+        ref = F.max_pool2d(xr, 3, 2)
+        dy = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+        ref.backward(dy.float())
+        y, bwd = ops.maxpool_fwd(Img(tok(xq), N, Hh, Ww), 3, 2)
+        assert (y.H, y.W) == tuple(ref.shape[2:])
+        assert torch.equal(y.t.float().cpu(), tok(ref.detach().to(torch.bfloat16)).float().cpu())
+        assert rel_err(bwd(tok(dy)).float().cpu(), tok(xr.grad).float().cpu()) <= 4e-3      # sums of up to four bf16 gradients, rounded once
     v = torch.linspace(-3, 3, 1024).to(torch.bfloat16).cuda()
     r, b = ops.leaky_relu_fwd(v, 0.0)
     assert torch.equal(r, torch.relu(v)) and torch.equal(b(torch.ones_like(v)).float(), (v > 0).float())
@@ -59,12 +70,12 @@ def test_lpips_layer_kernel(C, HW):
     assert rel_err(out, 2 * ref) <= 1e-4
 
 
-def _lpips():
+def _lpips(kind="vgg"):
     from neurosis_amd.modules.losses import LPIPS
 
-    fx = torch.load(G / "lpips_vgg_tiny.pt", weights_only=False)
-    shapes = json.loads((G / "lpips_vgg_tiny_keys.json").read_text())
-    lp = LPIPS(pnet_type="vgg", lin_weights=fx["lin"])
+    fx = torch.load(G / f"lpips_{kind}_tiny.pt", weights_only=False)
+    shapes = json.loads((G / f"lpips_{kind}_tiny_keys.json").read_text())
+    lp = LPIPS(pnet_type=kind, lin_weights=fx["lin"])
     lp.load_state_dict({k: v * 1.6 for k, v in synth_state_dict(shapes).items()}, strict=False)
     for k, v in fx["lin"].items():
         assert torch.equal(lp.state_dict()[k], v)
@@ -72,11 +83,12 @@ def _lpips():
     return fx, lp.cuda()
 
 
-def test_lpips_against_reference():
+@pytest.mark.parametrize("kind", ["vgg", "alex"])
+def test_lpips_against_reference(kind):
     from neurosis_amd import ops
     from neurosis_amd.ops import Img
 
-    fx, lp = _lpips()
+    fx, lp = _lpips(kind)
     dist = lp(fx["x"].cuda(), fx["y"].cuda())
     assert dist.shape == fx["distance"].shape and rel_err(dist, fx["distance"]) <= 5e-3, (dist.reshape(-1).tolist(), fx["distance"].reshape(-1).tolist())
     B, C, H, W = fx["y"].shape
@@ -92,8 +104,9 @@ def test_lpips_against_reference():
 def test_lpips_needs_weights_or_says_so():
     from neurosis_amd.modules.losses import LPIPS
 
-    with pytest.raises(NotImplementedError):
-        LPIPS(pnet_type="alex", pretrained=False)
+    assert LPIPS(pretrained=False).pnet_type == "alex"            # the reference's default trunk (perceptual.py:67)
+    with pytest.raises(KeyError):
+        LPIPS(pnet_type="squeeze", pretrained=False)
     try:
         import neurosis.data  # noqa: F401
     except Exception:
