@@ -1320,25 +1320,54 @@ __global__ __launch_bounds__((XL_BM / WM) * (XL_BN / WN) * 64, (XL_BM / WM) * (X
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slab kt has landed (this wave's share) ...
     __syncthreads();                                    // ... for every wave, and everyone is done with the other stage
     const char* cur = smem + (kt & 1) * XL_STAGE_BYTES;
+#ifndef XL_ABL_NODMA       // (tools/ablate: the main loop with one of its parts removed; never defined in the product build)
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * XL_STAGE_BYTES;
       opa.issue_next(kend, nxt, p.ga, p.tw);
       opb.issue_next(kend, nxt + 32768, p.gb, p.tw);
     }
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t af[MI], bfr[NJ];
+#ifndef XL_ABL_NOREAD
 #pragma unroll
       for (int i = 0; i < MI; ++i) af[i] = OperandDMA<OP_KC>::frag(cur, wm * WM + i * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) bfr[j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * WN + j * 16, ks, lane);
+#else
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = __builtin_bit_cast(bf16x8_t, (uint4_t){(unsigned)(kt + i), (unsigned)lane, 0x3c003c00u, (unsigned)ks});
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, (uint4_t){(unsigned)(kt - j), (unsigned)wave, 0x3c003c00u, (unsigned)ks});
+#endif
+#ifndef XL_ABL_NOMFMA
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)   // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {   // keep the fragment reads alive with one VALU op per pair
+          const uint4_t ua = __builtin_bit_cast(uint4_t, af[i]), ub = __builtin_bit_cast(uint4_t, bfr[j]);
+          acc[i][j][0] += __uint_as_float((ua[0] ^ ub[3]) & 0x3fffffffu);
+        }
+#endif
     }
   }
+#ifdef XL_ABL_NOEPI
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t != 123.456f) return;      // (practically always: the stores below are kept alive but never run)
+  }
+#endif
 #pragma unroll
   for (int ib = 0; ib < MI / 4; ++ib)
 #pragma unroll
