@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the multi-rank control flow)")
+    ap.add_argument("--wire-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1: dtype of the gradient all-reduce (fp32 = what Lightning DDP exchanges for the reference's fp32 parameters; "
+                         "bf16 halves the bytes on xGMI and sums in bf16)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
@@ -317,7 +320,7 @@ def main():
     unet = eng.model.diffusion_model
     if args.optimizer == "adafactor":
         eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)   # configs/sdxl/sdxl.example.yaml:158-164
-    dp = FlatDataParallel(unet, eng.store) if world > 1 else None
+    dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if args.wire_dtype == "bf16" else None) if world > 1 else None
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     gen_cpu = torch.Generator().manual_seed(42 + rank)
 
@@ -385,7 +388,7 @@ def main():
     if comm_marks:
         exposed = [a.elapsed_time(b) for a, b, _, _ in comm_marks]
         span = [f.elapsed_time(l) for _, _, f, l in comm_marks if f is not None and l is not None]
-        nbytes = eng.store.grad.numel() * eng.store.grad.element_size()
+        nbytes = eng.store.grad.numel() * (2 if args.wire_dtype == "bf16" else eng.store.grad.element_size())
         comm = {"allreduce_bytes_per_step": nbytes, "exposed_ms_mean": round(sum(exposed) / len(exposed), 2),
                 "first_to_last_collective_ms_mean": round(sum(span) / max(len(span), 1), 2) if span else None,
                 "busbw_GBps_over_span": round(nbytes * 2 * (world - 1) / world / (sum(span) / len(span) * 1e-3) / 1e9, 1) if span else None,
@@ -430,7 +433,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SDXL-base {'mixed-res buckets (~1024^2 pixels)' if args.mixed_res else str(args.res) + '^2'} bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, {'frozen TE outputs synthetic' if args.precomputed_te else 'frozen CLIP-L + OpenCLIP-bigG conditioner on synthetic token ids'}",
-                       "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}", "activation_checkpointing": False, "accumulate_grad_batches": args.accumulate},
+                       "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}", "allreduce_dtype": args.wire_dtype, "activation_checkpointing": False, "accumulate_grad_batches": args.accumulate},
             "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "step_ms_in_order": [round(t, 1) for t in in_order], "comm": comm,
             "stream_k_fixup_timeouts": lib.query("nk_gemm_sk_status"),   # 0: every K-split tile was joined (gemm.hip)
