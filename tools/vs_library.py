@@ -20,3 +20,21 @@ for M, N, K in shapes:
     fl = 2.0 * M * N * K
     print(f"M={M:6d} N={N:6d} K={K:5d}: library {t_lib * 1e6:7.1f} us = {fl / t_lib / 1e12:6.0f} TFLOP/s | tile engine {t_mine * 1e6:7.1f} us = {fl / t_mine / 1e12:6.0f} TFLOP/s"
           f" | ratio {t_lib / t_mine:.2f}", flush=True)
+
+if "--wgrad" in sys.argv or "--all" in sys.argv:
+    # weight gradients dW[N, K] = dy[M, N]^T x[M, K] (fp32 out here, bf16 out from the library: an upper bound for it) and
+    # input gradients dx[M, K] = dy[M, N] w[N, K]
+    for M, N, K in [(4096, 1280, 1280), (4096, 3840, 1280), (4096, 10240, 1280), (4096, 1280, 5120), (16384, 640, 640), (16384, 5120, 640), (16384, 640, 2560)]:
+        dy = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+        x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda") * N ** -0.5).to(torch.bfloat16)
+        dw = torch.zeros(N, K, device="cuda")
+        dwl = torch.empty(N, K, device="cuda", dtype=torch.bfloat16)
+        dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+        fl = 2.0 * M * N * K
+        t_lib = bench(lambda: torch.matmul(dy.t(), x, out=dwl))
+        t_mine = bench(lambda: ops.gemm_tn_f32(dy, x, dw, False))
+        t_libd = bench(lambda: torch.matmul(dy, w, out=dx))
+        t_mined = bench(lambda: ops.gemm_nn(dy, w, out=dx))
+        print(f"M={M:6d} N={N:6d} K={K:5d}: wgrad library {fl / t_lib / 1e12:6.0f} | tile engine {fl / t_mine / 1e12:6.0f} TFLOP/s ({t_mine * 1e6:6.1f} us)"
+              f"   dgrad library {fl / t_libd / 1e12:6.0f} | tile engine {fl / t_mined / 1e12:6.0f} TFLOP/s ({t_mined * 1e6:6.1f} us)", flush=True)
