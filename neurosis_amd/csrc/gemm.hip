@@ -1506,6 +1506,138 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xlp_kernel(const NkGemmParams 
     }
 }
 
+// =============================================================================================
+// Two-group phased form of the 256 x 256 kernel (8 waves = 2 row groups x 4, 128 x 64 per wave).  A k-slab is FOUR phases, each
+//   { LDS fragment reads + at most one operand unit of LDS-DMA }  barrier  { 16 MFMAs on one quadrant of the wave's tile }  barrier
+// and the second group runs one barrier BEHIND the first (it takes one extra barrier before the loop, the first group one after
+// it), so at every moment one group's four waves -- one per SIMD -- multiply while the other group reads and stages: the MFMA pipes
+// and the memory path alternate owners instead of idling together.  The slab's operands are four 16 KiB units (A rows 0-127 and
+// 128-255, B rows 0-127 and 128-255; unit Ag is read by group g only), staged by all eight waves, never drained:
+//   phase 0 of slab t: A1(t+1)   phase 1: A0(t+1)   phase 3: B0(t+2), B1(t+2) into the CURRENT stage, then s_waitcnt vmcnt(4)
+// With intervals numbered so that group 0 reads in 8t+2q and multiplies in 8t+2q+1 (group 1 one later), the last reads of slab t
+// retire by 8t+4 (B), 8t+5 (A0), 8t+6 (A1) and its buffers are first overwritten in 8t+6 (B), 8t+10 (A0), 8t+8 (A1); slab t+1
+// is first read in 8t+8, after every wave has passed the vmcnt(4) of its phase 3 of slab t (all but the four B pieces just
+// issued have landed) and the barrier behind it.
+// =============================================================================================
+template <int AMODE>
+__global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + XL_BN - 1) / XL_BN, ntm = (p.M + XL_BM - 1) / XL_BM;
+  constexpr int GM = 4;
+  const int per_group = GM * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GM;
+  const int gm = min(GM, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int m0 = (first_m + (in_group - nt * gm)) * XL_BM, n0 = nt * XL_BN;
+  const int kend = p.K, nk = (p.K + BK - 1) / BK;
+
+  OperandDMA<AMODE, 2> a0, a1;     // 8 waves x 2 pieces x 8 rows = 128 rows each
+  OperandDMA<OP_KC, 2> b0, b1;
+  a0.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  a1.init(p.A, p.lda, p.M, m0 + 128, tid, p.ga);
+  b0.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+  b1.init(p.B, p.ldb, p.N, n0 + 128, tid, p.gb);
+  a0.start(0); a1.start(0); b0.start(0); b1.start(0);
+  float4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  bf16x8_t ar[8], bc0[4], bc1[4];      // A: [k sub-step][4 row blocks of the current row half]; B: [k sub-step][2 column blocks]
+  typedef __attribute__((address_space(3))) const char* lds_c;
+  const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
+  const unsigned x0 = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4);              // 16-byte slot of k sub-step 0; sub-step 1 is x0 ^ 64
+  const unsigned arow = lds0 + (unsigned)(wm * 128 + (lane & 15)) * 128u;
+  const unsigned brow = lds0 + 32768u + (unsigned)(wn * 64 + (lane & 15)) * 128u;
+  const unsigned a_k0 = arow + x0, a_k1 = arow + (x0 ^ 64u), b_k0 = brow + x0, b_k1 = brow + (x0 ^ 64u);
+#define X2_RD1(f, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"((OFF)))
+#define X2_RDA(half)                                                                                             \
+  X2_RD1(ar[0], ca0, (half) * 8192); X2_RD1(ar[1], ca0, (half) * 8192 + 2048); X2_RD1(ar[2], ca0, (half) * 8192 + 4096);    \
+  X2_RD1(ar[3], ca0, (half) * 8192 + 6144); X2_RD1(ar[4], ca1, (half) * 8192); X2_RD1(ar[5], ca1, (half) * 8192 + 2048);    \
+  X2_RD1(ar[6], ca1, (half) * 8192 + 4096); X2_RD1(ar[7], ca1, (half) * 8192 + 6144)
+#define X2_RDB(f, half)                                                                                          \
+  X2_RD1(f[0], cb0, (half) * 4096); X2_RD1(f[1], cb0, (half) * 4096 + 2048); X2_RD1(f[2], cb1, (half) * 4096);              \
+  X2_RD1(f[3], cb1, (half) * 4096 + 2048)
+#define X2_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
+#define X2_MM(rb, cb, bf)                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                                             \
+  __builtin_amdgcn_s_setprio(1);                                                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+        acc[(rb) + i][(cb) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks * 2 + j], ar[ks * 4 + i], acc[(rb) + i][(cb) + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0)
+
+  if (nk > 0) {
+    a0.issue_next(kend, smem, p.ga, p.tw);
+    a1.issue_next(kend, smem + 16384, p.ga, p.tw);
+    b0.issue_next(kend, smem + 32768, p.gb, p.tw);
+    b1.issue_next(kend, smem + 49152, p.gb, p.tw);
+    b0.issue_next(kend, smem + XL_STAGE_BYTES + 32768, p.gb, p.tw);     // B of slab 1 (past the end: the zero page, never read)
+    b1.issue_next(kend, smem + XL_STAGE_BYTES + 49152, p.gb, p.tw);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  X2_BAR();
+  if (wm == 1) { X2_BAR(); }               // the second group runs one barrier behind
+  for (int t = 0; t < nk; ++t) {
+    const unsigned so = (unsigned)(t & 1) * XL_STAGE_BYTES;
+    char* cur = smem + so;
+    char* oth = smem + (so ^ XL_STAGE_BYTES);
+    const unsigned ca0 = a_k0 + so, ca1 = a_k1 + so, cb0 = b_k0 + so, cb1 = b_k1 + so;
+    // phase 0: rows 0-63 x columns 0-31 of the wave's tile
+    __builtin_amdgcn_sched_barrier(0);
+    X2_RDB(bc0, 0);
+    X2_RDA(0);
+    a1.issue_next(kend, oth + 16384, p.ga, p.tw);
+    X2_BAR();
+    X2_MM(0, 0, bc0);
+    X2_BAR();
+    // phase 1: rows 0-63 x columns 32-63
+    X2_RDB(bc1, 1);
+    a0.issue_next(kend, oth, p.ga, p.tw);
+    X2_BAR();
+    X2_MM(0, 2, bc1);
+    X2_BAR();
+    // phase 2: rows 64-127 x columns 32-63
+    X2_RDA(1);
+    X2_BAR();
+    X2_MM(4, 2, bc1);
+    X2_BAR();
+    // phase 3: rows 64-127 x columns 0-31; B of slab t + 2 goes into THIS slab's stage (its B reads retired two phases ago)
+    b0.issue_next(kend, cur + 32768, p.gb, p.tw);
+    b1.issue_next(kend, cur + 49152, p.gb, p.tw);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // all but those four pieces: slab t + 1 is complete (this wave's share)
+    X2_BAR();
+    X2_MM(4, 0, bc0);
+    X2_BAR();
+  }
+  if (wm == 0) { X2_BAR(); }               // ... and the first group waits for it here
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the past-the-end zero-page pieces
+#undef X2_RD1
+#undef X2_RDA
+#undef X2_RDB
+#undef X2_BAR
+#undef X2_MM
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4_t pair[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pair[i][0] = acc[ib * 4 + i][2 * half]; pair[i][1] = acc[ib * 4 + i][2 * half + 1]; }
+      reg_epilogue_64x32<0>(p, p.C, pair, m0 + wm * 128 + ib * 64, n0 + wn * 64 + half * 32, lane);
+    }
+}
+
 static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("NK_GEMM_XL"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -1529,8 +1661,20 @@ static int launch_xl_as(const NkGemmParams& p, hipStream_t stream) {
 }
 template <int AMODE>
 static int launch_xl(const NkGemmParams& p, hipStream_t stream) {
-  static int shape = -1;   // NK_GEMM_XL_WAVES = 16 (default) | 8 | 4
-  if (shape < 0) { const char* e = getenv("NK_GEMM_XL_WAVES"); shape = e ? atoi(e) : 16; }
+  // NK_GEMM_XL_WAVES: unset = by operand mode (dense k-contiguous A: the two-group phased kernel, +3..6 % on the Linear shapes;
+  // gathered A: the 16-wave kernel -- the gather's address arithmetic sits in the phased kernel's read phases, where only one wave
+  // per SIMD is there to absorb it: conv forward 781-785 vs 835-840 TFLOP/s); 12 / 16 force one of them; 8, 4, 9 = the variants of
+  // DESIGN 3.1's table
+  static int shape = -1;
+  if (shape < 0) { const char* e = getenv("NK_GEMM_XL_WAVES"); shape = e ? atoi(e) : 0; }
+  if (shape == 12 || (shape == 0 && AMODE == OP_KC)) {
+    static bool gattr = false;
+    auto kern = nk_gemm_xl2g_kernel<AMODE>;
+    if (!gattr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES); gattr = true; }
+    dim3 grid(((p.M + XL_BM - 1) / XL_BM) * ((p.N + XL_BN - 1) / XL_BN), 1, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), XL_SMEM_BYTES, stream, p);
+    return nk_check_launch("nk_gemm_xl2g_kernel");
+  }
   if (shape == 9) {
     static bool pattr = false;
     auto kern = nk_gemm_xlp_kernel<AMODE>;
