@@ -352,3 +352,15 @@ def test_stream_k_under_contention(ops, monkeypatch):
     for o in outs:
         assert torch.equal(o, want)     # deterministic fix-up order: bitwise equal
     assert lib.query("nk_gemm_sk_status") == 0
+
+
+def test_256x256_kernels_agree_bit_for_bit():
+    """The two-group phased kernel against the 16-wave kernel (same accumulation order => identical bits), each in its own process
+    over seeded inputs at the ragged and the full SDXL shapes, repeated under load from a second stream: tools/race_screen_xl.py."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    tool = Path(__file__).resolve().parent.parent / "tools" / "race_screen_xl.py"
+    run = subprocess.run([sys.executable, str(tool), "6"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "race screen: clean" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]

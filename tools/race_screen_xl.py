@@ -1,0 +1,57 @@
+"""Race screen for the 256x256 kernels: the two-group phased kernel (NK_GEMM_XL_WAVES=12) and the 16-wave kernel (=16) accumulate in the
+same order, so their outputs must agree BIT FOR BIT; each runs in its own process over the same seeded inputs, many repeats per shape,
+while a second stream keeps the chip busy with other GEMMs (memory load moves DMA landing times).   python tools/race_screen_xl.py [repeats]"""
+import hashlib, os, subprocess, sys
+
+SHAPES = [(65536, 1280, 1280), (4096, 3840, 1280), (4096, 10240, 1280), (16384, 5120, 640), (16300, 4104, 264), (4000, 3600, 328), (8192, 7680, 2048), (32768, 2048, 320)]
+
+
+def worker(repeats):
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from neurosis_amd import ops
+
+    side = torch.cuda.Stream()
+    noise_a = torch.randn(8192, 2048, device="cuda").to(torch.bfloat16)
+    noise_b = torch.randn(2048, 2048, device="cuda").to(torch.bfloat16)
+    for M, N, K in SHAPES:
+        g = torch.Generator(device="cuda").manual_seed(M + 7 * N + 13 * K)
+        x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda", generator=g)
+        h = hashlib.sha256()
+        first = None
+        for r in range(repeats):
+            if r % 2:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        ops.gemm_nn(noise_a, noise_b)
+            y = ops.gemm_nt(x, w, b)
+            torch.cuda.synchronize()
+            if first is None:
+                first = y.clone()
+                h.update(y.view(torch.int16).cpu().numpy().tobytes())
+            elif not torch.equal(first, y):
+                print(f"UNSTABLE {M} {N} {K} repeat {r}: {int((first != y).sum())} elements differ", flush=True)
+        print(f"{M} {N} {K} {h.hexdigest()}", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        worker(int(sys.argv[2]))
+        sys.exit(0)
+    repeats = sys.argv[1] if len(sys.argv) > 1 else "12"
+    outs = {}
+    for waves in ("16", "12"):
+        env = dict(os.environ, NK_GEMM_XL_WAVES=waves)
+        outs[waves] = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", repeats], env=env, capture_output=True, text=True).stdout.strip().splitlines()
+    bad = 0
+    for a, b in zip(outs["16"], outs["12"]):
+        same = a == b and not a.startswith("UNSTABLE")
+        bad += not same
+        print(("ok   " if same else "DIFF ") + a + ("" if same else "   |   " + b))
+    if len(outs["16"]) != len(outs["12"]) or len(outs["16"]) < len(SHAPES):
+        bad += 1
+        print("worker output incomplete", outs)
+    print("race screen:", "clean" if not bad else f"{bad} problems")
+    sys.exit(1 if bad else 0)
