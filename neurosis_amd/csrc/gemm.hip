@@ -1567,16 +1567,21 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
   X2_RD1(f[0], cb0, (half) * 4096); X2_RD1(f[1], cb0, (half) * 4096 + 2048); X2_RD1(f[2], cb1, (half) * 4096);              \
   X2_RD1(f[3], cb1, (half) * 4096 + 2048)
 #define X2_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
-#define X2_MM(rb, cb, bf)                                                                                        \
+#define X2_MM(rb, cb, bf, PREP)                                                                                  \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                                             \
   __builtin_amdgcn_s_setprio(1);                                                                                 \
+  PREP;              /* source addresses of the NEXT phase's DMA: VALU work that issues in the MFMAs' shadow */ \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
         acc[(rb) + i][(cb) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks * 2 + j], ar[ks * 4 + i], acc[(rb) + i][(cb) + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0)
 
+  const bf16_t* sa0[2];
+  const bf16_t* sa1[2];
+  const bf16_t* sb0[2];
+  const bf16_t* sb1[2];
   if (nk > 0) {
     a0.issue_next(kend, smem, p.ga, p.tw);
     a1.issue_next(kend, smem + 16384, p.ga, p.tw);
@@ -1586,6 +1591,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
     b1.issue_next(kend, smem + XL_STAGE_BYTES + 49152, p.gb, p.tw);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   }
+  a1.next_sources(kend, sa1, p.ga, p.tw);                               // A1 of slab 1, fired in phase 0 of slab 0
   X2_BAR();
   if (wm == 1) { X2_BAR(); }               // the second group runs one barrier behind
   for (int t = 0; t < nk; ++t) {
@@ -1597,27 +1603,31 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
     __builtin_amdgcn_sched_barrier(0);
     X2_RDB(bc0, 0);
     X2_RDA(0);
-    a1.issue_next(kend, oth + 16384, p.ga, p.tw);
+    a1.fire(0, sa1[0], oth + 16384);       // A1(t+1)
+    a1.fire(1, sa1[1], oth + 16384);
     X2_BAR();
-    X2_MM(0, 0, bc0);
+    X2_MM(0, 0, bc0, a0.next_sources(kend, sa0, p.ga, p.tw));
     X2_BAR();
     // phase 1: rows 0-63 x columns 32-63
     X2_RDB(bc1, 1);
-    a0.issue_next(kend, oth, p.ga, p.tw);
+    a0.fire(0, sa0[0], oth);               // A0(t+1)
+    a0.fire(1, sa0[1], oth);
     X2_BAR();
-    X2_MM(0, 2, bc1);
+    X2_MM(0, 2, bc1, (void)0);
     X2_BAR();
     // phase 2: rows 64-127 x columns 32-63
     X2_RDA(1);
     X2_BAR();
-    X2_MM(4, 2, bc1);
+    X2_MM(4, 2, bc1, (b0.next_sources(kend, sb0, p.gb, p.tw), b1.next_sources(kend, sb1, p.gb, p.tw)));
     X2_BAR();
     // phase 3: rows 64-127 x columns 0-31; B of slab t + 2 goes into THIS slab's stage (its B reads retired two phases ago)
-    b0.issue_next(kend, cur + 32768, p.gb, p.tw);
-    b1.issue_next(kend, cur + 49152, p.gb, p.tw);
+    b0.fire(0, sb0[0], cur + 32768);
+    b0.fire(1, sb0[1], cur + 32768);
+    b1.fire(0, sb1[0], cur + 49152);
+    b1.fire(1, sb1[1], cur + 49152);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // all but those four pieces: slab t + 1 is complete (this wave's share)
     X2_BAR();
-    X2_MM(4, 0, bc0);
+    X2_MM(4, 0, bc0, a1.next_sources(kend, sa1, p.ga, p.tw));
     X2_BAR();
   }
   if (wm == 0) { X2_BAR(); }               // ... and the first group waits for it here
