@@ -15,10 +15,16 @@
 // ds_read_b128; r-contiguous operands are staged as they lie in memory ([64 k][rows]) and read with
 // gfx950's transposing ds_read_b64_tr_b16, so no operand is ever transposed in HBM.
 //
-// Tile: 128x128x64 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4 MFMA tiles),
-// register-staged double-buffered LDS (global loads for tile t+1 are issued before the MFMAs of
-// tile t and written to LDS after them), one barrier per k-step, XCD-aware block->tile mapping,
-// epilogue staged through LDS so HBM stores are 16 B per lane and row-contiguous.
+// The kernels in this file, all over the same operand loaders, chosen per launch by shape (nk_gemm_dispatch):
+//   nk_gemm_kernel        128x128x64, 4 waves, register-staged double-buffered LDS          (first version; NK_GEMM_V1=1)
+//   nk_gemm_dma_kernel    128x128x64, 8 waves, LDS-DMA (global_load_lds) double buffer, two workgroups per CU: the general kernel
+//   nk_gemm_ring_kernel   the same tile with a 4-stage ring and counted vmcnt for grids of <= one workgroup per CU
+//   nk_gemm_sk_kernel     persistent stream-K over that tile for under-filled bf16-output grids (fix-up through a workspace)
+//   nk_gemm_xl_kernel     256x256x64, 16 waves, one workgroup per CU: large conv-forward grids (gathered A)
+//   nk_gemm_xl2g_kernel   256x256x64, 8 waves in two groups staggered by a barrier, four phases per k-slab: large Linear forward grids
+//   (nk_gemm_big_kernel, nk_gemm_xlp_kernel and the other wave shapes of nk_gemm_xl_kernel are measured variants kept opt-in)
+// All use an XCD-aware block->tile mapping with grouped tile order; bf16 outputs leave through a register-direct
+// permlane16_swap epilogue or an LDS-staged one (16 B per lane, row-contiguous), fp32 weight gradients through vector stores/atomics.
 //
 // Reference call sites this engine serves: K1 conv2d, K3 nn.Linear, and the
 // unfused attention products of the VAE mid block (K10).
