@@ -1661,7 +1661,10 @@ static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int
   const long ntn = (p.N + XL_BN - 1) / XL_BN;
   const long tiles = (long)((p.M + XL_BM - 1) / XL_BM) * ntn;
   // at least ~one workgroup per CU, and no more than 12 % of the last column tile wasted (N = 320 / 640 would idle 37 % / 17 %)
-  return tiles >= 224 && ntn * XL_BN * 100 <= (long)p.N * 112 && p.K >= 4 * BK;
+  // ... and rounds of 256 workgroups that are at least 80 % full (320 tiles would run as two rounds at 62 %: measured 775 vs 847 TFLOP/s
+  // against the 128 x 128 kernel's finer rounds)
+  const long rounds = (tiles + 255) / 256;
+  return tiles >= 224 && tiles * 10 >= rounds * 256 * 8 && ntn * XL_BN * 100 <= (long)p.N * 112 && p.K >= 4 * BK;
 }
 template <int AMODE, int WM, int WN>
 static int launch_xl_as(const NkGemmParams& p, hipStream_t stream) {

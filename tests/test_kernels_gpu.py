@@ -54,7 +54,8 @@ def test_linear_fwd_strided_alpha(ops):
     assert_close(got, 0.25 * xf[:, K:2 * K] @ w.t(), TOL_BF16, "linear_fwd strided")
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 200, 320), (4096, 1280, 640), (8, 1280, 2816)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 200, 320), (4096, 1280, 640), (8, 1280, 2816),
+                                   (4096, 1280, 5120), (4000, 328, 3600)])   # the last two: large grids (ragged M, N, K)
 def test_linear_dgrad(ops, M, N, K):
     dy, w, a = rnd(M, N), rnd(N, K, scale=N ** -0.5), rnd(M, K)
     got = ops.gemm_nn(dev(dy), dev(w), dev(a))
@@ -355,8 +356,9 @@ def test_stream_k_under_contention(ops, monkeypatch):
 
 
 def test_256x256_kernels_agree_bit_for_bit():
-    """The two-group phased kernel against the 16-wave kernel (same accumulation order => identical bits), each in its own process
-    over seeded inputs at the ragged and the full SDXL shapes, repeated under load from a second stream: tools/race_screen_xl.py."""
+    """The two-group phased kernel (Linear forward) against the 16-wave and the 128x128 kernels (same accumulation order =>
+    identical bits; the Linear dgrad shapes ride along as a stability check), each in its own process over seeded inputs at ragged and full SDXL shapes, repeated under load from a second
+    stream: tools/race_screen_xl.py."""
     import subprocess
     import sys
     from pathlib import Path
