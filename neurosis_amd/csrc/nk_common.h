@@ -83,8 +83,7 @@ static inline FastDiv make_fastdiv(unsigned d) {
   return f;
 }
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
-  if (f.d == 1) return n;
-  return (__umulhi(n, f.m) + n) >> f.s;
+  return (__umulhi(n, f.m) + n) >> f.s;      // d == 1 is m = 0, s = 0: the same expression, no branch in the callers' hot loops
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
