@@ -405,15 +405,14 @@ def main():
     roofline = None
     if not args.no_roofline:
         # every rank replays the step (it contains the gradient all-reduce: a collective); only rank 0 reports
-        from neurosis_amd import ops as _ops
-
         timer = GemmTimer()
         timer.install()
-        side, _ops.state.wgrad_stream = _ops.state.wgrad_stream, None  # no overlapping launches while timing kernels
+        est = eng.store.state
+        side, est.wgrad_stream = est.wgrad_stream, None  # no overlapping launches while timing kernels
         try:
             step()
         finally:
-            _ops.state.wgrad_stream = side
+            est.wgrad_stream = side
             timer.uninstall()
         f, ms, n, per = timer.summary()
         ach = f / (ms * 1e-3) / 1e12

@@ -109,10 +109,10 @@ class FlatDataParallel:
             # Only useful with a host-synchronous backend (the gloo rehearsal blocks the host inside all_reduce until the
             # exchange stream's dependencies are done: 14.8 vs 30 s/step); with RCCL the collective is stream-ordered.
             if os.environ.get("NK_DP_JOIN") == "1":
-                ops.join_wgrad_stream()
+                ops.join_wgrad_stream(self.store.params[0])
                 self.reducer.reduce_range(lo, hi)
             else:
-                self.reducer.reduce_range(lo, hi, also_wait=ops.state.wgrad_stream)
+                self.reducer.reduce_range(lo, hi, also_wait=self.store.state.wgrad_stream)
 
     def no_sync(self, flag: bool = True) -> None:
         """Gradient accumulation: skip the exchange on all but the last micro-batch (DDP's no_sync)."""

@@ -191,9 +191,11 @@ class AutoencodingEngine(nn.Module):
         self.store = FlatParamStore(self.get_autoencoder_params())
         if self.discriminator is not None:
             self.disc_store = FlatParamStore(list(self.discriminator.parameters()))
-        ops.state.assume_zeroed = False
-        if ops.state.wgrad_stream is None:
-            ops.state.wgrad_stream = torch.cuda.Stream()
+        if self.store.master.is_cuda:   # one side stream for both stores: their steps alternate, they never run together
+            side = torch.cuda.Stream(device=self.store.master.device)
+            self.store.state.wgrad_stream = side
+            if self.discriminator is not None:
+                self.disc_store.state.wgrad_stream = side
         return self.store
 
     @torch.no_grad()
@@ -272,7 +274,7 @@ class AutoencodingEngine(nn.Module):
             # d nll / d logvar = (-sum(p_rec) / exp(logvar) + numel) / B; the adversarial term does not depend on it
             g = ((rec.numel() - weighted_rec * inv_var) / B).reshape(())
             flat = ops.grad_flat(self.logvar)
-            flat.copy_(g.reshape(flat.shape)) if not ops.state.grad_accumulate else flat.add_(g.reshape(flat.shape))
+            flat.copy_(g.reshape(flat.shape)) if not ops.state_of(self.logvar).grad_accumulate else flat.add_(g.reshape(flat.shape))
         active = self.discriminator is not None and self.global_step >= self.disc_start
         log["nll_loss"] = nll.detach()
         if not active:
@@ -305,13 +307,14 @@ class AutoencodingEngine(nn.Module):
         if self.global_step < self.disc_start:
             return torch.zeros((), device=x.device), log
         loss, d_real, d_fake = self.disc_loss.with_grad(real, fake)
-        ops.state.grad_accumulate = False
+        dstate = self.disc_store.state if getattr(self, "disc_store", None) is not None else ops.state_of(next(self.discriminator.parameters()))
+        dstate.grad_accumulate = False
         b_real(ops.nchw_to_tokens((d_real * self.disc_factor).contiguous(), lr_img.C))
-        ops.state.grad_accumulate = True            # the fake pass adds to the real pass's weight gradients
+        dstate.grad_accumulate = True            # the fake pass adds to the real pass's weight gradients
         try:
             b_fake(ops.nchw_to_tokens((d_fake * self.disc_factor).contiguous(), lf_img.C))
         finally:
-            ops.state.grad_accumulate = False
+            dstate.grad_accumulate = False
         ops.join_wgrad_stream()
         return loss * self.disc_factor, log
 

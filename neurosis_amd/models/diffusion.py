@@ -55,6 +55,12 @@ class DiffusionEngine(nn.Module):
         self.vae_batch_size = vae_batch_size
         self.log_sigmas = log_sigmas
         self.sampler = sampler
+        # models/diffusion.py:43-44,78-79: LightningCLI hands over callables (params -> Optimizer, Optimizer -> LRScheduler);
+        # configure_optimizers() below calls them as the reference's does (:261-296)
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+        self._torch_optimizer = None
+        self._torch_scheduler = None
         self.vae_encoder = None
         self.vae_decoder = None
         if first_stage_model is not None:
@@ -113,13 +119,44 @@ class DiffusionEngine(nn.Module):
         """Re-home the trainable UNet parameters into the flat fp32/bf16/grad buffers (call after .cuda())."""
         self.store = FlatParamStore([p for p in self.model.diffusion_model.parameters() if p.requires_grad])
         # contract: every parameter gradient is OVERWRITTEN by its producer on the first micro-batch of a step
-        # (ops.state.grad_accumulate False) and added to on later ones, so the 10 GB buffer is never zero-filled between steps
-        ops.state.assume_zeroed = False
-        if ops.state.wgrad_stream is None:
-            ops.state.wgrad_stream = torch.cuda.Stream()
+        # (store.state.grad_accumulate False) and added to on later ones, so the 10 GB buffer is never zero-filled between steps
+        self.store.state.assume_zeroed = False
+        if self.store.master.is_cuda:
+            self.store.state.wgrad_stream = torch.cuda.Stream(device=self.store.master.device)
         if self.use_ema:
             self.configure_ema(self.ema_decay_rate)
+        if self.optimizer is not None and self._torch_optimizer is None:
+            self.configure_optimizers()
         return self.store
+
+    def configure_optimizers(self):
+        """models/diffusion.py:261-296: one parameter group for the UNet (plus `initial_lr` from `model.base_lr`), one per
+        trainable embedder; `self.optimizer(param_groups)`, then `self.scheduler(optimizer)`; the same return value.  What
+        comes back must be one of this package's fused optimizers (`neurosis_amd.optimizers.Adafactor` -- the class the example
+        configs name under the prefix swap -- or `.AdamW`): the step is a few HIP launches over the flat buffers, and an eager
+        torch optimizer walking 1 700 parameter views would silently replace it, so anything else is refused."""
+        if self.optimizer is None:
+            return None
+        from ..optimizers import Adafactor, AdamW
+
+        unet_params = {"name": "UNet", "params": [p for p in self.model.parameters() if p.requires_grad]}
+        if getattr(self.model, "base_lr", None) is not None:
+            unet_params["initial_lr"] = self.model.base_lr
+        param_groups = [unet_params]
+        for embedder in getattr(self.conditioner, "embedders", ()):
+            if getattr(embedder, "is_trainable", False):
+                raise NotImplementedError("trainable conditioner embedders are outside the fused training step (SURVEY.md section 8: frozen TE/VAE)")
+        opt = self.optimizer(param_groups) if callable(self.optimizer) and not isinstance(self.optimizer, torch.optim.Optimizer) else self.optimizer
+        if not isinstance(opt, (Adafactor, AdamW)):
+            raise TypeError(f"DiffusionEngine: optimizer {type(opt).__module__}.{type(opt).__name__} cannot be fused; use "
+                            "neurosis_amd.optimizers.Adafactor (the example configs' optimizer under the class_path prefix swap) or neurosis_amd.optimizers.AdamW")
+        self._torch_optimizer = opt
+        if self.store is not None and isinstance(opt, Adafactor):
+            self.adafactor = opt.flat            # bound to the flat buffers now; optimizer_step() drives it
+        if self.scheduler is not None:
+            self._torch_scheduler = self.scheduler(opt) if callable(self.scheduler) and not hasattr(self.scheduler, "get_last_lr") else self.scheduler
+            return {"optimizer": opt, "lr_scheduler": {"scheduler": self._torch_scheduler, "interval": "step"}}
+        return opt
 
     def get_input(self, batch: dict) -> Tensor:
         inputs = batch[self.input_key]
@@ -165,7 +202,7 @@ class DiffusionEngine(nn.Module):
         """Gradient accumulation (Lightning's `accumulate_grad_batches`, configs/sdxl/sdxl.example.yaml): call before the
         backward of micro-batch `micro_batch_index` of an optimizer step.  The first micro-batch overwrites the gradients,
         later ones add; with a FlatDataParallel `dp`, only the last micro-batch exchanges them (DDP's no_sync)."""
-        ops.state.grad_accumulate = micro_batch_index > 0
+        self.store.state.grad_accumulate = micro_batch_index > 0
         if dp is not None:
             dp.no_sync(not last)
 
@@ -186,7 +223,9 @@ class DiffusionEngine(nn.Module):
             raise RuntimeError("call setup_flat_params() first")
         from ..optim import FlatEma
 
-        self.model_ema = FlatEma(self.store, decay, use_num_updates)
+        # names as LitEma sees them: relative to the OpenAIWrapper (models/diffusion.py:96, ema.py:23-29)
+        by_id = {id(p): n for n, p in self.model.named_parameters()}
+        self.model_ema = FlatEma(self.store, decay, use_num_updates, names=[by_id[id(p)] for p in self.store.params])
         return self.model_ema
 
     def optimizer_step(self, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
@@ -208,14 +247,19 @@ class DiffusionEngine(nn.Module):
             self._optimizer_stream.wait_stream(torch.cuda.current_stream())      # gradients (and their exchange) are complete
             scope = torch.cuda.stream(self._optimizer_stream)
         with scope:
-            if getattr(self, "adafactor", None) is not None:
+            opt = self._torch_optimizer
+            if opt is not None and getattr(self, "adafactor", None) is None:
+                opt.step(grad_scale=grad_scale)                      # fused AdamW from the config (or an Adafactor bound late)
+            elif getattr(self, "adafactor", None) is not None:
                 self.adafactor.step(grad_scale)
             else:
                 self.store.adamw_step(lr, betas, eps, weight_decay, grad_scale)
+            if self._torch_scheduler is not None:
+                self._torch_scheduler.step()
             if getattr(self, "model_ema", None) is not None:
                 self.model_ema.update()
         self._optimizer_in_flight = overlap
-        ops.state.grad_accumulate = False
+        self.store.state.grad_accumulate = False
         self.global_step += 1
 
     def join_optimizer(self) -> None:

@@ -102,7 +102,7 @@ class CrossAttention(nn.Module):
         wq, wk, wv = self.to_q.weight, self.to_k.weight, self.to_v.weight
         inner = wq.shape[0]
         self_attn = context is None
-        acc = ops.wgrad_mode
+        acc = lambda: ops.wgrad_mode(wq)
         if self_attn and adjacent(wq, wk, wv):
             # one projection GEMM: [to_q; to_k; to_v] are back to back in the flat parameter store
             w_qkv = torch.as_strided(ops.shadow(wq), (3 * inner, wq.shape[1]), (wq.shape[1], 1))
@@ -116,7 +116,7 @@ class CrossAttention(nn.Module):
                 dqkv = torch.empty_like(qkv)
                 b_att(do, dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:])
                 g_qkv = torch.as_strided(ops.grad_flat(wq), (3 * inner, wq.shape[1]), (wq.shape[1], 1))
-                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dqkv, x, g_qkv, acc()), dqkv, x)
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dqkv, x, g_qkv, acc()), dqkv, x, owner=wq)
                 return ops.gemm_nn(dqkv, w_qkv), None
 
             return y, bwd
@@ -140,7 +140,7 @@ class CrossAttention(nn.Module):
                 dkv = torch.empty_like(kv)
                 dq, _, _ = b_att(do, None, dkv[:, :inner], dkv[:, inner:])
                 g_kv = torch.as_strided(ops.grad_flat(wk), (2 * inner, wk.shape[1]), (wk.shape[1], 1))
-                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dkv, ctx, g_kv, acc()), dkv, ctx)
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dkv, ctx, g_kv, acc()), dkv, ctx, owner=wq)
             else:
                 dq, dk, dv = b_att(do)
 
@@ -148,11 +148,11 @@ class CrossAttention(nn.Module):
                     ops.gemm_tn_f32(dk, ctx, ops.g2d(wk), acc())
                     ops.gemm_tn_f32(dv, ctx, ops.g2d(wv), acc())
 
-                ops.on_wgrad_stream(wg_kv, dk, dv, ctx)
+                ops.on_wgrad_stream(wg_kv, dk, dv, ctx, owner=wq)
             if ops._wgrad_queue is not None and dq.is_contiguous() and x.is_contiguous():
                 ops._wgrad_queue.add(dq, x, ops.g2d(wq))
             else:
-                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dq, x, ops.g2d(wq), acc()), dq, x)
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dq, x, ops.g2d(wq), acc()), dq, x, owner=wq)
             dx = ops.gemm_nn(dq, ops.w2d(wq))
             dctx = None
             if self_attn or need_dctx:

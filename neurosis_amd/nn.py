@@ -122,6 +122,11 @@ class Conv2d(nn.Module):
                 b = torch.zeros(co, device=self.weight.device)
                 b[: self.out_channels] = self.bias.detach()
                 bp = nn.Parameter(b, requires_grad=self.weight.requires_grad)
+        # the stand-ins always overwrite their own small gradient (folded back below) but share the engine's side stream
+        st = ops.state_of(self.weight).derived()
+        wp._nk_state = st
+        if bp is not None:
+            bp._nk_state = st
         self._pad_cache = (stamp, wp, bp)
         return wp, bp
 
@@ -135,15 +140,11 @@ class Conv2d(nn.Module):
         out, b = ops.conv2d_fwd(x, wp, bp, self.stride, self.padding, upsample, rowvec, residual, need_dx, self.asym_pad)
 
         def bwd(dy: Tensor):
-            acc = ops.state.grad_accumulate
-            ops.state.grad_accumulate = False
-            try:
-                res = b(dy)
-            finally:
-                ops.state.grad_accumulate = acc
+            acc = ops.state_of(self.weight).grad_accumulate
+            res = b(dy)
             if not self.weight.requires_grad:
                 return res
-            ops.join_wgrad_stream()
+            ops.join_wgrad_stream(wp)
             with torch.no_grad():  # fold the padded gradient back (a few thousand elements)
                 g = wp.grad[: self.out_channels, : self.in_channels]
                 ops.grad_flat(self.weight)
@@ -217,6 +218,11 @@ class FlatParamStore:
         self.exp_avg: Optional[Tensor] = None
         self.exp_avg_sq: Optional[Tensor] = None
         self.step_count = 0
+        self.epoch = 0          # bumped whenever THIS store's masters / shadows change (ops.shadow compares against it)
+        self.listeners = []     # objects with masters_changed(): state derived from the masters (Adafactor RMS sums, EMA seed)
+        # backward-health word: kernels that detect an unusable result (a stream-K fix-up that gave up) raise it; the fused
+        # optimizer kernels refuse to apply an update while it is set (models/diffusion.DiffusionEngine.optimizer_step)
+        self.state = ops.EngineState()
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):
                 n = p.numel()
@@ -236,19 +242,28 @@ class FlatParamStore:
             return flat[off:off + n].view(O, KH, KW, I).permute(0, 3, 1, 2)
         return flat[off:off + n].view(p.shape)
 
+    def add_listener(self, obj) -> None:
+        if all(o is not obj for o in self.listeners):
+            self.listeners.append(obj)
+
     def refresh(self) -> None:
-        """Recompute every bf16 shadow from the fp32 masters (after load_state_dict or an external optimizer)."""
+        """The fp32 masters were changed from OUTSIDE the fused optimizers (load_state_dict, broadcast, EMA swap): recompute
+        every bf16 shadow and tell whoever keeps state derived from the masters."""
         call("nk_cast_f32_to_bf16", self.master.data_ptr(), self.shadow.data_ptr(), self.numel, ops._stream())
         self._mark_fresh()
+        for o in self.listeners:
+            o.masters_changed()
+
+    masters_changed = refresh
 
     def _mark_fresh(self) -> None:
-        ops.state.param_epoch += 1
-        for p in self.params:
-            p._nk_shadow_epoch = ops.state.param_epoch
+        """Shadows are current (a fused optimizer step rewrote them together with the masters, or refresh() did)."""
+        self.epoch += 1
+        ops.state.param_epoch += 1      # global "some parameter changed" counter: keys of captured graphs
 
     def zero_grad(self) -> None:
         """Not needed between steps: every parameter gradient is overwritten by its producer on the first micro-batch
-        (ops.state.grad_accumulate False) and added to on the following ones.  Kept for callers that skip parameters."""
+        (store.state.grad_accumulate False) and added to on the following ones.  Kept for callers that skip parameters."""
         self.grad.zero_()
 
     def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, grad_scale: float = 1.0) -> None:
@@ -261,6 +276,35 @@ class FlatParamStore:
              self.shadow.data_ptr(), self.numel, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
              int(self.step_count), float(grad_scale), ops._stream())
         self._mark_fresh()
+
+    # -- checkpointing of the fused AdamW state (torch.optim.AdamW's per-parameter keys) -----------------
+    def optimizer_state_dict(self) -> dict:
+        state = {}
+        if self.exp_avg is not None:
+            for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self._view(self.exp_avg, off, p).detach().clone().contiguous(),
+                            "exp_avg_sq": self._view(self.exp_avg_sq, off, p).detach().clone().contiguous()}
+        return {"state": state, "param_groups": [{"params": list(range(len(self.params)))}]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        state = sd.get("state", {})
+        if not state:
+            self.exp_avg = self.exp_avg_sq = None
+            self.step_count = 0
+            return
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.master)
+            self.exp_avg_sq = torch.zeros_like(self.master)
+        steps = set()
+        with torch.no_grad():
+            for i, st in state.items():
+                p, off = self.params[int(i)], self.offsets[int(i)]
+                self._view(self.exp_avg, off, p).copy_(st["exp_avg"])
+                self._view(self.exp_avg_sq, off, p).copy_(st["exp_avg_sq"])
+                steps.add(int(st["step"]))
+        if len(steps) != 1:
+            raise ValueError(f"FlatParamStore.load_optimizer_state_dict: per-parameter step counts differ ({sorted(steps)})")
+        self.step_count = steps.pop()
 
     def param_range(self, module: nn.Module) -> tuple[int, int]:
         """[lo, hi) element range of the flat buffers covered by `module`'s parameters."""

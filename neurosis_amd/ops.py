@@ -13,6 +13,7 @@ Conventions
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Callable, Optional
 
@@ -25,39 +26,64 @@ from .lib import NkAttnDesc, NkConvDesc, call, query
 BF16 = torch.bfloat16
 
 
-class _State:
-    grad_accumulate = False  # False: weight-grad kernels overwrite; True: they add (micro-batch accumulation)
-    assume_zeroed = False  # True: a caller guarantees .grad buffers are all-zero before the first micro-batch (split-K skips its memset)
-    param_epoch = 0  # bumped whenever fp32 masters change (optimizer step / load_state_dict)
-    wgrad_stream = None  # optional side HIP stream: weight-gradient GEMMs run there, concurrently with the dgrad chain
-    # same-shape weight gradients of one transformer block as ONE batched launch (nk_linear_wgrad_batched).  Measured
-    # 215 vs 210 ms/step: on the side stream the under-filled grids already overlap the dgrad chain, and deferring them to the
-    # end of the block only delays that overlap -- so off by default.
-    batch_wgrads = False
-    # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):
-    # 210 more cross-stream waits per step delay the weight-gradient GEMMs queued behind them.  Off.
-    norm_params_on_side_stream = False
+class EngineState:
+    """Training-step flags of ONE engine (= one FlatParamStore; `store.state`).  They used to be process-global, which let two
+    engines in one process (the GAN step's autoencoder and discriminator stores, a test next to a model) leak the accumulate
+    flag and the side stream into each other.  Parameters that belong to no store use the default instance `ops.state`."""
+
+    _live = weakref.WeakSet()
+
+    def __init__(self, wgrad_stream=None):
+        self.grad_accumulate = False  # False: weight-grad kernels overwrite; True: they add (micro-batch accumulation)
+        self.assume_zeroed = False  # True: a caller guarantees .grad buffers are all-zero before the first micro-batch (split-K skips its memset)
+        self.wgrad_stream = wgrad_stream  # optional side HIP stream: weight-gradient GEMMs run there, concurrently with the dgrad chain
+        # same-shape weight gradients of one transformer block as ONE batched launch (nk_linear_wgrad_batched).  Measured
+        # 215 vs 210 ms/step: on the side stream the under-filled grids already overlap the dgrad chain, and deferring them to the
+        # end of the block only delays that overlap -- so off by default.
+        self.batch_wgrads = False
+        # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):
+        # 210 more cross-stream waits per step delay the weight-gradient GEMMs queued behind them.  Off.
+        self.norm_params_on_side_stream = False
+        EngineState._live.add(self)
+
+    def derived(self) -> "EngineState":
+        """A state that shares this one's side stream but always overwrites (channel-padded stand-in parameters)."""
+        return EngineState(self.wgrad_stream)
 
 
-state = _State()
+state = EngineState()
+state.param_epoch = 0  # process-wide "some parameter changed" counter (keys of captured graphs); bumped by every store
 
 
-def wgrad_mode() -> int:
-    """accumulate argument of the weight-gradient kernels (see include/neurosis_hip.h)."""
-    if state.grad_accumulate:
+def state_of(p) -> EngineState:
+    """The engine state that governs parameter `p`: its own tag, its store's, or the default."""
+    if p is not None:
+        st = getattr(p, "_nk_state", None)
+        if st is not None:
+            return st
+        store = getattr(p, "_nk_store", None)
+        if store is not None:
+            return store.state
+    return state
+
+
+def wgrad_mode(p=None) -> int:
+    """accumulate argument of the weight-gradient kernels (see include/neurosis_hip.h) for parameter `p`."""
+    st = state_of(p)
+    if st.grad_accumulate:
         return 1
-    return 2 if state.assume_zeroed else 0
+    return 2 if st.assume_zeroed else 0
 
 
-def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor) -> None:
-    """Run `fn` (kernels that only WRITE parameter gradients) on the side stream if one is configured.
+def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None) -> None:
+    """Run `fn` (kernels that only WRITE parameter gradients of `owner`'s engine) on that engine's side stream if it has one.
 
     Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads them until the optimizer /
     all-reduce), and most of them -- like the dgrad GEMMs they sit next to -- do not fill 256 CUs x 2 workgroups on
     their own (e.g. 1280x1280 outputs = 100 tiles).  Issuing them on a second HIP stream lets the hardware co-schedule
     both kernels' workgroups, which recovers the tile-quantisation tail of each without split-K atomics.
     `reads` are the activation tensors fn consumes: they are pinned to the side stream for the caching allocator."""
-    side = state.wgrad_stream
+    side = state_of(owner).wgrad_stream
     if side is None:
         fn()
         return
@@ -73,8 +99,9 @@ class WgradQueue:
     """Collects weight-gradient GEMMs and issues those of identical shape as ONE batched launch (blockIdx.z).
     Used per transformer block: its attn1.to_out / attn2.to_q / attn2.to_out gradients are three 100-tile grids."""
 
-    def __init__(self):
+    def __init__(self, owner=None):
         self.items = []  # (dy, x, dw2d)
+        self.owner = owner
 
     def add(self, dy: Tensor, x: Tensor, dw: Tensor) -> None:
         self.items.append((dy, x, dw))
@@ -88,7 +115,7 @@ class WgradQueue:
             dy, x, dw = it
             key = (dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), dw.stride(0))
             groups.setdefault(key, []).append(it)
-        mode = wgrad_mode()
+        mode = wgrad_mode(self.owner)
 
         def run():
             for (M, N, K, lddy, ldx, lddw), its in groups.items():
@@ -102,7 +129,7 @@ class WgradQueue:
                     call("nk_linear_wgrad_batched", arr(*[c[0].data_ptr() for c in chunk]), arr(*[c[1].data_ptr() for c in chunk]),
                          arr(*[c[2].data_ptr() for c in chunk]), n, M, N, K, lddy, ldx, lddw, mode, _stream())
 
-        on_wgrad_stream(run, *[t for it in items for t in it[:2]])
+        on_wgrad_stream(run, *[t for it in items for t in it[:2]], owner=self.owner)
 
 
 _wgrad_queue: Optional[WgradQueue] = None
@@ -112,10 +139,13 @@ class batched_wgrads:
     """Context manager: inside it, linear_fwd's backward defers bias-free bookkeeping of weight gradients to a queue that is
     flushed (batched by shape) on exit."""
 
+    def __init__(self, owner=None):
+        self.owner = owner      # a parameter of the block: selects the engine whose flags apply
+
     def __enter__(self):
         global _wgrad_queue
         self.prev = _wgrad_queue
-        _wgrad_queue = WgradQueue() if state.batch_wgrads else None
+        _wgrad_queue = WgradQueue(self.owner) if state_of(self.owner).batch_wgrads else None
         return _wgrad_queue
 
     def __exit__(self, *exc):
@@ -126,10 +156,20 @@ class batched_wgrads:
         return False
 
 
-def join_wgrad_stream() -> None:
-    """Make the current stream wait for every weight-gradient kernel issued so far."""
-    if state.wgrad_stream is not None:
-        torch.cuda.current_stream().wait_stream(state.wgrad_stream)
+def join_wgrad_stream(owner=None) -> None:
+    """Make the current stream wait for every weight-gradient kernel issued so far (on `owner`'s engine's side stream, or, with
+    no owner, on every live engine's)."""
+    if owner is not None:
+        side = state_of(owner).wgrad_stream
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        return
+    seen = set()
+    for st in list(EngineState._live):
+        side = st.wgrad_stream
+        if side is not None and id(side) not in seen:
+            seen.add(id(side))
+            torch.cuda.current_stream().wait_stream(side)
 
 
 def _ws(n_floats: int, device) -> Tensor:
@@ -183,17 +223,16 @@ def _param_stamp(p: Tensor):
     updated by raw-pointer kernels, which torch's version counter does not see: they go by the global epoch the store bumps.
     Everything else (frozen VAE / text-encoder weights, stand-alone modules) goes by the tensor's own version counter and
     address, so that an optimizer step on the UNet does not invalidate 850 M frozen parameters' shadows every step."""
-    if getattr(p, "_nk_store", None) is not None:
-        return ("epoch", state.param_epoch)
+    st = getattr(p, "_nk_store", None)
+    if st is not None:
+        return ("epoch", id(st), st.epoch)
     return ("version", p._version, p.data_ptr())
 
 
 def shadow(p: Tensor) -> Tensor:
     """bf16 copy of an fp32 parameter in the same physical layout (flat store view, or cached cast)."""
     if getattr(p, "_nk_store", None) is not None:
-        if getattr(p, "_nk_shadow_epoch", -1) != state.param_epoch:
-            p._nk_store.refresh()      # store-managed: the store refreshes all shadows at once
-        return p._nk_shadow
+        return p._nk_shadow            # store-managed: rewritten with the masters by the fused optimizers / store.refresh()
     s = getattr(p, "_nk_shadow", None)
     stamp = _param_stamp(p)
     if s is not None and getattr(p, "_nk_shadow_stamp", None) == stamp:
@@ -360,16 +399,16 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
         if queued:
             _wgrad_queue.add(dy, x, g2d(weight))
 
-        acc = state.grad_accumulate   # every parameter gradient is OVERWRITTEN by its (single) producer unless accumulating
+        acc = state_of(weight).grad_accumulate   # every parameter gradient is OVERWRITTEN by its (single) producer unless accumulating
 
         def wg():
             if not queued:
-                gemm_tn_f32(dy, x, g2d(weight), wgrad_mode())
+                gemm_tn_f32(dy, x, g2d(weight), wgrad_mode(weight))
             if bias is not None:
                 colsum(dy, grad_flat(bias), acc)
 
         if not queued or bias is not None:
-            on_wgrad_stream(wg, dy, x)
+            on_wgrad_stream(wg, dy, x, owner=weight)
         if not need_dx:
             return None
         return gemm_nn(dy, w2d(weight), dx_add)
@@ -415,15 +454,15 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
         _check2d(dy, "dy")
         if not dy.is_contiguous():
             raise ValueError("conv2d bwd: dy must be dense")
-        acc = state.grad_accumulate
+        acc = state_of(weight).grad_accumulate
 
         def wg():
-            call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(), _stream())
+            call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(weight), _stream())
             if bias is not None:
                 colsum(dy, grad_flat(bias), acc)
 
         if weight.requires_grad:          # frozen convolutions (the LPIPS trunk) only pass the gradient through
-            on_wgrad_stream(wg, dy, x.t)
+            on_wgrad_stream(wg, dy, x.t, owner=weight)
         drow = None
         if rowvec is not None:
             drow32 = torch.empty(x.N, Cout, dtype=torch.float32, device=dy.device)
@@ -465,7 +504,7 @@ def groupnorm_fwd(x: Img, weight: Tensor, bias: Tensor, groups: int, eps: float,
         ws2 = _ws(nws, dy.device)
         call("nk_groupnorm_bwd", dy.data_ptr(), x.t.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
              _p(dx_add), dx.data_ptr(), grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws2.data_ptr(), N, HW, Cc, groups,
-             int(silu), int(state.grad_accumulate), _stream())
+             int(silu), int(state_of(weight).grad_accumulate), _stream())
         return dx
 
     return Img(y, x.N, x.H, x.W), bwd
@@ -488,14 +527,14 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
              dx.data_ptr(), M, Cc, _stream())
         ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
 
-        acc = state.grad_accumulate
+        acc = state_of(weight).grad_accumulate
 
         def params():   # gamma / beta gradients
             call("nk_layernorm_bwd_params", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                  grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, int(acc), _stream())
 
-        if state.norm_params_on_side_stream:
-            on_wgrad_stream(params, dy, x, mean, rstd, ws)
+        if state_of(weight).norm_params_on_side_stream:
+            on_wgrad_stream(params, dy, x, mean, rstd, ws, owner=weight)
         else:
             params()
         return dx
@@ -599,7 +638,7 @@ def batchnorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Optiona
     def bwd(dy: Tensor) -> Tensor:
         dx = torch.empty_like(x)
         call("nk_batchnorm_bwd", dy.data_ptr(), x.data_ptr(), y.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-             grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), _ws(nws, x.device).data_ptr(), M, Cc, float(slope), int(state.grad_accumulate),
+             grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), _ws(nws, x.device).data_ptr(), M, Cc, float(slope), int(state_of(weight).grad_accumulate),
              _stream())
         return dx
 

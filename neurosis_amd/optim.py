@@ -7,7 +7,10 @@ gradient buffers (`csrc/optim.hip`), rewriting the bf16 shadows in the same pass
 
 Differences, all deliberate: `beta1` (first moment) is not implemented -- the example configs leave it `None`
 (`configs/sdxl/sdxl.example.yaml:158-164`) -- and asking for it raises; state lives in two flat buffers instead of a
-per-parameter dict (`state_dict()` exposes the reference's keys as views).
+per-parameter dict; `state_dict()` / `load_state_dict()` speak the reference optimizer's checkpoint format (per-parameter
+`step`, `exp_avg_sq_row`, `exp_avg_sq_col` / `exp_avg_sq`, `RMS`) so a run resumes with its second moments, step count
+(relative-step warm-up, beta2_t) and per-tensor RMS intact.  `FlatEma` is an `nn.Module` carrying `LitEma`'s buffer names
+(`decay`, `num_updates`, one shadow per parameter), so `model_ema.*` keys of a reference checkpoint load and save unchanged.
 """
 from __future__ import annotations
 
@@ -136,6 +139,12 @@ class FlatAdafactor:
         self.scale = torch.zeros(self.ntensors, dtype=torch.float32, device=dev)
         self.lr_t = torch.zeros(self.ntensors, dtype=torch.float32, device=dev)
         self._p2_valid = False
+        store.add_listener(self)
+
+    def masters_changed(self) -> None:
+        """FlatParamStore hook: the fp32 masters were rewritten from outside (checkpoint load, broadcast, EMA swap): the
+        per-tile sums of p^2 that scale_parameter uses are stale."""
+        self._p2_valid = False
 
     # -- the update -------------------------------------------------------------------------------
     def _args(self, chunk, beta2t: float, rel_step: float, grad_scale: float) -> _Args:
@@ -192,6 +201,51 @@ class FlatAdafactor:
         return {"step": self.step_count, "exp_avg_sq": self.state[int(t["row_off"]):int(t["row_off"]) + p.numel()].view(p.shape)}
 
 
+    # -- checkpointing (torch.optim.Optimizer.state_dict layout, the reference class's keys: adafactor.py:186-204) ------
+    def _rms(self, index: int) -> Tensor:
+        p = self.store.params[index]
+        return (ops._phys_flat(p).float().norm(2) / (p.numel() ** 0.5)).reshape(())
+
+    def state_dict(self) -> dict:
+        """{"state": {i: {...}}, "param_groups": [...]}: parameter i is `store.params[i]` (registration order, as
+        torch numbers them).  Tensors are copies in the reference's logical shapes."""
+        state = {}
+        if self.step_count > 0:
+            for i in range(self.ntensors):
+                st = {k: (v.detach().clone().contiguous() if torch.is_tensor(v) else v) for k, v in self.param_state(i).items()}
+                st["RMS"] = self._rms(i) if self.scale_parameter else 0
+                state[i] = st
+        group = dict(lr=self.lr, eps=self.eps, clip_threshold=self.clip_threshold, decay_rate=self.decay_rate, beta1=None,
+                     weight_decay=self.weight_decay, scale_parameter=self.scale_parameter, relative_step=self.relative_step,
+                     warmup_init=self.warmup_init, params=list(range(self.ntensors)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        state = sd.get("state", {})
+        if not state:
+            self.step_count = 0
+            self.state.zero_()
+            return
+        steps = set()
+        for i, st in state.items():
+            i = int(i)
+            if not 0 <= i < self.ntensors:
+                raise ValueError(f"FlatAdafactor.load_state_dict: parameter index {i} out of range (0..{self.ntensors - 1})")
+            mine = self.param_state(i)
+            for k in ("exp_avg_sq_row", "exp_avg_sq_col", "exp_avg_sq"):
+                if (k in mine) != (k in st):
+                    raise ValueError(f"FlatAdafactor.load_state_dict: parameter {i} is {'not ' if k not in mine else ''}factored here but the checkpoint disagrees ({k})")
+                if k in mine:
+                    if tuple(mine[k].shape) != tuple(st[k].shape):
+                        raise ValueError(f"FlatAdafactor.load_state_dict: {k} of parameter {i} has shape {tuple(st[k].shape)}, expected {tuple(mine[k].shape)}")
+                    mine[k].copy_(st[k].to(mine[k].device, torch.float32))
+            steps.add(int(st["step"]))
+        if len(steps) != 1:
+            raise ValueError(f"FlatAdafactor.load_state_dict: per-parameter step counts differ ({sorted(steps)}); the fused update keeps one")
+        self.step_count = steps.pop()
+        self._p2_valid = False       # RMS(p) is recomputed from the (separately restored) parameters
+
+
 class AdafactorScheduler:
     """Proxy scheduler (adafactor.py:258-291): reports `initial_lr` before the first step, then the optimizer's own lr of
     the first parameter."""
@@ -208,44 +262,106 @@ class AdafactorScheduler:
         pass
 
 
-class FlatEma:
+class FlatEma(torch.nn.Module):
     """`LitEma` (reference modules/ema.py:11-93) for a FlatParamStore: ONE flat fp32 shadow of every trainable parameter,
     updated by one kernel per step.  Same constructor arguments, decay warm-up `min(decay, (1+n)/(10+n))`, and the
-    `store` / `copy_to` / `restore` protocol `DiffusionEngine.ema_scope` uses (models/diffusion.py:247-257)."""
+    `store` / `copy_to` / `restore` protocol `DiffusionEngine.ema_scope` uses (models/diffusion.py:247-257).
 
-    def __init__(self, store, decay: float = 0.9999, use_num_updates: bool = True):
+    Checkpoint format = LitEma's: buffers `decay`, `num_updates` and one buffer per parameter named after it with the dots
+    removed (ema.py:25-29); here those per-parameter entries are views of the flat shadow, written and read through
+    `_save_to_state_dict` / `_load_from_state_dict`.  `names` are the parameter names as LitEma saw them (relative to the
+    wrapped model, e.g. `diffusion_model.input_blocks.0.0.weight`); without names, positional `p<i>` keys are used."""
+
+    def __init__(self, store, decay: float = 0.9999, use_num_updates: bool = True, names=None):
+        super().__init__()
         if decay < 0.0 or decay > 1.0:
             raise ValueError("Decay must be between 0 and 1")
         self.param_store = store
-        self.decay = float(decay)
-        self.num_updates = 0 if use_num_updates else -1
-        self.shadow = store.master.detach().clone()
+        self.register_buffer("decay", torch.tensor(decay, dtype=torch.float32))
+        self.register_buffer("num_updates", torch.tensor(0 if use_num_updates else -1, dtype=torch.int))
+        self._decay = float(decay)                       # host copies: update() must not read the device
+        self._num_updates = 0 if use_num_updates else -1
+        self.shadow = store.master.detach().clone()      # not a registered buffer: saved per parameter (below)
         self.collected: Optional[Tensor] = None
+        names = list(names) if names is not None else [f"p{i}" for i in range(len(store.params))]
+        if len(names) != len(store.params):
+            raise ValueError("FlatEma: one name per store parameter expected")
+        self.m_name2s_name = {n: n.replace(".", "") for n in names}
+        self._s_names = [self.m_name2s_name[n] for n in names]
+        store.add_listener(self)
+
+    def masters_changed(self) -> None:
+        """FlatParamStore hook.  Before the first update the average IS the model (LitEma clones the parameters at
+        construction, after the checkpoint is loaded): follow the new weights.  Later the average is training state of its own."""
+        if self._num_updates <= 0 and self.collected is None:
+            self.shadow.copy_(self.param_store.master)
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self.shadow = fn(self.shadow)
+        return out
 
     def reset_num_updates(self) -> None:
-        self.num_updates = 0
+        self._num_updates = 0
+        self.num_updates.zero_()
 
     def update(self) -> None:
         """ema.py:40-59"""
-        decay = self.decay
-        if self.num_updates >= 0:
+        decay = self._decay
+        if self._num_updates >= 0:
+            self._num_updates += 1
             self.num_updates += 1
-            decay = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+            decay = min(self._decay, (1 + self._num_updates) / (10 + self._num_updates))
         call("nk_ema_flat", self.shadow.data_ptr(), self.param_store.master.data_ptr(), self.shadow.numel(), float(1.0 - decay), ops._stream())
 
-    __call__ = update
+    def forward(self, model=None) -> None:   # LitEma is called as `self.model_ema(self.model)` (models/diffusion.py:244)
+        self.update()
 
-    def copy_to(self) -> None:
+    def copy_to(self, model=None) -> None:
         """ema.py:61-68: the averaged weights become the model's (masters and bf16 shadows)."""
         self.param_store.master.copy_(self.shadow)
         self.param_store.refresh()
 
-    def store(self) -> None:
+    def store(self, parameters=None) -> None:
         self.collected = self.param_store.master.detach().clone()
 
-    def restore(self) -> None:
+    def restore(self, parameters=None) -> None:
         if self.collected is None:
             raise RuntimeError("FlatEma.restore() without store()")
         self.param_store.master.copy_(self.collected)
         self.param_store.refresh()
         self.collected = None
+
+    # -- LitEma-format checkpoint entries ---------------------------------------------------------------
+    def _views(self):
+        st = self.param_store
+        return [(s, st._view(self.shadow, off, p)) for s, p, off in zip(self._s_names, st.params, st.offsets)]
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        for s_name, view in self._views():
+            destination[prefix + s_name] = view if keep_vars else view.detach()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if prefix + "decay" in state_dict:
+            self._decay = float(state_dict[prefix + "decay"])
+        if prefix + "num_updates" in state_dict:
+            self._num_updates = int(state_dict[prefix + "num_updates"])
+        mine = set()
+        for s_name, view in self._views():
+            key = prefix + s_name
+            mine.add(key)
+            if key not in state_dict:
+                if strict:
+                    missing_keys.append(key)
+                continue
+            src = state_dict[key]
+            if tuple(src.shape) != tuple(view.shape):
+                error_msgs.append(f"size mismatch for {key}: checkpoint {tuple(src.shape)}, model {tuple(view.shape)}")
+                continue
+            with torch.no_grad():
+                view.copy_(src)
+        if strict:
+            own = {prefix + "decay", prefix + "num_updates"} | mine
+            unexpected_keys.extend(k for k in state_dict if k.startswith(prefix) and k not in own)

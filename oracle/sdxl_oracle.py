@@ -361,6 +361,53 @@ def edm_loss(net, table: Tensor, x: Tensor, sigma: Tensor, noise: Tensor) -> Ten
     return ((d.float() - x.float()) ** 2).flatten(1).mean(1) * w.float()
 
 
+def rf_xl_coefficients(sigma: Tensor):
+    """RectifiedFlowXLPreconditioning, modules/diffusion/denoiser_preconditioning.py:77-90: (c_skip, c_out, c_in, c_noise)."""
+    c_in = (1.0 / (1.0 + sigma)) / ((1.0 / (sigma + 1.0)) ** 2.0 + (sigma / (sigma + 1.0)) ** 2.0) ** 0.5
+    return torch.ones_like(sigma), -sigma, c_in, 1000.0 * (sigma / (1 + sigma))
+
+
+def rf_weighting(sigma: Tensor, m: float = 0.0, s: float = 1.0) -> Tensor:
+    """RectifiedFlowWeighting.__call__, modules/diffusion/denoiser_weighting.py:38-55 (fp64, as the reference computes it)."""
+    sigma = sigma.to(torch.float64)
+    t = sigma / (1.0 + sigma)
+    cfm = 1 / (1 - t) ** 2
+    half_pi = torch.acos(torch.zeros(1, dtype=torch.float64))[0]
+    pi_w = (1 / (s * (4.0 * half_pi) ** 0.5)) * (1 / (t * (1.0 - t))) * torch.exp(-0.5 * (torch.log(sigma) - m) ** 2 / s ** 2)
+    return cfm * pi_w
+
+
+def noise_with_offset(noise: Tensor, offset: Optional[Tensor], noise_offset: float) -> Tensor:
+    """DiffusionLoss.apply_noise_offset with the drawn per-(sample, channel) `offset` handed in, modules/diffusion/loss.py:32-40
+    (noise_offset clamped to [0, 1] by the constructor, :27-30)."""
+    noise_offset = min(max(noise_offset, 0.0), 1.0)
+    if noise_offset <= 0 or offset is None:
+        return noise
+    return noise + noise_offset * offset.to(noise)
+
+
+def diffusion_loss(net, table: Tensor, x: Tensor, sigma: Tensor, noise: Tensor, loss_type: str = "l2", objective: str = "edm") -> Tensor:
+    """StandardDiffusionLoss._forward + get_loss with injected sigma / noise, modules/diffusion/loss.py:105-157, both objectives
+    and both loss types (BatchMSELoss / BatchL1Loss with reduction "mean" = per-sample mean, losses/functions.py:65-94).
+      edm: z = x + sigma*noise; D = DiscreteDenoiser(EpsPreconditioning)(z) ("D" output); loss = l(D, x) * EpsWeighting(sigma)
+      rf : z = (1-sigma)*x + sigma*noise; F = Denoiser(RectifiedFlowXLPreconditioning) "F" output = raw network output on
+           (z*c_in, c_noise); loss = l(F, noise) * RectifiedFlowWeighting(sigma)                        (loss.py:126-137)
+    Returns loss[B]."""
+    sb = sigma[:, None, None, None]
+    if objective == "rf":
+        z = (1.0 - sb) * x + sb * noise
+        _, _, c_in, c_noise = rf_xl_coefficients(sb)
+        out = net(z * c_in.to(z.dtype), c_noise.reshape(sigma.shape))
+        target, w = noise, rf_weighting(sigma)
+    else:
+        z = x + sb * noise
+        out = eps_denoiser(net, table, z, sigma)
+        target, w = x, sigma ** -2.0
+    diff = out.float() - target.float()
+    per = diff * diff if loss_type == "l2" else diff.abs()
+    return per.flatten(1).mean(1) * w.float()
+
+
 def training_step_loss(unet_sd: SD, unet_cfg: dict, vae_sd: SD, vae_dd: dict, scale_factor: float, image: Tensor,
                        sigma: Tensor, noise: Tensor, context: Tensor, y: Optional[Tensor], table: Optional[Tensor] = None):
     """DiffusionEngine.training_step, models/diffusion.py:205-233 with encode_first_stage :186-197 and

@@ -45,8 +45,14 @@ class _StubLoader(importlib.abc.Loader):
         return m
 
     def exec_module(self, module):
-        if module.__name__ == "lightning.pytorch" or module.__name__ == "pytorch_lightning":
-            module.LightningModule = type("LightningModule", (torch.nn.Module,), {})
+        if module.__name__ in ("lightning", "lightning.pytorch", "pytorch_lightning"):
+            module.__version__ = "2.2.1"       # the reference's pin (pyproject.toml:35); it branches on it (autoencoder.py:61)
+            def _freeze(self):          # LightningModule.freeze(): requires_grad False everywhere + eval()
+                for p_ in self.parameters():
+                    p_.requires_grad = False
+                self.eval()
+
+            module.LightningModule = type("LightningModule", (torch.nn.Module,), {"freeze": _freeze})
             module.LightningDataModule = type("LightningDataModule", (), {})
             module.Callback = type("Callback", (), {})
 
@@ -798,9 +804,182 @@ def dataset_cases():
     print("dataset: lists", {k: len(v) for k, v in out["lists"].items()}, "batches", {k: len(v) for k, v in out["schedule"].items()})
 
 
+# ------------------------------------------------------------------------------------------------
+# round 2: the loss CLASS itself, the engine's own methods, and the example configs' class-path tree
+# ------------------------------------------------------------------------------------------------
+class FixedSigma:
+    """sigma generator stand-in handed to the reference's StandardDiffusionLoss: returns the injected sigmas whatever `t` is
+    (the config's own DiscreteSigmaGenerator always yields 0 under the loss's t ~ U[0,1))."""
+
+    def __init__(self, sigmas):
+        self.sigmas = sigmas
+
+    def __call__(self, n_samples, t=None):
+        return self.sigmas[:n_samples].clone()
+
+
+LOSS_CLASS_CASES = [("edm_l2", dict(loss_type="l2", objective_type="edm")), ("edm_l1", dict(loss_type="l1", objective_type="edm")),
+                    ("edm_l2_offset", dict(loss_type="l2", objective_type="edm", noise_offset=0.1, noise_offset_chance=1.0)),
+                    ("rf_l2", dict(loss_type="l2", objective_type="rf"))]
+
+
+def loss_class_case(nd):
+    """The reference's own `StandardDiffusionLoss._forward` / `get_loss` / `apply_noise_offset` (modules/diffusion/loss.py:
+    32-40,105-157) executed on the tiny SDXL-shaped UNet -- round 1's fixture restated the loss assembly by hand.  The
+    random draws of `_forward` (t, the noise, the per-(sample, channel) offset) come from the global generator after
+    `torch.manual_seed(SEED)`; the fixture stores the tensors they produced so the HIP path can be fed the same ones."""
+    from neurosis.modules.diffusion.loss import StandardDiffusionLoss
+
+    SEED = 4242
+    cfg = UNET_TINY
+    torch.manual_seed(0)
+    net = nd.UNetModel(**cfg).eval()
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synth_state_dict(shapes))
+    g = torch.Generator().manual_seed(77)
+    B, HW = 2, 16
+    x = torch.randn(B, 4, HW, HW, generator=g)
+    ctx = torch.randn(B, 7, cfg["context_dim"], generator=g)
+    y = torch.randn(B, cfg["adm_in_channels"], generator=g)
+    out = {"cfg": cfg, "x": x, "context": ctx, "y": y, "seed": SEED, "cases": {}}
+    for tag, kw in LOSS_CLASS_CASES:
+        sig = torch.tensor([0.6, 0.3]) if kw["objective_type"] == "rf" else torch.tensor([0.8, 4.2])
+        if kw["objective_type"] == "rf":
+            denoiser = nd.Denoiser(preconditioning=nd.RectifiedFlowXLPreconditioning())
+            weighting = nd.RectifiedFlowWeighting() if hasattr(nd, "RectifiedFlowWeighting") else nd.UnitWeighting()
+        else:
+            denoiser = nd.DiscreteDenoiser(preconditioning=nd.EpsPreconditioning(), num_idx=1000, discretization=nd.LegacyDDPMDiscretization())
+            weighting = nd.EpsWeighting()
+        loss_fn = StandardDiffusionLoss(sigma_generator=FixedSigma(sig), loss_weighting=weighting, **kw)
+        for p_ in net.parameters():
+            p_.grad = None
+        # replay of the draws _forward makes, in its order, to record them
+        torch.manual_seed(SEED)
+        _t = torch.rand((B,), dtype=torch.float64)
+        noise = torch.randn_like(x)
+        offset = torch.randn(x.shape[:2] + (1, 1)) if kw.get("noise_offset", 0.0) > 0 else None
+        torch.manual_seed(SEED)
+        loss, extra = loss_fn._forward(nd.OpenAIWrapper(net), denoiser, {"crossattn": ctx, "vector": y}, x, {}, return_dict=True)
+        loss.mean().backward()
+        assert torch.equal(extra["t"], _t)
+        grads = {k: p_.grad.detach().clone() for k, p_ in net.named_parameters() if k in GRAD_KEYS}
+        gnorm = {k: float(p_.grad.norm()) for k, p_ in net.named_parameters()}
+        # apply_noise_offset on its own, seeded, for the CPU check of this package's method
+        torch.manual_seed(SEED + 1)
+        offset_out = loss_fn.apply_noise_offset(noise.clone(), x)
+        out["cases"][tag] = dict(kwargs=kw, sigma=sig, noise=noise, offset=offset, loss=loss.detach(), sigmas_out=extra["sigmas"].detach(), grads=grads,
+                                 grad_norms=gnorm, offset_seed=SEED + 1, offset_out=offset_out, weighting=type(weighting).__name__,
+                                 denoiser="rf" if kw["objective_type"] == "rf" else "discrete_eps")
+        print(f"loss_class {tag}: loss={loss.tolist()}")
+    torch.save(out, HERE / "loss_class_tiny.pt")
+
+
+def engine_case(nd, nmodel):
+    """The reference's own `DiffusionEngine` (models/diffusion.py:35-233) with the Lightning base class stubbed: constructor
+    wiring (`_init_first_stage` with ddconfig.standalone=true, quirk Q4), `get_input`, `encode_first_stage` (chunked by
+    vae_batch_size) and `training_step` on a tiny SDXL-shaped UNet + tiny VAE.  The draws of the loss come from the global
+    generator after manual_seed(SEED), recorded as in loss_class_case."""
+    import neurosis.models.autoencoder as nma
+    import neurosis.models.diffusion as nmd
+    from neurosis.modules.diffusion.loss import StandardDiffusionLoss
+
+    SEED = 999
+    torch.manual_seed(0)
+    net = nd.UNetModel(**UNET_TINY).eval()
+    ushapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synth_state_dict(ushapes))
+    vae = nma.AutoencoderKL(embed_dim=4, ddconfig={k: v for k, v in VAE_TINY.items() if k != "embed_dim"})
+    vshapes = {k: list(v.shape) for k, v in vae.state_dict().items()}
+    vae.load_state_dict(synth_state_dict(vshapes))
+    denoiser = nd.DiscreteDenoiser(preconditioning=nd.EpsPreconditioning(), num_idx=1000, discretization=nd.LegacyDDPMDiscretization())
+    sig = torch.tensor([1.7, 0.25, 6.0])
+
+    class BatchCond(torch.nn.Module):          # conditioner stand-in: the batch already carries the conditioning tensors
+        embedders = []
+
+        def forward(self, batch, force_zero_embeddings=None):
+            return {"crossattn": batch["crossattn"], "vector": batch["vector"]}
+
+    loss_fn = StandardDiffusionLoss(sigma_generator=FixedSigma(sig), loss_weighting=nd.EpsWeighting())
+    # the stubbed LightningModule has no trainer / logger plumbing: give the instance the three members training_step touches
+    nmd.DiffusionEngine.loggers = property(lambda self: [])
+    nmd.DiffusionEngine.save_hyperparameters = lambda self, *a, **k: None
+    nmd.DiffusionEngine.global_step = 0
+    logged = {}
+    nmd.DiffusionEngine.log_dict = lambda self, d, **k: logged.update({kk: vv.detach().clone() for kk, vv in d.items()})
+    eng = nmd.DiffusionEngine(model=net, denoiser=denoiser, first_stage_model=vae, conditioner=BatchCond(), sampler=None, optimizer=None, scheduler=None,
+                              loss_fn=loss_fn, scale_factor=0.13025, input_key="image", vae_batch_size=2)
+    g = torch.Generator().manual_seed(31)
+    B = 3
+    image = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+    batch = {"image": image, "crossattn": torch.randn(B, 7, UNET_TINY["context_dim"], generator=g), "vector": torch.randn(B, UNET_TINY["adm_in_channels"], generator=g)}
+    with torch.no_grad():
+        latents = eng.encode_first_stage(eng.get_input(batch))
+    torch.manual_seed(SEED)
+    _t = torch.rand((B,), dtype=torch.float64)
+    noise = torch.randn_like(latents)
+    torch.manual_seed(SEED)
+    loss_mean = eng.training_step(dict(batch), 0)
+    loss_mean.backward()
+    grads = {k: p_.grad.detach().clone() for k, p_ in net.named_parameters() if k in GRAD_KEYS}
+    sd_keys = sorted(k for k in eng.state_dict().keys())
+    torch.save(dict(unet_cfg=UNET_TINY, vae_cfg=VAE_TINY, image=image, crossattn=batch["crossattn"], vector=batch["vector"], sigma=sig, noise=noise,
+                    latents=latents, loss_mean=loss_mean.detach(), logged=logged, grads=grads, scale_factor=0.13025, vae_batch_size=2, seed=SEED),
+               HERE / "engine_tiny.pt")
+    (HERE / "engine_tiny_keys.json").write_text(json.dumps({"unet": ushapes, "vae": vshapes, "engine_state_dict_keys": sd_keys}, indent=0))
+    print(f"engine: latents {tuple(latents.shape)} loss_mean={float(loss_mean):.6f} logged={ {k: float(v) for k, v in logged.items()} } state_dict keys={len(sd_keys)}")
+
+
+def config_case():
+    """The `model:` tree of the reference's example configs as DATA: for every node that names a class, where it sits, its
+    class_path, the names of its init_args (and their values when they are plain scalars / lists of scalars), and whether that
+    class path resolves in the reference itself.  tests/test_config_classpaths.py walks this with the `neurosis.` ->
+    `neurosis_amd.` prefix swap INTEGRATION.md promises.  (Data derived from the YAML, not the YAML text.)"""
+    import importlib
+
+    import yaml
+
+    def resolves(cp: str) -> bool:
+        mod, _, name = cp.rpartition(".")
+        try:
+            return hasattr(importlib.import_module(mod), name)
+        except Exception:
+            return False
+
+    def plain(v):
+        if isinstance(v, dict):      # e.g. ddconfig: a dict of scalars / lists, no nested class
+            return "class_path" not in v and all(plain(e) for e in v.values())
+        return isinstance(v, (int, float, str, bool, type(None))) or (isinstance(v, list) and all(isinstance(e, (int, float, str, bool)) for e in v))
+
+    out = {}
+    for cfg_path in ("configs/sdxl/sdxl.example.yaml", "configs/sd15/sd15.example.yml"):
+        cfg = yaml.safe_load(open(Path("/root/reference") / cfg_path))
+        nodes = []
+
+        def walk(node, where):
+            if isinstance(node, dict):
+                if "class_path" in node:
+                    ia = node.get("init_args", {}) or {}
+                    nodes.append({"where": where, "class_path": node["class_path"], "init_arg_names": sorted(ia.keys()),
+                                  "plain_init_args": {k: v for k, v in ia.items() if plain(v)}, "resolves_in_reference": resolves(node["class_path"])})
+                    for k, v in ia.items():
+                        walk(v, f"{where}.init_args.{k}")
+                else:
+                    for k, v in node.items():
+                        walk(v, f"{where}.{k}")
+            elif isinstance(node, list):
+                for i, v in enumerate(node):
+                    walk(v, f"{where}[{i}]")
+
+        walk(cfg["model"], "model")
+        out[cfg_path] = {"nodes": nodes, "trainer": {k: cfg["trainer"].get(k) for k in ("precision", "accumulate_grad_batches", "strategy", "devices")}}
+        print(f"config {cfg_path}: {len(nodes)} class nodes; unresolved in the reference itself: {[n['class_path'] for n in nodes if not n['resolves_in_reference']]}")
+    (HERE / "config_class_paths.json").write_text(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes", "lpips"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes", "lpips", "loss_class", "engine", "config"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -829,3 +1008,9 @@ if __name__ == "__main__":
         glue_class_cases(nd)
     if "lpips" in which:
         lpips_case()
+    if "loss_class" in which:
+        loss_class_case(nd)
+    if "engine" in which:
+        engine_case(nd, nmodel)
+    if "config" in which:
+        config_case()

@@ -99,7 +99,7 @@ def test_engine_accumulate_helper_overwrites_then_adds():
     torch.cuda.synchronize()
     assert float((eng.store.grad - 2 * g1).norm() / (2 * g1).norm()) < 1e-2
     eng.optimizer_step(lr=1e-6)
-    assert ops.state.grad_accumulate is False
+    assert eng.store.state.grad_accumulate is False and ops.state.grad_accumulate is False
 
 
 @pytest.mark.parametrize("optimizer", ["adafactor", "adamw"])

@@ -76,8 +76,7 @@ def test_linear_wgrad(ops, M, N, K):
 @pytest.mark.parametrize("M,N,K,count", [(1024, 256, 384, 3), (64, 128, 128, 8), (4096, 1280, 1280, 3)])
 def test_linear_wgrad_batched(ops, M, N, K, count, monkeypatch):
     """`count` same-shape weight gradients in one launch (blockIdx.z) == the launches one by one; also through the queue."""
-    monkeypatch.setattr(ops.state, "assume_zeroed", False)  # an engine built by an earlier test leaves "grads are zero" set
-    monkeypatch.setattr(ops.state, "grad_accumulate", False)
+    assert not ops.state.assume_zeroed and not ops.state.grad_accumulate   # engines keep their flags in their own store.state
     dys, xs = [rnd(M, N) for _ in range(count)], [rnd(M, K) for _ in range(count)]
     q = ops.WgradQueue()
     dws = [torch.full((N, K), 3.0, device="cuda") for _ in range(count)]

@@ -1,0 +1,157 @@
+"""HIP path against fixtures produced by the reference's own `StandardDiffusionLoss._forward / get_loss /
+apply_noise_offset` (edm/l2, edm/l1, edm/l2 + noise offset, rf/l2) and its own `DiffusionEngine.encode_first_stage /
+training_step` (tests/golden/make_golden.py: loss_class_case, engine_case).  Tolerances as in test_modules_gpu.py
+(bf16 MFMA operands vs an fp32 CPU reference): per-sample loss 1e-2 relative, gradient cosine >= 0.99, latents 3e-2."""
+import json
+from functools import partial
+from pathlib import Path
+from unittest import mock
+
+import pytest
+import torch
+
+from tests.golden.make_golden import LOSS_CLASS_CASES, UNET_TINY, VAE_TINY, synth_state_dict
+from tests.util import cosine, rel_err
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+
+
+def _unet(store=True):
+    import neurosis_amd.modules.diffusion as D
+    from neurosis_amd.nn import FlatParamStore
+
+    net = D.UNetModel(**UNET_TINY)
+    net.load_state_dict(synth_state_dict(json.loads((G / "unet_sdxl_tiny_keys.json").read_text())))
+    net = net.cuda()
+    return net, (FlatParamStore(net.parameters()) if store else None)
+
+
+@pytest.mark.parametrize("tag", [t for t, _ in LOSS_CLASS_CASES])
+def test_hip_loss_class_matches_the_reference_class(tag):
+    import neurosis_amd.modules.diffusion as D
+
+    fx = torch.load(G / "loss_class_tiny.pt", weights_only=False)
+    case = fx["cases"][tag]
+    kw = case["kwargs"]
+    net, st = _unet()
+    if kw["objective_type"] == "rf":
+        den, weighting = D.Denoiser(preconditioning=D.RectifiedFlowXLPreconditioning()), D.RectifiedFlowWeighting()
+    else:
+        den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization()).cuda()
+        weighting = D.EpsWeighting()
+    assert type(weighting).__name__ == case["weighting"]
+    lossfn = D.StandardDiffusionLoss(sigma_generator=D.InjectedSigmaGenerator(), loss_weighting=weighting, **kw)
+    cond = {"crossattn": fx["context"].cuda(), "vector": fx["y"].cuda()}
+    # the per-(sample, channel) offset the reference drew: apply_noise_offset asks torch.randn for it (loss.py:37)
+    with mock.patch("torch.randn", side_effect=lambda *a, **k: case["offset"].clone()) if case["offset"] is not None else mock.patch("builtins.id", id):
+        loss = lossfn._forward(D.OpenAIWrapper(net), den, cond, fx["x"].cuda(), {}, sigmas=case["sigma"].cuda(), noise=case["noise"].cuda())
+    assert loss.shape == case["loss"].shape and loss.dtype == torch.float32
+    assert rel_err(loss.detach(), case["loss"]) <= 1e-2, (loss.tolist(), case["loss"].tolist())
+    loss.mean().backward()
+    torch.cuda.synchronize()
+    named = dict(net.named_parameters())
+    gmax = max(case["grad_norms"].values())
+    for k, g in case["grads"].items():
+        if float(g.norm()) > 1e-2 * gmax:
+            assert cosine(named[k].grad, g) >= 0.99, (tag, k, cosine(named[k].grad, g))
+    for k, n in case["grad_norms"].items():
+        if n > 1e-2 * gmax:
+            assert abs(float(named[k].grad.norm()) - n) <= 6e-2 * n, (tag, k)
+
+
+def _engine(**kw):
+    import neurosis_amd.modules.diffusion as D
+    from neurosis_amd.models import AutoencoderKL, DiffusionEngine
+
+    keys = json.loads((G / "engine_tiny_keys.json").read_text())
+    net = D.UNetModel(**UNET_TINY)
+    net.load_state_dict(synth_state_dict(keys["unet"]))
+    vae = AutoencoderKL(embed_dim=4, ddconfig={k: v for k, v in VAE_TINY.items() if k != "embed_dim"})
+    vae.load_state_dict(synth_state_dict(keys["vae"]))
+    den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization())
+    eng = DiffusionEngine(model=net, denoiser=den, first_stage_model=vae, scale_factor=0.13025, input_key="image", vae_batch_size=2,
+                          loss_fn=D.StandardDiffusionLoss(sigma_generator=D.InjectedSigmaGenerator(), loss_weighting=D.EpsWeighting()), **kw).cuda()
+    eng.setup_flat_params()
+    return eng
+
+
+def test_engine_methods_match_the_reference_engine():
+    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    eng = _engine()
+    batch = {"image": e["image"].cuda(), "crossattn": e["crossattn"].cuda(), "vector": e["vector"].cuda()}
+    latents = eng.encode_first_stage(eng.get_input(batch))          # 3 images in chunks of vae_batch_size = 2
+    assert latents.shape == e["latents"].shape
+    assert rel_err(latents.float(), e["latents"]) <= 3e-2 and cosine(latents.float(), e["latents"]) >= 0.999
+    loss = eng.training_step(batch, 0, sigmas=e["sigma"].cuda(), noise=e["noise"].cuda())
+    assert abs(float(loss) - float(e["loss_mean"])) <= 1e-2 * float(e["loss_mean"])
+    for k, v in e["logged"].items():                                   # the reference's log_dict entries (models/diffusion.py:228-231)
+        assert abs(float(eng.last_log[k]) - float(v)) <= 1.5e-2 * abs(float(v)), k
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(eng.model.diffusion_model.named_parameters())
+    for k, g in e["grads"].items():
+        if float(g.norm()) > 1e-6:
+            assert cosine(named[k].grad, g) >= 0.99, k
+
+
+def test_optimizer_and_ema_state_survive_a_checkpoint_round_trip():
+    """Adafactor's factored second moments / step count and the EMA shadow are training state.  Two steps, save
+    (engine.state_dict + optimizer.state_dict), load into a fresh engine, third step on both: bitwise equal parameters,
+    optimizer state and EMA.  The EMA entries carry LitEma's names (modules/ema.py:23-29)."""
+    from neurosis_amd.optimizers import Adafactor, AdafactorScheduler
+
+    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    mk = lambda: _engine(optimizer=partial(Adafactor, scale_parameter=True, relative_step=True, warmup_init=True),
+                         scheduler=partial(AdafactorScheduler, initial_lr=4e-7), use_ema=True, ema_decay_rate=0.99)
+    batch = lambda: {"image": e["image"].cuda(), "crossattn": e["crossattn"].cuda(), "vector": e["vector"].cuda()}
+
+    def step(eng, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        noise = torch.randn(e["noise"].shape, device="cuda", generator=g)
+        eng.training_step(batch(), 0, sigmas=e["sigma"].cuda(), noise=noise).backward()
+        eng.optimizer_step()
+
+    a = mk()
+    assert isinstance(a._torch_optimizer, Adafactor) and a.adafactor is a._torch_optimizer.flat
+    step(a, 1)
+    step(a, 2)
+    sd = {k: v.detach().clone() for k, v in a.state_dict().items()}
+    osd = a._torch_optimizer.state_dict()
+    ema_keys = [k for k in sd if k.startswith("model_ema.")]
+    assert "model_ema.decay" in sd and "model_ema.num_updates" in sd and int(sd["model_ema.num_updates"]) == 2
+    assert "model_ema.diffusion_modelinput_blocks00weight" in sd and sd["model_ema.diffusion_modelinput_blocks00weight"].shape == (32, 4, 3, 3)
+    assert len(ema_keys) == 2 + len(a.store.params)
+    st0 = osd["state"][0]
+    assert int(st0["step"]) == 2 and "RMS" in st0 and ("exp_avg_sq_row" in st0 or "exp_avg_sq" in st0)
+
+    b = mk()
+    missing, unexpected = b.load_state_dict(sd, strict=True)
+    b.store.refresh()
+    b._torch_optimizer.load_state_dict(osd)
+    assert b.adafactor.step_count == 2
+    assert torch.equal(b.model_ema.shadow, a.model_ema.shadow) and torch.equal(b.store.master, a.store.master)
+    assert torch.equal(b.adafactor.state, a.adafactor.state)
+    step(a, 3)
+    step(b, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(a.store.master, b.store.master)
+    assert torch.equal(a.adafactor.state, b.adafactor.state)
+    assert torch.equal(a.model_ema.shadow, b.model_ema.shadow)
+    assert a._torch_scheduler.get_last_lr() == b._torch_scheduler.get_last_lr() and a._torch_scheduler.get_last_lr()[0] != 4e-7
+
+
+def test_masters_changed_refreshes_derived_state():
+    """a checkpoint load / broadcast after the optimizer exists must invalidate Adafactor's per-tile sums of
+    p^2 and, before the first update, re-seed the EMA from the new weights."""
+    from neurosis_amd.optimizers import Adafactor
+
+    eng = _engine(optimizer=partial(Adafactor, scale_parameter=True, relative_step=True, warmup_init=True), use_ema=True)
+    eng.adafactor.refresh_param_norms()
+    assert eng.adafactor._p2_valid
+    with torch.no_grad():
+        eng.store.master.mul_(2.0)
+    eng.store.masters_changed()
+    assert not eng.adafactor._p2_valid
+    assert torch.equal(eng.model_ema.shadow, eng.store.master)
+    assert torch.equal(eng.store.shadow.float(), eng.store.master.bfloat16().float())

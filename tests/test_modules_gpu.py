@@ -106,11 +106,11 @@ def test_gradient_accumulation_and_adamw():
     fx, net, st = _build_unet("unet_sdxl_tiny", True)
     _loss(net, fx).mean().backward()
     g1 = st.grad.clone()
-    ops.state.grad_accumulate = True
+    st.state.grad_accumulate = True          # the flag lives with the store (one engine), not in the process
     try:
         _loss(net, fx).mean().backward()
     finally:
-        ops.state.grad_accumulate = False
+        st.state.grad_accumulate = False
     assert rel_err(st.grad, 2 * g1) <= 2e-3
     st.zero_grad()
     assert float(st.grad.abs().max()) == 0.0

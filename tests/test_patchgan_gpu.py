@@ -95,13 +95,14 @@ def test_discriminator_step_against_reference(kind):
     loss, _, _ = get_discr_loss_fn(kind).with_grad(real, fake)
     assert abs(float(loss) - float(case["d_loss"])) <= 1e-2 * float(case["d_loss"])
     _, d_real, d_fake = get_discr_loss_fn(kind).with_grad(case["logits_real"].cuda(), case["logits_fake"].cuda())
-    ops.state.grad_accumulate = False
+    dstate = ops.state_of(next(disc.parameters()))
+    dstate.grad_accumulate = False
     b_real(ops.nchw_to_tokens(d_real.contiguous(), 8))
-    ops.state.grad_accumulate = True                      # the second pass adds to the first one's weight gradients
+    dstate.grad_accumulate = True                         # the second pass adds to the first one's weight gradients
     try:
         b_fake(ops.nchw_to_tokens(d_fake.contiguous(), 8))
     finally:
-        ops.state.grad_accumulate = False
+        dstate.grad_accumulate = False
     ops.join_wgrad_stream()
     torch.cuda.synchronize()
     grads = dict(disc.named_parameters())

@@ -13,14 +13,15 @@ def main():
         sig = bench.draw_sigmas(4, gen_cpu, dev)
         loss = eng.training_step(batch, 0, sigmas=sig); loss.backward(); eng.optimizer_step(lr=1e-6)
     variants = {}
-    side = ops.state.wgrad_stream
+    est = eng.store.state
+    side = est.wgrad_stream
     variants["base"] = lambda: None
     def setenv(lo, hi):
         os.environ["NK_SPLIT_LO"] = str(lo); os.environ["NK_SPLIT_HI"] = str(hi)
-    variants["ln_side"] = lambda: setattr(ops.state, "norm_params_on_side_stream", True)
+    variants["ln_side"] = lambda: setattr(est, "norm_params_on_side_stream", True)
     variants["no_ring"] = lambda: os.environ.__setitem__("NK_GEMM_RING", "0")
     variants["no_sk"] = lambda: os.environ.__setitem__("NK_GEMM_SK", "0")
-    def restore(): ops.state.wgrad_stream = side; setenv(96, 192); os.environ["NK_GEMM_NW"] = "8"; os.environ["NK_GEMM_SK"] = "4"; os.environ["NK_SK_GRID"] = "512"; ops.state.norm_params_on_side_stream = False; os.environ["NK_GEMM_RING"] = "1"
+    def restore(): est.wgrad_stream = side; setenv(96, 192); os.environ["NK_GEMM_NW"] = "8"; os.environ["NK_GEMM_SK"] = "4"; os.environ["NK_SK_GRID"] = "512"; est.norm_params_on_side_stream = False; os.environ["NK_GEMM_RING"] = "1"
     for _ in range(2): step()
     res = {k: [] for k in variants}
     for rnd in range(3):

@@ -24,9 +24,9 @@ def flops(name, args):
     return orig_flops(name, args)
 timer.flops = flops
 timer.install()
-side, ops.state.wgrad_stream = ops.state.wgrad_stream, None
+side, eng.store.state.wgrad_stream = eng.store.state.wgrad_stream, None
 step()
-ops.state.wgrad_stream = side
+eng.store.state.wgrad_stream = side
 timer.uninstall()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
