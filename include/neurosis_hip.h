@@ -46,6 +46,18 @@ int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int 
  * (that launch's output is wrong), -1 on a device error.  Synchronises the device; meant for tests and end-of-run checks. */
 int nk_gemm_sk_status(void);
 
+/* Backward-health word: fail-closed handling of such a give-up on the TRAINING path (no reference counterpart; the
+ * reference's cuBLAS / cuDNN calls cannot produce a partial tile).  The workgroup that gives up poisons its output tile
+ * with NaN and raises one device word; nk_adafactor_chunk / nk_adamw_flat gate every kernel of the update on that word
+ * (masters, optimizer state and bf16 shadows stay untouched) and return NK_ERR_HEALTH (3) from the NEXT call on, without
+ * synchronising (a stream-ordered snapshot of the word to pinned memory).
+ *   nk_health_status(): 0 healthy / 1 raised / -1 device error; synchronises.
+ *   nk_health_clear():  synchronises, lowers the word and every stream-K flag, so a caller that has decided to go on can.
+ *   nk_debug_raise_health(stream): test hook, raises the word the way a kernel would. */
+int nk_health_status(void);
+int nk_health_clear(void);
+int nk_debug_raise_health(void* stream);
+
 /* `count` (<= 8) weight gradients of identical shape in ONE launch: the three 1280x1280 projections of a transformer
  * block are 100 tiles each, far below one workgroup per CU on their own.  dy / x / dw are HOST arrays of device pointers. */
 int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, int count, int M, int N, int K,

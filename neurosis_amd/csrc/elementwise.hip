@@ -568,7 +568,8 @@ extern "C" int nk_edm_loss(const void* net_out, const float* zt, const float* ta
 // ---- flat fused AdamW over the whole parameter buffer; also refreshes the bf16 shadow ----------
 __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, bf16_t* __restrict__ shadow, long n, float lr, float b1,
-                                  float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+                                  float b2, float eps, float wd, float bc1, float bc2, float gscale, const unsigned* health) {
+  if (*(const volatile unsigned*)health) return;     // a flagged backward: leave masters, moments and shadows untouched
   const long n4 = n >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     float4_t pp = *(float4_t*)(p + i * 4);
@@ -594,8 +595,13 @@ __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict
 extern "C" int nk_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, long n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
   NK_CHECK_ARG(p && g && m && v && shadow && n > 0 && (n & 3) == 0 && step >= 1);
+  if (int e = nk_health_poll()) return e;
+  const unsigned* health = nk_health_word();
+  if (!health) { nk_set_error(__FILE__, __LINE__, "health word allocation failed"); return NK_ERR_LAUNCH; }
   float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_flat_kernel, dim3(ew_blocks(n >> 2)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, g, m, v,
-                     (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
-  return nk_check_launch("adamw_flat");
+                     (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, health);
+  if (int e = nk_check_launch("adamw_flat")) return e;
+  nk_health_snapshot((hipStream_t)stream);
+  return NK_OK;
 }

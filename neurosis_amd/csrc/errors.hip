@@ -19,4 +19,86 @@ int nk_check_launch(const char* what) {
 }
 
 extern "C" const char* nk_last_error(void) { return g_err; }
-extern "C" int nk_abi_version(void) { return 1; }
+extern "C" int nk_abi_version(void) { return 2; }
+
+// ---- backward-health word ---------------------------------------------------------------------------------------------
+#include <mutex>
+static std::mutex g_health_mutex;
+static unsigned* g_health_dev = nullptr;     // device word
+static unsigned* g_health_host = nullptr;    // pinned mirror written by the snapshots
+static hipEvent_t g_health_event;
+static bool g_health_pending = false;        // a snapshot is in flight
+static bool g_health_tripped = false;        // sticky until nk_health_clear()
+
+unsigned* nk_health_word(void) {
+  std::lock_guard<std::mutex> lock(g_health_mutex);
+  if (!g_health_dev) {
+    unsigned* d = nullptr;
+    if (hipMalloc((void**)&d, 64) != hipSuccess) return nullptr;
+    if (hipMemset(d, 0, 64) != hipSuccess || hipHostMalloc((void**)&g_health_host, 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&g_health_event, hipEventDisableTiming) != hipSuccess) {
+      (void)hipFree(d);
+      return nullptr;
+    }
+    g_health_host[0] = 0;
+    g_health_dev = d;
+  }
+  return g_health_dev;
+}
+
+void nk_health_snapshot(hipStream_t stream) {
+  if (!nk_health_word()) return;
+  std::lock_guard<std::mutex> lock(g_health_mutex);
+  if (g_health_pending && hipEventQuery(g_health_event) != hipSuccess) return;   // one snapshot in flight is enough
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;
+  if (g_health_pending && g_health_host[0]) g_health_tripped = true;
+  if (hipMemcpyAsync(g_health_host, g_health_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess) return;
+  g_health_pending = hipEventRecord(g_health_event, stream) == hipSuccess;
+}
+
+int nk_health_poll(void) {
+  std::lock_guard<std::mutex> lock(g_health_mutex);
+  if (g_health_pending && hipEventQuery(g_health_event) == hipSuccess) {
+    g_health_pending = false;
+    if (g_health_host[0]) g_health_tripped = true;
+  }
+  if (g_health_tripped) {
+    snprintf(g_err, sizeof(g_err), "backward health word is set: a stream-K GEMM gave up waiting for a partial tile in an earlier step (its output was "
+                                   "poisoned with NaN and the optimizer skipped that update); inspect with nk_health_status(), reset with nk_health_clear()");
+    return NK_ERR_HEALTH;
+  }
+  return NK_OK;
+}
+
+// 0 = healthy, 1 = raised.  Synchronises the device.
+extern "C" int nk_health_status(void) {
+  unsigned* d = nk_health_word();
+  if (!d || hipDeviceSynchronize() != hipSuccess) return -1;
+  unsigned v = 0;
+  if (hipMemcpy(&v, d, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lock(g_health_mutex);
+  if (v) g_health_tripped = true;
+  return (v || g_health_tripped) ? 1 : 0;
+}
+
+int nk_gemm_sk_reset(void);   // gemm.hip
+extern "C" int nk_health_clear(void) {
+  unsigned* d = nk_health_word();
+  if (!d || hipDeviceSynchronize() != hipSuccess || hipMemset(d, 0, 64) != hipSuccess) return NK_ERR_LAUNCH;
+  if (int e = nk_gemm_sk_reset()) return e;
+  std::lock_guard<std::mutex> lock(g_health_mutex);
+  g_health_pending = false;
+  g_health_tripped = false;
+  g_health_host[0] = 0;
+  return NK_OK;
+}
+
+__global__ void nk_raise_health_kernel(unsigned* w) { __hip_atomic_store(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// test hook: raises the word the way a kernel would (stream-ordered)
+extern "C" int nk_debug_raise_health(void* stream) {
+  unsigned* d = nk_health_word();
+  if (!d) { nk_set_error(__FILE__, __LINE__, "health word allocation failed"); return NK_ERR_LAUNCH; }
+  hipLaunchKernelGGL(nk_raise_health_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d);
+  return nk_check_launch("nk_raise_health_kernel");
+}

@@ -1144,13 +1144,27 @@ __global__ __launch_bounds__(SK_NT, 4) void nk_gemm_sk_kernel(const NkGemmParams
             // The workgroup waited for has a LOWER index on the same XCD: the dispatcher hands workgroups out in index
             // order, so it is running or done.  The wait is bounded all the same (~0.2 s): on expiry the launch is marked
             // failed (checked by nk_gemm_sk_status) instead of hanging the device.
+            // FAIL CLOSED: a tile whose partials never arrived is poisoned (NaN reaches the loss / the gradient norm) and the
+            // process-wide health word is raised, which makes the fused optimizer kernels skip the update of this step and
+            // the next optimizer call return an error -- the launch never continues with whatever the workspace held.
             int spins = 0;
-            while (__hip_atomic_load(p.sk_flags + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            bool gave_up = (p.sk_debug & 2) != 0;
+            while (!gave_up && __hip_atomic_load(p.sk_flags + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
               __builtin_amdgcn_s_sleep(8);
-              if (++spins > (1 << 21)) {
-                if (tid == 0) __hip_atomic_store(p.sk_flags + SK_MAX_GRID + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+              if (++spins > (1 << 21)) gave_up = true;
+            }
+            if (gave_up) {
+              if (tid == 0) {
+                __hip_atomic_store(p.sk_flags + SK_MAX_GRID + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.sk_health, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
+              const float poison = __builtin_nanf("");
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = (float4_t){poison, poison, poison, poison};
+              break;      // (a publisher that does show up later finds its flag lowered by nobody: nk_health_clear() re-zeroes
+                          // every workspace's flags before training may continue)
             }
             sk_add_partial(p.sk_ws + (size_t)ticket * SK_TILE_FLOATS, acc, wave, lane);
             // Every published partial has exactly one reader (the workgroup finishing that tile), which lowers the flag again
@@ -1834,11 +1848,21 @@ static int sk_prepare(NkGemmParams& p, int grid, hipStream_t stream) {
     // zeroed ON THE LAUNCHING STREAM (a null-stream memset is not ordered against a non-blocking stream's kernels)
     if (hipMemsetAsync(w.flags, 0, (SK_MAX_GRID + 64) * sizeof(unsigned), stream) != hipSuccess) return NK_ERR_LAUNCH;
   }
+  p.sk_health = nk_health_word();
+  if (!p.sk_health) { nk_set_error(__FILE__, __LINE__, "health word allocation failed"); return NK_ERR_LAUNCH; }
   p.sk_counter = w.counter;
   p.sk_flags = w.flags;
   p.sk_ws = w.ws;
   p.sk_base = 0;
   p.sk_epoch = 0;
+  return NK_OK;
+}
+
+// called by nk_health_clear() (device already synchronised): lower every flag a failed launch may have left raised
+int nk_gemm_sk_reset(void) {
+  std::lock_guard<std::mutex> lock(sk_mutex);
+  for (auto& kv : sk_spaces)
+    if (kv.second.flags && hipMemset(kv.second.flags, 0, (SK_MAX_GRID + 64) * sizeof(unsigned)) != hipSuccess) return NK_ERR_LAUNCH;
   return NK_OK;
 }
 

@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int uint2_t;
 #define NK_OK 0
 #define NK_ERR_ARG 1
 #define NK_ERR_LAUNCH 2
+#define NK_ERR_HEALTH 3   // a kernel of an earlier step reported an unusable result (see nk_health_* in errors.hip)
 
 #define NK_CHECK_ARG(cond)                                                        \
   do {                                                                            \
@@ -26,6 +27,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned int uint2_t;
 
 void nk_set_error(const char* file, int line, const char* what);
 int nk_check_launch(const char* what);
+// Backward-health word (errors.hip): ONE device word per process.  A kernel that cannot deliver a correct result (a
+// stream-K fix-up that gave up waiting) raises it and poisons its output; the fused optimizer kernels read it first and
+// leave every buffer untouched while it is set; the optimizer entry points report it on the host without synchronising.
+unsigned* nk_health_word(void);                 // device pointer (allocated and zeroed on first use; nullptr on failure)
+int nk_health_poll(void);                        // NK_OK, or NK_ERR_HEALTH once a finished snapshot has seen the word set
+void nk_health_snapshot(hipStream_t stream);     // async copy of the word to pinned host memory behind `stream`'s work
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -52,7 +52,8 @@ struct NkGemmParams {
   unsigned sk_epoch;        // (unused: no per-launch state, so a launch replayed from a hipGraph is a fresh one)
   float* sk_ws;             // [grid][128*128] fp32 partial tiles in accumulator-register order
   int sk_chunked;           // 1: each XCD owns a contiguous eighth of the tile list
-  int sk_debug;             // ablation switches (NK_SK_DEBUG): 1 = no epilogue stores, 2 = no fixup exchange
+  int sk_debug;             // NK_SK_DEBUG: 1 = no epilogue stores (ablation), 2 = every fix-up wait gives up at once (tests the fail-closed path)
+  unsigned* sk_health;      // backward-health word (errors.hip): raised when a fix-up wait gives up
 };
 #define NK_MAX_BATCH 8
 

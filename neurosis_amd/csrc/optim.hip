@@ -47,7 +47,10 @@ struct NkAfArgs {
   int item_lo, item_hi, tensor_lo, tensor_hi;
   float beta2t, eps1, eps2, clip, rel_step, weight_decay, grad_scale;
   int scale_parameter;
+  const unsigned* health;   // backward-health word (errors.hip): non-zero -> every kernel of the step returns at once
 };
+// (wave-uniform scalar load; `volatile` so it is not hoisted or cached across the check)
+#define AF_HEALTH_GATE(a) do { if (*(const volatile unsigned*)(a).health) return; } while (0)
 
 #define AF_TR 256   // matrix tile rows
 #define AF_TC 64    // matrix tile cols
@@ -173,6 +176,7 @@ __device__ __forceinline__ float af_conv_apply(const NkAfArgs& a, const NkAfTens
 }
 
 __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
+  AF_HEALTH_GATE(a);
   __shared__ float red[4];
   __shared__ float colsh[16][AF_TC + 4];
   const NkAfItem it = a.items[a.item_lo + blockIdx.x];
@@ -251,6 +255,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
 // also leave the sum of their rows' EMAs behind (mean of the row EMA = sum of those slots / d0, summed by the consumers).
 #define AF_FIN 1024
 __global__ __launch_bounds__(256) void af_finalize_stats_kernel(const NkAfArgs a) {
+  AF_HEALTH_GATE(a);
   __shared__ float red[4];
   const NkAfItem it = a.fin_items[a.fin_lo + blockIdx.x];
   const NkAfTensor t = a.tensors[it.tensor];
@@ -295,6 +300,7 @@ __device__ __forceinline__ float af_mean_row(const NkAfArgs& a, const NkAfTensor
 
 // matrices: partial sum of u^2 per tile
 __global__ __launch_bounds__(256) void af_u2_kernel(const NkAfArgs a) {
+  AF_HEALTH_GATE(a);
   __shared__ float red[4];
   const NkAfItem it = a.items[a.item_lo + blockIdx.x];
   const NkAfTensor t = a.tensors[it.tensor];
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(256) void af_u2_kernel(const NkAfArgs a) {
 
 // one block per tensor: RMS(u) -> clip, RMS(p) -> step size
 __global__ __launch_bounds__(256) void af_finalize_scale_kernel(const NkAfArgs a) {
+  AF_HEALTH_GATE(a);
   __shared__ float red[4];
   const int ti = a.tensor_lo + blockIdx.x;
   const NkAfTensor t = a.tensors[ti];
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(256) void af_finalize_scale_kernel(const NkAfArgs a
 }
 
 __global__ __launch_bounds__(256) void af_apply_kernel(const NkAfArgs a) {
+  AF_HEALTH_GATE(a);
   __shared__ float red[4];
   const NkAfItem it = a.items[a.item_lo + blockIdx.x];
   const NkAfTensor t = a.tensors[it.tensor];
@@ -490,6 +498,7 @@ static NkAfArgs af_args(const NkAdafactorArgs* h) {
   a.item_lo = h->item_lo; a.item_hi = h->item_hi; a.tensor_lo = h->tensor_lo; a.tensor_hi = h->tensor_hi;
   a.beta2t = h->beta2t; a.eps1 = h->eps1; a.eps2 = h->eps2; a.clip = h->clip_threshold; a.rel_step = h->rel_step;
   a.weight_decay = h->weight_decay; a.grad_scale = h->grad_scale; a.scale_parameter = h->scale_parameter;
+  a.health = nk_health_word();
   return a;
 }
 
@@ -504,8 +513,10 @@ extern "C" int nk_adafactor_init(const NkAdafactorArgs* h, void* stream) {
 
 extern "C" int nk_adafactor_chunk(const NkAdafactorArgs* h, void* stream_) {
   if (int e = af_check(h)) return e;
+  if (int e = nk_health_poll()) return e;       // an earlier step's backward was flagged: refuse to go on silently
   hipStream_t stream = (hipStream_t)stream_;
   NkAfArgs a = af_args(h);
+  if (!a.health) { nk_set_error(__FILE__, __LINE__, "health word allocation failed"); return NK_ERR_LAUNCH; }
   const int nitems = a.item_hi - a.item_lo, ntens = a.tensor_hi - a.tensor_lo;
   hipLaunchKernelGGL(af_stats_kernel, dim3(nitems), dim3(256), 0, stream, a);
   if (int e = nk_check_launch("af_stats_kernel")) return e;
@@ -519,7 +530,9 @@ extern "C" int nk_adafactor_chunk(const NkAdafactorArgs* h, void* stream_) {
   hipLaunchKernelGGL(af_finalize_scale_kernel, dim3(ntens), dim3(256), 0, stream, a);
   if (int e = nk_check_launch("af_finalize_scale_kernel")) return e;
   hipLaunchKernelGGL(af_apply_kernel, dim3(nitems), dim3(256), 0, stream, a);
-  return nk_check_launch("af_apply_kernel");
+  if (int e = nk_check_launch("af_apply_kernel")) return e;
+  nk_health_snapshot(stream);                    // what the backward in front of this update left in the word
+  return NK_OK;
 }
 
 // ---- LitEma.forward (modules/ema.py:40-59) over the flat buffer: shadow -= (1 - decay) * (shadow - p) -------------------

@@ -83,6 +83,8 @@ SIGNATURES: dict[str, list] = {
     "nk_sample_euler_step": [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp],
     "nk_adamw_flat": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
     "nk_ema_flat": [vp, vp, i64, f32, vp],
+    "nk_debug_raise_health": [vp],
+    "nk_health_clear": [],
     "nk_adafactor_init": [vp, vp],
     "nk_adafactor_chunk": [vp, vp],
 }
@@ -97,6 +99,7 @@ SIZE_QUERIES: dict[str, list] = {
     "nk_attention_bwd_ws_floats": [adp],
     "nk_adafactor_tensor_bytes": [],
     "nk_gemm_sk_status": [],
+    "nk_health_status": [],
 }
 
 _lib = None

@@ -248,8 +248,8 @@ class DiffusionEngine(nn.Module):
             scope = torch.cuda.stream(self._optimizer_stream)
         with scope:
             opt = self._torch_optimizer
-            if opt is not None and getattr(self, "adafactor", None) is None:
-                opt.step(grad_scale=grad_scale)                      # fused AdamW from the config (or an Adafactor bound late)
+            if opt is not None:
+                opt.step(grad_scale=grad_scale)                      # the config's optimizer object (fused underneath)
             elif getattr(self, "adafactor", None) is not None:
                 self.adafactor.step(grad_scale)
             else:

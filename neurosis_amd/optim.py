@@ -362,6 +362,5 @@ class FlatEma(torch.nn.Module):
                 continue
             with torch.no_grad():
                 view.copy_(src)
-        if strict:
-            own = {prefix + "decay", prefix + "num_updates"} | mine
-            unexpected_keys.extend(k for k in state_dict if k.startswith(prefix) and k not in own)
+        # the base class reports every key under the prefix that is not a registered buffer: the per-parameter entries are ours
+        unexpected_keys[:] = [k for k in unexpected_keys if k not in mine]

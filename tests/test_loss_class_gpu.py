@@ -68,7 +68,9 @@ def _engine(**kw):
     net = D.UNetModel(**UNET_TINY)
     net.load_state_dict(synth_state_dict(keys["unet"]))
     vae = AutoencoderKL(embed_dim=4, ddconfig={k: v for k, v in VAE_TINY.items() if k != "embed_dim"})
-    vae.load_state_dict(synth_state_dict(keys["vae"]))
+    # (ddconfig.standalone=true gives the reference's Encoder / Decoder their own quant convs, which _init_first_stage then
+    # overwrites with the autoencoder's top-level ones, models/diffusion.py:157-162: those four entries carry no information)
+    vae.load_state_dict({k: v for k, v in synth_state_dict(keys["vae"]).items() if not k.startswith(("encoder.quant_conv", "decoder.post_quant_conv"))})
     den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization())
     eng = DiffusionEngine(model=net, denoiser=den, first_stage_model=vae, scale_factor=0.13025, input_key="image", vae_batch_size=2,
                           loss_fn=D.StandardDiffusionLoss(sigma_generator=D.InjectedSigmaGenerator(), loss_weighting=D.EpsWeighting()), **kw).cuda()
@@ -132,13 +134,24 @@ def test_optimizer_and_ema_state_survive_a_checkpoint_round_trip():
     assert b.adafactor.step_count == 2
     assert torch.equal(b.model_ema.shadow, a.model_ema.shadow) and torch.equal(b.store.master, a.store.master)
     assert torch.equal(b.adafactor.state, a.adafactor.state)
+    # a control that resumes WITHOUT the optimizer state (what round 1 did): step count 0 -> relative step 1e-6 * 1 instead of 1e-6 * 3
+    c = mk()
+    c.load_state_dict(sd, strict=True)
+    c.store.refresh()
+    before = a.store.master.double().clone()
     step(a, 3)
     step(b, 3)
+    step(c, 3)
     torch.cuda.synchronize()
-    assert torch.equal(a.store.master, b.store.master)
-    assert torch.equal(a.adafactor.state, b.adafactor.state)
-    assert torch.equal(a.model_ema.shadow, b.model_ema.shadow)
-    assert a._torch_scheduler.get_last_lr() == b._torch_scheduler.get_last_lr() and a._torch_scheduler.get_last_lr()[0] != 4e-7
+    # (bitwise equality is not on offer: the tiny-grid weight gradients sum their K splits with fp32 atomics)
+    upd_a, upd_b, upd_c = (x.store.master.double() - before for x in (a, b, c))
+    assert float((upd_a - upd_b).norm() / upd_a.norm()) <= 1e-3
+    assert float((upd_a - upd_c).norm() / upd_a.norm()) >= 0.3, "resuming without the optimizer state must be visibly different"
+    assert float((a.adafactor.state - b.adafactor.state).norm() / a.adafactor.state.norm()) <= 1e-4
+    assert float((a.model_ema.shadow - b.model_ema.shadow).abs().max()) <= 1e-6
+    assert a.adafactor.step_count == b.adafactor.step_count == 3 and c.adafactor.step_count == 1
+    lr_a, lr_b = a._torch_scheduler.get_last_lr()[0], b._torch_scheduler.get_last_lr()[0]
+    assert abs(lr_a - lr_b) <= 1e-6 * lr_a and lr_a != 4e-7
 
 
 def test_masters_changed_refreshes_derived_state():
