@@ -41,10 +41,15 @@ def _loss(eng, fx, sel):
     return eng(fx["x"][sel].cuda(), batch, sigmas=fx["sigma"][sel].cuda(), noise=fx["noise"][sel].cuda())
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, out, backend="gloo"):
+    # (nothing touches the GPU in this process before this point: one process per device, device chosen first)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":            # RCCL: one GPU per rank, stream-ordered collectives on the exchange stream
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from neurosis_amd.dp import FlatDataParallel
 
     fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
@@ -74,6 +79,21 @@ def test_flat_data_parallel_two_ranks_one_gpu():
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert out["scale"] == 0.5
     # bf16 activations: per-rank batches of 1 vs one batch of 2 round differently; same bound as the golden-vector test
+    assert out["cos"] >= 0.999 and out["err"] <= 5e-2, dict(out)
+
+
+def test_flat_data_parallel_rccl_one_gpu_per_rank():
+    """The collective the exchange exists for: backend "nccl" (= RCCL over xGMI), one process per GPU, the same check as the
+    gloo rehearsal above.  Needs >= 2 visible devices (the driver's 8-GPU node; a 1-GPU box skips with that reason).
+    `torch.cuda.device_count()` does not initialise the GPU in the parent, so the children are started before any HIP call."""
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip(f"RCCL needs one GPU per rank: {ndev} device(s) visible")
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, "nccl"), nprocs=world, join=True)
+    assert out["scale"] == 0.5
     assert out["cos"] >= 0.999 and out["err"] <= 5e-2, dict(out)
 
 

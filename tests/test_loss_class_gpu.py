@@ -168,3 +168,43 @@ def test_masters_changed_refreshes_derived_state():
     assert not eng.adafactor._p2_valid
     assert torch.equal(eng.model_ema.shadow, eng.store.master)
     assert torch.equal(eng.store.shadow.float(), eng.store.master.bfloat16().float())
+
+
+def test_lightning_adapter_step_logic_with_a_stand_in_trainer():
+    """neurosis_amd.trainer.DiffusionEngineMI355X without Lightning installed: manual optimization, accumulate_grad_batches
+    handled by DiffusionEngine.accumulate (first micro-batch overwrites, the last one steps), optimizer state in the checkpoint."""
+    from types import SimpleNamespace
+
+    import neurosis_amd.modules.diffusion as D
+    from neurosis_amd.models import AutoencoderKL
+    from neurosis_amd.optimizers import Adafactor
+    from neurosis_amd.trainer import DiffusionEngineMI355X
+
+    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    keys = json.loads((G / "engine_tiny_keys.json").read_text())
+    net = D.UNetModel(**UNET_TINY)
+    net.load_state_dict(synth_state_dict(keys["unet"]))
+    vae = AutoencoderKL(embed_dim=4, ddconfig={k: v for k, v in VAE_TINY.items() if k != "embed_dim"})
+    vae.load_state_dict({k: v for k, v in synth_state_dict(keys["vae"]).items() if not k.startswith(("encoder.quant_conv", "decoder.post_quant_conv"))})
+    den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization())
+    ad = DiffusionEngineMI355X(require_lightning=False, model=net, denoiser=den, first_stage_model=vae, scale_factor=0.13025, input_key="image",
+                               optimizer=partial(Adafactor, scale_parameter=True, relative_step=True, warmup_init=True),
+                               loss_fn=D.StandardDiffusionLoss(sigma_generator=D.EDMSigmaGenerator(), loss_weighting=D.EpsWeighting()))
+    ad._trainer_stub = SimpleNamespace(device=torch.device("cuda", 0), world_size=1, accumulate_grad_batches=2)
+    ad.on_fit_start()
+    eng = ad.engine
+    batch = lambda: {"image": e["image"].cuda(), "crossattn": e["crossattn"].cuda(), "vector": e["vector"].cuda()}
+    m0 = eng.store.master.clone()
+    l0 = ad.training_step(batch(), 0)
+    torch.cuda.synchronize()
+    g0 = eng.store.grad.clone()
+    assert torch.equal(eng.store.master, m0) and eng.global_step == 0 and eng.store.state.grad_accumulate is False
+    l1 = ad.training_step(batch(), 1)                     # second micro-batch: adds, then the fused update
+    eng.join_optimizer()
+    torch.cuda.synchronize()
+    assert eng.global_step == 1 and not torch.equal(eng.store.master, m0)
+    assert float(eng.store.grad.norm()) > 0 and not torch.equal(eng.store.grad, g0)
+    assert torch.isfinite(l0) and torch.isfinite(l1) and not l0.requires_grad
+    ckpt = {}
+    ad.on_save_checkpoint(ckpt)
+    assert ckpt["nk_global_step"] == 1 and int(ckpt["nk_optimizer"]["state"][0]["step"]) == 1
