@@ -890,8 +890,8 @@ __device__ __forceinline__ void sk_decode(const NkGemmParams& p, int t, int ntm,
 
 // accumulators -> global, fused bias / rowvec / residual.  acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)]
 //                                                                           [n0 + wn*32 + j*16 + (lane>>4)*4 + r]
-template <int OUT_F32>
-__device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* Cv, float4_t (&acc)[4][2], int mbase, int nbase, int lane) {
+template <int OUT_F32, int MI = 4>     // MI 16-row blocks x one pair of 16-column blocks
+__device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI][2], int mbase, int nbase, int lane) {
   const int g = lane >> 4;
   // after the row swap: lanes g=0 hold columns 0-7 of the wave's 32, g=1 16-23, g=2 8-15, g=3 24-31
   const int n = nbase + (g & 1) * 16 + (g >> 1) * 8;
@@ -912,7 +912,7 @@ __device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* 
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     float v[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {   // every lane takes part in the swap; the bounds predicates come after it
@@ -1668,6 +1668,9 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
     }
 }
 
+static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk);
+#include "gemm_g2.h"
+
 static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("NK_GEMM_XL"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -1943,6 +1946,15 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   if (p.residual) NK_CHECK_ARG(((uintptr_t)p.residual & 15) == 0 && ((p.ldr & 7) == 0 || (p.N & 7) != 0));
   if (!out_f32) NK_CHECK_ARG((p.ldc & 7) == 0 || (p.N & 7) != 0);
   if (p.fRowsPerBatch.d == 0) p.fRowsPerBatch = make_fastdiv(1);
+
+  // two-group staggered ring at one workgroup per CU (gemm_g2.h): Linear forward / dgrad / wgrad shapes whose 128 x 160 (or
+  // 128 x 128) tiles come out in whole rounds of 256
+  if (!use_v1() && (!p.nbatch || p.nbatch <= NK_MAX_BATCH) && use_g2(p, amode, bmode, out_f32, 1) && (g2_mode() == 2 || !use_xl(p, amode, bmode, out_f32, 1))) {
+    if (p.accumulate == 2) p.accumulate = 0;       // no K split here: "destination known zero" means plain stores
+    if (amode == OP_KC && bmode == OP_KC) return out_f32 ? launch_g2<OP_KC, OP_KC, 1>(p, stream) : launch_g2<OP_KC, OP_KC, 0>(p, stream);
+    if (amode == OP_KC && bmode == OP_MC) return out_f32 ? launch_g2<OP_KC, OP_MC, 1>(p, stream) : launch_g2<OP_KC, OP_MC, 0>(p, stream);
+    return out_f32 ? launch_g2<OP_MC, OP_MC, 1>(p, stream) : launch_g2<OP_MC, OP_MC, 0>(p, stream);
+  }
 
   if (!use_v1() && use_sk(p, out_f32)) {
     const long ntm_ = (p.M + BM - 1) / BM, ntn_ = (p.N + BN - 1) / BN, nk_ = (p.K + BK - 1) / BK;

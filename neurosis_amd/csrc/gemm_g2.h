@@ -1,0 +1,397 @@
+// Two-group staggered ring kernel of the MFMA tile engine (included by gemm.hip; not a stand-alone translation unit).
+//
+// Why it exists.  SDXL at batch 4 / 1024^2 puts 4096 tokens in its 1280-channel levels (60 of the 70 transformer blocks)
+// and 16384 in the 640-channel ones, so the GEMMs are 4096 x {1280, 3840, 5120, 10240} and 16384 x {640, 1920, 5120}.
+// With 128 x 128 tiles these give 320 / 960 / 1280 / 2560 and 640 / 1920 / 5120 tiles against 512 slots (2 workgroups per
+// CU): 62 % / 94 % / 83 % / 100 % and 62 % / 94 % / 100 % full rounds -- the 1280- and 640-wide outputs (three to four GEMMs
+// per transformer block, forward and backward) ran at 410-480 TFLOP/s for that reason alone.  All those widths are
+// multiples of 160, and 128 x 160 tiles at ONE workgroup per CU quantise exactly: 256, 768, 1024, 2048 and 512, 1536, 4096
+// tiles = whole rounds of 256.  One workgroup per CU needs a loop that keeps the MFMA pipes busy on its own, which the
+// lock-step ring kernel (nk_gemm_ring_kernel: every wave reads, then every wave multiplies) does not.
+//
+// Structure (the two-group idea of nk_gemm_xl2g_kernel at k-step granularity):
+//   * 8 waves = 2 groups x 4.  Group g owns columns [g*BN/2, (g+1)*BN/2) of the tile, its 4 waves 32 rows each: wave tile
+//     32 x 64 (BN = 128) or 32 x 80 (BN = 160): 2 A + 4|5 B fragments and 8|10 MFMAs (16x16x32) per k sub-step.
+//   * a k-step of a wave is  R { fragment reads of slab t; LDS-DMA of slab t+2; s_waitcnt vmcnt(pieces per slab) }  barrier
+//     M { lgkmcnt(0); 16|20 MFMAs }  barrier, and group 1 runs ONE BARRIER BEHIND group 0: while one group multiplies the other
+//     reads LDS and stages -- the MFMA pipes and the LDS / texture path alternate owners instead of idling together.
+//   * ring of FOUR 36 KiB stages, prefetch distance two slabs, never drained (counted vmcnt; past-the-end slabs come from the
+//     zero page so the count is the same in every iteration).  With barriers numbered so that group 0 passes 2t between R and
+//     M of slab t and 2t+1 after M (group 1: 2t+1 and 2t+2):
+//       RAW  slab t+1 is first read after barrier 2t+1; every wave waited for its own pieces of it before its barrier 2t / 2t+1.
+//       WAR  slab t+2 overwrites the stage of slab t-2, whose last reads (group 1) retired right after barrier 2t-3; the
+//            first DMA into it is issued after barrier 2t-1.
+//   * operands: k-contiguous (KC: [rows][64 k] image, XOR-swizzled 16-byte slots, ds_read_b128) or r-contiguous (MC: staged
+//     as it lies in memory, [64 k][rows], read with the transposing ds_read_b64_tr_b16).  The 160-wide MC image has 320-byte
+//     k-rows; its 8 k-rows that one half-wave touches fall on 8 distinct 32-byte bank windows once the rows with (k>>3)&1 set
+//     swap their 32-byte column-block pairs (source chunk c ^ 2): conflict-free without any other swizzle.
+//   * swapped-operand MFMAs and the register-direct permlane16_swap epilogue (no LDS staging): bf16 with fused bias / row
+//     vector / residual, or fp32 (weight gradients; overwrite or read-add-write: no K split here, so no atomics).
+// Linear forward (KC x KC), dgrad (KC x MC) and wgrad (MC x MC, also the batched form); convolutions keep the gather kernels.
+#pragma once
+
+#ifndef G2_ABL
+#define G2_ABL 0       // tools/ablate: 1 = no DMA in the loop, 2 = no fragment reads, 3 = no MFMAs, 5 = every piece issued in the R phase
+#endif
+#define G2_BM 128
+#define G2_STAGE_BYTES 36864                     // A image 16 KiB + B image up to 20 KiB
+#define G2_NS 4
+#define G2_SMEM_BYTES (G2_NS * G2_STAGE_BYTES)   // 147456
+
+// one operand of the tile: ROWS rows (128 for A; 128 or 160 for B), staged by all 8 waves: piece pc = wave + 8 i
+template <int MODE, int ROWS>
+struct OpG2 {
+  static constexpr int NPC = ROWS / 8;                 // 1 KiB pieces per slab
+  static constexpr int NPW = (NPC + 7) / 8;            // pieces per wave (waves past NPC - 8*(NPW-1) issue one fewer)
+  static constexpr int CH = ROWS / 8;                  // MC: 16-byte chunks per k-row
+  const bf16_t* rp[NPW];                               // running source pointer of each piece of this lane
+  int kk[NPW];                                         // KC: k offset of the lane's chunk (same for all pieces); MC: k row of the piece
+  bool ok[NPW];                                        // row / r-chunk in range
+  long step;                                           // pointer advance per slab
+  int kcur;
+
+  __device__ __forceinline__ int pieces(int wave) const { return wave + 8 * (NPW - 1) < NPC ? NPW : NPW - 1; }
+
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int R, int r0, int wave, int lane) {
+    kcur = 0;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pc = wave + 8 * i;
+      if constexpr (MODE == OP_KC) {
+        const int row = pc * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (lane >> 3);                 // slot (lane&7) of row (lane>>3) holds source chunk slot ^ (row & 7)
+        ok[i] = (pc < NPC) && (r0 + row < R);
+        kk[i] = chunk * 8;
+        rp[i] = P + (long)(r0 + row) * ld + chunk * 8;
+        step = BK;
+      } else {                                                      // OP_MC
+        const int S = 64 * pc + lane;
+        const int k = S / CH, c = S - k * CH;
+        const int src = CH == 16 ? (c ^ mc_swz(k)) : (c ^ (((k >> 3) & 1) << 1));
+        ok[i] = (pc < NPC) && (r0 + src * 8 < R);
+        kk[i] = k;
+        rp[i] = P + (long)k * ld + r0 + src * 8;
+        step = (long)BK * ld;
+      }
+    }
+  }
+  // sources of the next slab (advances the running state); past K or out of range: the zero page
+  __device__ __forceinline__ void next_sources(int K, const bf16_t* (&src)[NPW]) {
+    const bf16_t* zp = (const bf16_t*)nk_zero_page;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      src[i] = (ok[i] && kcur + kk[i] < K) ? rp[i] : zp;
+      rp[i] += step;
+    }
+    kcur += BK;
+  }
+  __device__ __forceinline__ void fire(const bf16_t* const (&src)[NPW], char* img, int wave) const {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+      if (i < NPW - 1 || wave + 8 * i < NPC)      // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave + 8 * i) * 1024), 16, 0, 0);
+  }
+};
+
+// Per-lane LDS read addresses of the fragments of a wave: NF 16-row blocks starting at row `first` of the operand image.
+// KC: one ds_read_b128 per (block, k sub-step); MC: two ds_read_b64_tr_b16 (k and k+4).
+template <int MODE, int ROWS, int NF>
+struct FragG2 {
+  unsigned a[MODE == OP_KC ? 2 : NF];     // KC: base of k sub-step 0 / 1 (blocks by immediate offset); MC: base per block
+  __device__ __forceinline__ void init(unsigned img0, int first, int lane) {
+    if constexpr (MODE == OP_KC) {
+      const unsigned x0 = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4);          // first must be a multiple of 8: row & 7 == lane & 7
+      const unsigned row = img0 + (unsigned)(first + (lane & 15)) * 128u;
+      a[0] = row + x0;
+      a[1] = row + (x0 ^ 64u);
+    } else {
+      const int g4 = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+      const int k = 8 * g4 + q;
+      if constexpr (ROWS == 128) {
+        const unsigned base = (unsigned)(k * 256 + (mc_swz(k) << 4) + (p >> 1) * 16 + (p & 1) * 8);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) a[j] = img0 + (base ^ (unsigned)((first + 16 * j) * 2));
+      } else {                                                                   // 160-wide: 320-byte k-rows
+        const unsigned base = (unsigned)(k * 320 + (p >> 1) * 16 + (p & 1) * 8);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int sub = first + 16 * j;
+          a[j] = img0 + base + 2u * (unsigned)((g4 & 1) ? (sub ^ 16) : sub);
+        }
+      }
+    }
+  }
+};
+
+#define G2_RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define G2_RDTR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+
+// fragment f[ks*NF + j] <- block j, k sub-step ks of the image whose per-lane addresses are `fa` (+ so: stage offset)
+template <int MODE, int ROWS, int NF>
+__device__ __forceinline__ void g2_read(bf16x8_t (&f)[2 * NF], const FragG2<MODE, ROWS, NF>& fa, unsigned so) {
+  if constexpr (MODE == OP_KC) {
+    const unsigned a0 = fa.a[0] + so, a1 = fa.a[1] + so;
+    G2_RD128(f[0], a0, 0);
+    G2_RD128(f[1], a0, 2048);
+    if constexpr (NF > 2) { G2_RD128(f[2], a0, 4096); G2_RD128(f[3], a0, 6144); }
+    if constexpr (NF > 4) { G2_RD128(f[4], a0, 8192); }
+    G2_RD128(f[NF + 0], a1, 0);
+    G2_RD128(f[NF + 1], a1, 2048);
+    if constexpr (NF > 2) { G2_RD128(f[NF + 2], a1, 4096); G2_RD128(f[NF + 3], a1, 6144); }
+    if constexpr (NF > 4) { G2_RD128(f[NF + 4], a1, 8192); }
+  } else {
+    constexpr int RS = ROWS * 2;          // bytes per k-row
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const unsigned aj = fa.a[j] + so;
+      short4_t lo0, hi0, lo1, hi1;
+      G2_RDTR(lo0, aj, 0);
+      G2_RDTR(hi0, aj, 4 * RS);
+      G2_RDTR(lo1, aj, 32 * RS);
+      G2_RDTR(hi1, aj, 36 * RS);
+      short8_t r0, r1;
+      r0[0] = lo0[0]; r0[1] = lo0[1]; r0[2] = lo0[2]; r0[3] = lo0[3]; r0[4] = hi0[0]; r0[5] = hi0[1]; r0[6] = hi0[2]; r0[7] = hi0[3];
+      r1[0] = lo1[0]; r1[1] = lo1[1]; r1[2] = lo1[2]; r1[3] = lo1[3]; r1[4] = hi1[0]; r1[5] = hi1[1]; r1[6] = hi1[2]; r1[7] = hi1[3];
+      f[j] = __builtin_bit_cast(bf16x8_t, r0);
+      f[NF + j] = __builtin_bit_cast(bf16x8_t, r1);
+    }
+  }
+}
+
+// a lone 16-column block of the wave tile (the fifth of the 80-column half): the lane holds 4 consecutive columns of one row
+template <int OUT_F32, int MI>
+__device__ __forceinline__ void reg_epilogue_col16(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI], int mbase, int nbase, int lane) {
+  const int n = nbase + (lane >> 4) * 4;
+  const int mrow = mbase + (lane & 15);
+  if (n >= p.N) return;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mrow + i * 16;
+    if (m >= p.M) continue;
+    float v[4] = {acc[i][0] * p.alpha, acc[i][1] * p.alpha, acc[i][2] * p.alpha, acc[i][3] * p.alpha};
+    if constexpr (OUT_F32) {
+      float* dst = (float*)Cv + (long)m * p.ldc + n;
+      if ((p.N & 3) == 0 && (p.ldc & 3) == 0) {
+        float4_t o = {v[0], v[1], v[2], v[3]};
+        if (p.accumulate) o += *(const float4_t*)dst;
+        *(float4_t*)dst = o;
+      } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
+      }
+    } else {
+      bf16_t* C = (bf16_t*)Cv;
+      if ((p.N & 3) == 0 && (p.ldc & 3) == 0) {
+        if (p.bias) { const float4_t b = *(const float4_t*)(p.bias + n); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+        if (p.rowvec) {
+          float t[4];
+          unpack4(*(const uint2_t*)(p.rowvec + (long)fdiv((unsigned)m, p.fRowsPerBatch) * p.ld_rowvec + n), t);
+          v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        }
+        if (p.residual) {
+          float t[4];
+          unpack4(*(const uint2_t*)(p.residual + (long)m * p.ldr + n), t);
+          v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        }
+        uint2_t o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2_t*)(C + (long)m * p.ldc + n) = o;
+      } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) {
+          float x = v[e];
+          if (p.bias) x += p.bias[n + e];
+          if (p.rowvec) x += bf2f(p.rowvec[(long)fdiv((unsigned)m, p.fRowsPerBatch) * p.ld_rowvec + n + e]);
+          if (p.residual) x += bf2f(p.residual[(long)m * p.ldr + n + e]);
+          C[(long)m * p.ldc + n + e] = f2bf(x);
+        }
+      }
+    }
+  }
+}
+
+template <int AMODE, int BMODE, int OUT_F32, int BN_>
+__global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HN = BN_ / 2, NJ = HN / 16;          // columns per group; 16-column blocks per wave: 4 or 5
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3;
+
+  // XCD-aware bijective remap + grouped tile order (4 x ntn patches: with 8 column tiles of 160 an XCD's 32 workgroups
+  // share 4 A panels and the whole of B)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + BN_ - 1) / BN_, ntm = (p.M + G2_BM - 1) / G2_BM;
+  constexpr int GM = 4;
+  const int per_group = GM * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GM;
+  const int gm = min(GM, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int m0 = (first_m + (in_group - nt * gm)) * G2_BM, n0 = nt * BN_;
+  const int nk = (p.K + BK - 1) / BK;
+  const bf16_t* Ap = p.nbatch ? p.Ab[blockIdx.z] : p.A;
+  const bf16_t* Bp = p.nbatch ? p.Bb[blockIdx.z] : p.B;
+  void* Cp = p.nbatch ? p.Cb[blockIdx.z] : p.C;
+
+  OpG2<AMODE, 128> oa;
+  OpG2<BMODE, BN_> ob;
+  oa.init(Ap, p.lda, p.M, m0, wave, lane);
+  ob.init(Bp, p.ldb, p.N, n0, wave, lane);
+  typedef __attribute__((address_space(3))) const char* lds_c;
+  const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
+  FragG2<AMODE, 128, 2> fa;
+  FragG2<BMODE, BN_, NJ> fb;
+  fa.init(lds0, wq * 32, lane);
+  fb.init(lds0 + 16384u, grp * HN, lane);
+
+  float4_t acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[4], bfr[2 * NJ];
+
+#define G2_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
+  // this wave's pieces per slab: 4 (BN 128) or 5 / 4 (BN 160, waves 0-3 / 4-7) -- the counted wait leaves exactly one slab in flight
+  const bool five = ob.pieces(wave) + oa.pieces(wave) == 5;
+#define G2_WAIT_ONE_SLAB()                                            \
+  do {                                                                \
+    if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        \
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             \
+  } while (0)
+
+  const bf16_t* sa[OpG2<AMODE, 128>::NPW];
+  const bf16_t* sb[OpG2<BMODE, BN_>::NPW];
+  // prologue: slabs 0 and 1 in flight, slab 0 landed for everyone
+  oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);
+  oa.fire(sa, smem, wave); ob.fire(sb, smem + 16384, wave);
+  oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);
+  oa.fire(sa, smem + G2_STAGE_BYTES, wave); ob.fire(sb, smem + G2_STAGE_BYTES + 16384, wave);
+  oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);             // sources of slab 2, fired in the first R phase
+  G2_WAIT_ONE_SLAB();
+  G2_BAR();
+  if (grp == 1) { G2_BAR(); }                                       // the second group runs one barrier behind
+
+  unsigned so = 0, sn = 2 * G2_STAGE_BYTES;                         // stage of slab t / of slab t + 2
+  for (int t = 0; t < nk; ++t) {
+    // ---- R: fragment reads of slab t, DMA of slab t + 2, wait for slab t + 1 ----
+    __builtin_amdgcn_sched_barrier(0);
+#if G2_ABL != 2
+    g2_read<BMODE, BN_, NJ>(bfr, fb, so);
+    g2_read<AMODE, 128, 2>(af, fa, so);
+#endif
+#if G2_ABL != 1
+    oa.fire(sa, smem + sn, wave);                        // the two A pieces here, the two or three B pieces behind the barrier, in the
+#if G2_ABL == 5                                          // MFMA phase: a piece costs the issuing wave 60-120 cycles, and with all of them
+    ob.fire(sb, smem + sn + 16384, wave);                // here the R phase outlasted the partner group's MFMAs (61 -> 56 us at 4096x1280x5120)
+#endif
+#endif
+#if G2_ABL == 5
+    G2_WAIT_ONE_SLAB();
+#else
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but the two A pieces just issued: slab t + 1 is complete (this wave's share)
+#endif
+    G2_BAR();
+    // ---- M: the wave's MFMAs; the next slab's source addresses are computed in their shadow ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#if G2_ABL != 5 && G2_ABL != 1
+    ob.fire(sb, smem + sn + 16384, wave);
+#endif
+    oa.next_sources(p.K, sa);
+    ob.next_sources(p.K, sb);
+#if G2_ABL != 3
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)     // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks * NJ + j], af[ks * 2 + i], acc[i][j], 0, 0, 0);
+#else
+    { asm volatile("" :: "v"(bfr[0]), "v"(bfr[NJ]), "v"(af[0]), "v"(af[2])); }
+#endif
+    __builtin_amdgcn_s_setprio(0);
+    G2_BAR();
+    so += G2_STAGE_BYTES; if (so == G2_NS * G2_STAGE_BYTES) so = 0;
+    sn += G2_STAGE_BYTES; if (sn == G2_NS * G2_STAGE_BYTES) sn = 0;
+  }
+  if (grp == 0) { G2_BAR(); }                                       // ... and the first group waits for it here
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the past-the-end zero-page pieces must land before the LDS is given up
+#undef G2_BAR
+#undef G2_WAIT_ONE_SLAB
+
+  const int mb = m0 + wq * 32, nb = n0 + grp * HN;
+#pragma unroll
+  for (int half = 0; half < NJ / 2; ++half) {
+    float4_t pair[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { pair[i][0] = acc[i][2 * half]; pair[i][1] = acc[i][2 * half + 1]; }
+    reg_epilogue_64x32<OUT_F32, 2>(p, Cp, pair, mb, nb + half * 32, lane);
+  }
+  if constexpr (NJ & 1) {
+    float4_t last[2] = {acc[0][NJ - 1], acc[1][NJ - 1]};
+    reg_epilogue_col16<OUT_F32, 2>(p, Cp, last, mb, nb + (NJ - 1) * 16, lane);
+  }
+}
+
+// NK_GEMM_G2: 0 = never; 1 (default) = by shape; 2 = every eligible launch (A/B runs)
+static int g2_mode() {
+  int mode = 1;
+  if (const char* e = getenv("NK_GEMM_G2")) mode = atoi(e);     // read per call: tools flip it in-process
+  return mode;
+}
+// tile width for this N: 160 when it divides N (1280, 640, 1920, 3840, 5120, 10240 ...), else 128 when that wastes little
+static int g2_bn(int N) {
+  if (N % 160 == 0) return 160;
+  const int ntn = (N + 127) / 128;
+  return (long)ntn * 128 * 100 <= (long)N * 112 ? 128 : 0;
+}
+static bool use_g2(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
+  const int mode = g2_mode();
+  if (!mode || splitk != 1) return false;
+  if (!((amode == OP_KC && bmode == OP_KC) || (amode == OP_KC && bmode == OP_MC) || (amode == OP_MC && bmode == OP_MC))) return false;
+  if (p.K < 2 * BK) return false;
+  {  // NK_GEMM_G2_MASK (A/B runs): bit 0 forward (KC x KC), bit 1 dgrad (KC x MC), bit 2 wgrad (MC x MC); default 3
+    int mask = 3;   // default: forward and dgrad (in the two-stream step the weight gradients do better with the co-resident 128 x 128 kernels: 187.6 vs 189.0 ms)
+    if (const char* e = getenv("NK_GEMM_G2_MASK")) mask = atoi(e);
+    const int bit = (amode == OP_KC && bmode == OP_KC) ? 1 : (amode == OP_KC ? 2 : 4);
+    if (!(mask & bit)) return false;
+  }
+  const int bn = g2_bn(p.N);
+  if (!bn) return false;
+  if (mode == 2) return true;
+  // By shape (tools/bench_g2.py, interleaved A/B on the SDXL Linear shapes).  The kernel wins where its tiles come out in ONE or
+  // TWO whole rounds of 256 (one workgroup per CU: 4096 x 1280 -> 256 tiles, 16384 x 640 -> 512, 3840 x 1280 -> 240, three batched
+  // 1280 x 1280 weight gradients -> 240) -- forward +12..29 %, dgrad +5..27 %, wgrad +32..35 % -- and where K is long enough (>= 40
+  // slabs) to amortise a tile's prologue and epilogue over up to four rounds.  It loses where many short rounds follow each other
+  // (at one workgroup per CU nothing overlaps a tile's epilogue: 16384 x 1280 x 640 forward 0.87x, 65536 x 1280 x 1280 0.67x) and
+  // against the 256 x 256 two-group kernel on the shapes that one takes (4096 x 3840 / 10240 x 1280 forward 0.76-0.80x).
+  const long tiles = (long)((p.M + G2_BM - 1) / G2_BM) * ((p.N + bn - 1) / bn) * (p.nbatch ? p.nbatch : 1);
+  const long rounds = (tiles + 255) / 256;
+  const double fill = (double)tiles / (double)(rounds * 256);
+  const long nk = (p.K + BK - 1) / BK;
+  if (fill < 0.85) return false;
+  return rounds <= 2 || (rounds <= 4 && nk >= 40);
+}
+
+template <int AMODE, int BMODE, int OUT_F32, int BN_>
+static int launch_g2_as(const NkGemmParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = nk_gemm_g2_kernel<AMODE, BMODE, OUT_F32, BN_>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(((p.M + G2_BM - 1) / G2_BM) * ((p.N + BN_ - 1) / BN_), 1, p.nbatch ? p.nbatch : 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), G2_SMEM_BYTES, stream, p);
+  return nk_check_launch("nk_gemm_g2_kernel");
+}
+template <int AMODE, int BMODE, int OUT_F32>
+static int launch_g2(const NkGemmParams& p, hipStream_t stream) {
+  return g2_bn(p.N) == 160 ? launch_g2_as<AMODE, BMODE, OUT_F32, 160>(p, stream) : launch_g2_as<AMODE, BMODE, OUT_F32, 128>(p, stream);
+}

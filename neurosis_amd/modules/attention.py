@@ -149,7 +149,7 @@ class CrossAttention(nn.Module):
                     ops.gemm_tn_f32(dv, ctx, ops.g2d(wv), acc())
 
                 ops.on_wgrad_stream(wg_kv, dk, dv, ctx, owner=wq)
-            if ops._wgrad_queue is not None and dq.is_contiguous() and x.is_contiguous():
+            if ops._wgrad_queue is not None and ops._wgrad_queue.takes(wq) and dq.is_contiguous() and x.is_contiguous():
                 ops._wgrad_queue.add(dq, x, ops.g2d(wq))
             else:
                 ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dq, x, ops.g2d(wq), acc()), dq, x, owner=wq)
@@ -225,7 +225,7 @@ class BasicTransformerBlock(nn.Module):
         y, b_ff = self.ff.fwd(n3, residual=a2)
 
         def bwd(dy: Tensor):
-            with ops.batched_wgrads():          # same-shape weight gradients of this block go out as one launch
+            with ops.batched_wgrads(self.norm1.weight):   # the block's small same-shape weight gradients go out as one launch
                 da2 = b_n3(b_ff(dy), dy)       # LN3 backward + the residual branch of x + ff(...)
                 dn2, dctx2 = b_a2(da2)
                 da1 = b_n2(dn2, da2)

@@ -37,9 +37,14 @@ class EngineState:
         self.grad_accumulate = False  # False: weight-grad kernels overwrite; True: they add (micro-batch accumulation)
         self.assume_zeroed = False  # True: a caller guarantees .grad buffers are all-zero before the first micro-batch (split-K skips its memset)
         self.wgrad_stream = wgrad_stream  # optional side HIP stream: weight-gradient GEMMs run there, concurrently with the dgrad chain
-        # same-shape weight gradients of one transformer block as ONE batched launch (nk_linear_wgrad_batched).  Measured
-        # 215 vs 210 ms/step: on the side stream the under-filled grids already overlap the dgrad chain, and deferring them to the
-        # end of the block only delays that overlap -- so off by default.
+        # the small same-shape weight gradients of one transformer block (attn1.to_out, attn2.to_q, attn2.to_out: 1280 x 1280 =
+        # 80 tiles of 128 x 160 each) as ONE batched launch (nk_linear_wgrad_batched): 240 tiles = one full round of the two-group
+        # kernel, 49.7 us for the three against 3 x 45.4 us one by one (tools/bench_g2.py).  (Round 1 measured batching -2 % with the
+        # 128 x 128 kernels, which gained nothing from the fuller grid, and with the block's LARGE weight gradients deferred too.)
+        # In the real two-stream step batching still LOSES, by a lot: 199.4 vs 189.1 ms (tools/ab_step.py, interleaved; 202.9 vs
+        # 190.7 with the 128 x 128 kernels): a 240-workgroup launch that needs whole CUs starves behind the main stream's kernels and
+        # the deferred gradients pile up into the tail of backward.  So off; the serialized figure above is what a single-stream
+        # backward would get.
         self.batch_wgrads = False
         # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):
         # 210 more cross-stream waits per step delay the weight-gradient GEMMs queued behind them.  Off.
@@ -102,6 +107,12 @@ class WgradQueue:
     def __init__(self, owner=None):
         self.items = []  # (dy, x, dw2d)
         self.owner = owner
+
+    MAX_ELEMS = 2 << 20     # weights up to 1280 x 1280: larger ones fill the chip alone and should not wait for the end of the block
+
+    @classmethod
+    def takes(cls, weight: Tensor) -> bool:
+        return weight.numel() <= cls.MAX_ELEMS
 
     def add(self, dy: Tensor, x: Tensor, dw: Tensor) -> None:
         self.items.append((dy, x, dw))
@@ -395,7 +406,7 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
     y = gemm_nt(x, w2d(weight), bias, residual)
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
-        queued = _wgrad_queue is not None and dy.is_contiguous() and x.is_contiguous()
+        queued = _wgrad_queue is not None and _wgrad_queue.takes(weight) and dy.is_contiguous() and x.is_contiguous()
         if queued:
             _wgrad_queue.add(dy, x, g2d(weight))
 

@@ -16,20 +16,25 @@ def main():
     est = eng.store.state
     side = est.wgrad_stream
     variants["base"] = lambda: None
-    def setenv(lo, hi):
-        os.environ["NK_SPLIT_LO"] = str(lo); os.environ["NK_SPLIT_HI"] = str(hi)
-    variants["ln_side"] = lambda: setattr(est, "norm_params_on_side_stream", True)
-    variants["no_ring"] = lambda: os.environ.__setitem__("NK_GEMM_RING", "0")
-    variants["no_sk"] = lambda: os.environ.__setitem__("NK_GEMM_SK", "0")
-    def restore(): est.wgrad_stream = side; setenv(96, 192); os.environ["NK_GEMM_NW"] = "8"; os.environ["NK_GEMM_SK"] = "4"; os.environ["NK_SK_GRID"] = "512"; est.norm_params_on_side_stream = False; os.environ["NK_GEMM_RING"] = "1"
-    for _ in range(2): step()
+    variants["no g2"] = lambda: os.environ.__setitem__("NK_GEMM_G2", "0")
+    variants["batch"] = lambda: setattr(est, "batch_wgrads", True)
+    for name in sys.argv[1:]:       # extra variants from the command line: ENV=VALUE[,ENV=VALUE...]
+        kv = [a.split("=", 1) for a in name.split(",")]
+        variants[name] = lambda kv=kv: [os.environ.__setitem__(k, v) for k, v in kv]
+    extra_env = sorted({a.split("=", 1)[0] for name in sys.argv[1:] for a in name.split(",")})
+    def restore():
+        est.wgrad_stream = side; est.batch_wgrads = False; est.norm_params_on_side_stream = False
+        os.environ["NK_GEMM_G2"] = "1"
+        for k in extra_env: os.environ.pop(k, None)
+    for _ in range(3): step()
+    import gc; gc.collect(); gc.freeze()      # (the cyclic GC's full collections otherwise show up as 200+ ms steps: DESIGN section 7)
     res = {k: [] for k in variants}
-    for rnd in range(3):
+    for rnd in range(5):
         for name, setup in variants.items():
             restore(); setup()
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(3): step()
             torch.cuda.synchronize(); res[name].append((time.perf_counter() - t0) / 3 * 1e3)
     restore()
-    for k, v in res.items(): print(f"{k:18s} " + " ".join(f"{x:7.1f}" for x in v) + f"   min {min(v):.1f} ms")
+    for k, v in res.items(): print(f"{k:18s} " + " ".join(f"{x:7.1f}" for x in v) + f"   min {min(v):.1f}  median {sorted(v)[len(v) // 2]:.1f} ms")
 main()
