@@ -71,6 +71,12 @@ class DiffusionEngine(nn.Module):
         self.overlap_optimizer = os.environ.get("NK_OPT_OVERLAP", "1") != "0"
         self._optimizer_stream: Optional[torch.cuda.Stream] = None
         self._optimizer_in_flight = False
+        # NK_OPT_STREAM=1: stream the update of each top-level UNet block behind that block's backward (_grads_ready).  Off by
+        # default -- measured 187.4 vs 184.9 ms/step (tools/ab_step.py, interleaved): the HBM-bound update steals bandwidth from a
+        # backward whose two streams already contend, while after backward it overlaps the next step's frozen VAE encoder for free.
+        self.stream_optimizer = os.environ.get("NK_OPT_STREAM", "0") == "1"
+        self._streaming_step = False
+        self._last_micro_batch = True
         self.store: Optional[FlatParamStore] = None
         self.last_log: dict = {}
         if ckpt_path is not None:
@@ -127,7 +133,54 @@ class DiffusionEngine(nn.Module):
             self.configure_ema(self.ema_decay_rate)
         if self.optimizer is not None and self._torch_optimizer is None:
             self.configure_optimizers()
+        self.model.diffusion_model.grad_ready_hook = self._grads_ready     # (a FlatDataParallel wrapper takes the hook over: N > 1)
         return self.store
+
+    def _block_boundaries(self) -> list:
+        """first tensor index (in store order) of every top-level UNet block: where the fused optimizer may cut its chunks"""
+        unet = self.model.diffusion_model
+        index = {id(p): i for i, p in enumerate(self.store.params)}
+        tops = [unet.time_embed, getattr(unet, "label_emb", None), *unet.input_blocks, unet.middle_block, *unet.output_blocks, unet.out]
+        out = []
+        for m in tops:
+            if m is None:
+                continue
+            idx = [index[id(p)] for p in m.parameters() if id(p) in index]
+            if idx:
+                out.append(min(idx))
+        return sorted(set(out))
+
+    def _grads_ready(self, module: nn.Module) -> None:
+        """UNetModel.grad_ready_hook: `module`'s parameter gradients have been enqueued (main stream + weight-gradient stream).
+        With the fused Adafactor, no data-parallel exchange and this being the step's last micro-batch, its slice of the update is
+        issued NOW on the optimizer stream: the HBM-bound update (22 B per parameter) runs beside the MFMA-bound rest of backward
+        instead of after it.  Same kernels on the same data as the one-shot update (per-tensor statistics never cross a block)."""
+        af = getattr(self, "adafactor", None)
+        if af is None or not self.stream_optimizer or not self._last_micro_batch or not self.store.master.is_cuda:
+            return
+        if self.model.diffusion_model.grad_ready_hook != self._grads_ready:       # a data-parallel wrapper owns the hook
+            return
+        idx = [p._nk_index for p in module.parameters() if getattr(p, "_nk_store", None) is self.store]
+        if not idx:
+            return
+        chunks = af.chunks_in(min(idx), max(idx) + 1)
+        if not chunks:
+            return
+        if self._optimizer_stream is None:
+            self._optimizer_stream = torch.cuda.Stream(device=self.store.master.device)
+        if not self._streaming_step:
+            self.join_optimizer()
+            af.begin_step()
+            self._streaming_step = True
+        opt = self._optimizer_stream
+        opt.wait_stream(torch.cuda.current_stream())
+        side = self.store.state.wgrad_stream
+        if side is not None:
+            opt.wait_stream(side)
+        with torch.cuda.stream(opt):
+            for ci in chunks:
+                af.step_chunk(ci, 1.0)
+        self._optimizer_in_flight = True
 
     def configure_optimizers(self):
         """models/diffusion.py:261-296: one parameter group for the UNet (plus `initial_lr` from `model.base_lr`), one per
@@ -142,6 +195,8 @@ class DiffusionEngine(nn.Module):
         unet_params = {"name": "UNet", "params": [p for p in self.model.parameters() if p.requires_grad]}
         if getattr(self.model, "base_lr", None) is not None:
             unet_params["initial_lr"] = self.model.base_lr
+        if self.store is not None:
+            unet_params["chunk_boundaries"] = self._block_boundaries()     # lets the fused update be streamed block by block
         param_groups = [unet_params]
         for embedder in getattr(self.conditioner, "embedders", ()):
             if getattr(embedder, "is_trainable", False):
@@ -203,6 +258,7 @@ class DiffusionEngine(nn.Module):
         backward of micro-batch `micro_batch_index` of an optimizer step.  The first micro-batch overwrites the gradients,
         later ones add; with a FlatDataParallel `dp`, only the last micro-batch exchanges them (DDP's no_sync)."""
         self.store.state.grad_accumulate = micro_batch_index > 0
+        self._last_micro_batch = bool(last)
         if dp is not None:
             dp.no_sync(not last)
 
@@ -213,6 +269,7 @@ class DiffusionEngine(nn.Module):
             raise RuntimeError("call setup_flat_params() first")
         from ..optim import FlatAdafactor
 
+        kwargs.setdefault("boundaries", self._block_boundaries())
         self.adafactor = FlatAdafactor(self.store, **kwargs)
         return self.adafactor
 
@@ -248,7 +305,14 @@ class DiffusionEngine(nn.Module):
             scope = torch.cuda.stream(self._optimizer_stream)
         with scope:
             opt = self._torch_optimizer
-            if opt is not None:
+            if self._streaming_step:                                  # most of the update already went out behind backward
+                if grad_scale != 1.0:
+                    raise RuntimeError("a streamed optimizer step cannot take a grad_scale: chunks were already applied with 1.0")
+                self.adafactor.end_step()
+                self._streaming_step = False
+                if opt is not None:
+                    opt._step_count = getattr(opt, "_step_count", 0) + 1       # what torch's LRScheduler looks at
+            elif opt is not None:
                 opt.step(grad_scale=grad_scale)                      # the config's optimizer object (fused underneath)
             elif getattr(self, "adafactor", None) is not None:
                 self.adafactor.step(grad_scale)

@@ -224,14 +224,16 @@ class FlatParamStore:
         # optimizer kernels refuse to apply an update while it is set (models/diffusion.DiffusionEngine.optimizer_step)
         self.state = ops.EngineState()
         with torch.no_grad():
-            for p, off in zip(self.params, self.offsets):
+            for i, (p, off) in enumerate(zip(self.params, self.offsets)):
                 n = p.numel()
+                p._nk_index = i
                 self.master[off:off + n].copy_(ops._phys_flat(p))
                 p.data = self._view(self.master, off, p)
                 p.grad = self._view(self.grad, off, p)
                 p._nk_shadow = self.shadow[off:off + n]
                 p._nk_store = self
                 p._nk_offset = off
+
         self.refresh()
 
     @staticmethod

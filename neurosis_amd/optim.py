@@ -51,7 +51,7 @@ class FlatAdafactor:
 
     def __init__(self, store, lr: Optional[float] = None, eps: tuple[float, float] = (1e-30, 1e-3), clip_threshold: float = 1.0,
                  decay_rate: float = -0.8, beta1: Optional[float] = None, weight_decay: float = 0.0, scale_parameter: bool = True,
-                 relative_step: bool = True, warmup_init: bool = False, chunk_bytes: Optional[int] = None):
+                 relative_step: bool = True, warmup_init: bool = False, chunk_bytes: Optional[int] = None, boundaries=None):
         if lr is not None and relative_step:
             raise ValueError("Cannot combine manual `lr` and `relative_step=True` options")
         if warmup_init and not relative_step:
@@ -67,6 +67,9 @@ class FlatAdafactor:
             import os
 
             chunk_bytes = int(os.environ.get("NK_AF_CHUNK_MB", "2048")) << 20
+        # `boundaries`: tensor indices at which a new chunk must begin (the first parameter of every top-level UNet block), so
+        # that a block's update can be issued as soon as that block's gradients are final, while backward is still running
+        bounds = set(int(b) for b in (boundaries or ()))
         self.store = store
         self.lr, self.eps, self.clip_threshold, self.decay_rate = lr, eps, clip_threshold, decay_rate
         self.weight_decay, self.scale_parameter, self.relative_step, self.warmup_init = weight_decay, scale_parameter, relative_step, warmup_init
@@ -86,7 +89,7 @@ class FlatAdafactor:
             if p.dim() >= 2 and p.dim() not in (2, 4):
                 raise NotImplementedError(f"FlatAdafactor: {p.dim()}-d parameters are not supported")
             nbytes = p.numel() * 4
-            if c_bytes and c_bytes + nbytes > chunk_bytes:   # close the current chunk before this tensor
+            if c_bytes and (c_bytes + nbytes > chunk_bytes or ti in bounds):   # close the current chunk before this tensor
                 self.chunks.append((c_t0, ti, c_i0, len(items), c_f0, len(fin)))
                 ws_max = max(ws_max, c_ws)
                 c_t0, c_i0, c_f0, c_bytes, c_ws = ti, len(items), len(fin), 0, 0
@@ -171,15 +174,36 @@ class FlatAdafactor:
 
     def step(self, grad_scale: float = 1.0) -> None:
         """One Adafactor update of every parameter (adafactor.py:162-255); also rewrites the bf16 shadows."""
+        self.begin_step()
+        for ci in range(len(self.chunks)):
+            self.step_chunk(ci, grad_scale)
+        self.end_step()
+
+    # -- the same update, chunk by chunk: a chunk may be issued as soon as ITS gradients are final (DiffusionEngine streams the
+    # update of each top-level block behind that block's backward).  Every per-step scalar (step count, beta2_t, relative step)
+    # is fixed by begin_step(); the per-tensor statistics never cross a chunk, so the order of chunks does not matter. ------------
+    def begin_step(self) -> None:
         if not self._p2_valid:
             self.refresh_param_norms()
         self.step_count += 1
-        beta2t = 1.0 - math.pow(self.step_count, self.decay_rate)
-        rel = self.rel_step(self.step_count)
-        stream = ops._stream()
-        for chunk in self.chunks:
-            a = self._args(chunk, beta2t, rel, grad_scale)
-            call("nk_adafactor_chunk", C.byref(a), stream)
+        self._beta2t = 1.0 - math.pow(self.step_count, self.decay_rate)
+        self._rel = self.rel_step(self.step_count)
+        self._done = [False] * len(self.chunks)
+
+    def step_chunk(self, ci: int, grad_scale: float = 1.0) -> None:
+        if self._done[ci]:
+            return
+        a = self._args(self.chunks[ci], self._beta2t, self._rel, grad_scale)
+        call("nk_adafactor_chunk", C.byref(a), ops._stream())
+        self._done[ci] = True
+
+    def chunks_in(self, tensor_lo: int, tensor_hi: int) -> list:
+        """indices of the chunks that lie entirely inside tensors [tensor_lo, tensor_hi)"""
+        return [ci for ci, c in enumerate(self.chunks) if c[0] >= tensor_lo and c[1] <= tensor_hi]
+
+    def end_step(self, grad_scale: float = 1.0) -> None:
+        for ci in range(len(self.chunks)):
+            self.step_chunk(ci, grad_scale)
         self.store._mark_fresh()
 
     # -- introspection mirroring the reference's per-parameter state --------------------------------

@@ -79,7 +79,8 @@ class Adafactor(Optimizer):
                 self._flat.append(FlatAdafactor(store, lr=g["lr"] if not g["relative_step"] else None, eps=tuple(g["eps"]),
                                                 clip_threshold=g["clip_threshold"], decay_rate=g["decay_rate"], beta1=g["beta1"],
                                                 weight_decay=g["weight_decay"], scale_parameter=g["scale_parameter"],
-                                                relative_step=g["relative_step"], warmup_init=g["warmup_init"]))
+                                                relative_step=g["relative_step"], warmup_init=g["warmup_init"],
+                                                boundaries=g.get("chunk_boundaries")))
             if self._pending_state is not None:
                 sd, self._pending_state = self._pending_state, None
                 self._load_flat(sd)

@@ -151,3 +151,35 @@ def test_optimizer_on_its_own_stream_equals_in_line(optimizer):
     assert float((finals[0] - finals[1]).norm() / finals[1].norm()) <= 1e-4
     moved = float((finals[1] - _build(fx, shapes).store.master).norm())
     assert moved > 0.0
+
+
+def test_streamed_optimizer_equals_the_one_shot_update():
+    """DiffusionEngine streams the fused Adafactor update of each top-level block behind that block's backward (its own stream,
+    _grads_ready): three steps must give the parameters, optimizer state and losses of the one-shot update after backward
+    (same kernels on the same data; tolerance covers the fp32 atomics of the split-K weight gradients)."""
+    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
+    finals, states, losses = [], [], []
+    for streamed in (True, False):
+        eng = _build(fx, shapes)
+        eng.stream_optimizer = streamed
+        af = eng.configure_adafactor(scale_parameter=True, relative_step=False, warmup_init=False, lr=1e-3)
+        assert len(af.chunks) >= 10                  # one chunk per top-level block at least
+        run = []
+        for _ in range(3):
+            loss = _loss(eng, fx, slice(0, 2))
+            loss.mean().backward()
+            assert eng._streaming_step is streamed   # the hook fired during backward (or not)
+            eng.optimizer_step()
+            assert eng._streaming_step is False and af._done == [True] * len(af.chunks)
+            run.append(loss.detach().float().cpu())
+        eng.join_optimizer()
+        torch.cuda.synchronize()
+        assert af.step_count == 3
+        finals.append(eng.store.master.clone())
+        states.append(af.state.clone())
+        losses.append(torch.stack(run))
+    assert float((losses[0] - losses[1]).abs().max() / losses[1].abs().max()) <= 2e-3
+    assert float((finals[0] - finals[1]).norm() / finals[1].norm()) <= 1e-4
+    assert float((states[0] - states[1]).norm() / states[1].norm()) <= 1e-3
+    assert float((finals[1] - _build(fx, shapes).store.master).norm()) > 0.0

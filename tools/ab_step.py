@@ -7,6 +7,7 @@ from neurosis_amd import ops
 def main():
     dev = torch.device("cuda", 0)
     eng = bench.build_engine(dev)
+    eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)
     gen = torch.Generator(device=dev).manual_seed(42); gen_cpu = torch.Generator().manual_seed(42)
     def step():
         batch = bench.synthetic_batch(dev, 4, (1024, 1024), gen)
@@ -18,12 +19,13 @@ def main():
     variants["base"] = lambda: None
     variants["no g2"] = lambda: os.environ.__setitem__("NK_GEMM_G2", "0")
     variants["batch"] = lambda: setattr(est, "batch_wgrads", True)
+    variants["opt streamed"] = lambda: setattr(eng, "stream_optimizer", True)
     for name in sys.argv[1:]:       # extra variants from the command line: ENV=VALUE[,ENV=VALUE...]
         kv = [a.split("=", 1) for a in name.split(",")]
         variants[name] = lambda kv=kv: [os.environ.__setitem__(k, v) for k, v in kv]
     extra_env = sorted({a.split("=", 1)[0] for name in sys.argv[1:] for a in name.split(",")})
     def restore():
-        est.wgrad_stream = side; est.batch_wgrads = False; est.norm_params_on_side_stream = False
+        est.wgrad_stream = side; est.batch_wgrads = False; eng.stream_optimizer = False; est.norm_params_on_side_stream = False
         os.environ["NK_GEMM_G2"] = "1"
         for k in extra_env: os.environ.pop(k, None)
     for _ in range(3): step()
