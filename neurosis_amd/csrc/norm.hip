@@ -593,6 +593,107 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const bf16_t* __restr
 
 static int ln_param_split(int M) { return (M + LNP_ROWS - 1) / LNP_ROWS; }
 
+// LayerNorm backward in ONE pass over x and dy: dx as in ln_bwd_dx_kernel, and -- from the same registers -- this wave's column
+// partials of dgamma (sum dy*xhat) and dbeta (sum dy), combined over the block's 8 waves in LDS in a fixed order and written as
+// one partial row per block (<= 512 rows for colpart_reduce_kernel: 5 MB at C = 1280 against the 21 MB the separate parameter
+// kernel re-read).  Algorithmic traffic 6 B/elem (+2 with dx_add); the two-kernel form moved 10.
+#define LNF_WAVES 8
+#define LNF_MAX_BLOCKS 512      // x 8 waves = one row per wave at M = 4096 (these 10 MB tensors are latency-bound: rows in flight matter more than bytes)
+template <int NCH>
+__global__ __launch_bounds__(LNF_WAVES * 64) void ln_bwd_fused_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                        const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
+                                                                        bf16_t* __restrict__ dx, float* __restrict__ part, int M, int C) {
+  extern __shared__ __attribute__((aligned(16))) char ln_smem[];
+  float* red = (float*)ln_smem;                     // [LNF_WAVES][2][C]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * LNF_WAVES + wv;
+  const int nwaves = gridDim.x * LNF_WAVES;
+  const int cpr = C >> 3;
+  const float invC = 1.0f / (float)C;
+  float gm[NCH][8], sg[NCH][8], sb[NCH][8];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int ch = lane + 64 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[j][e] = 0.f; sg[j][e] = 0.f; sb[j][e] = 0.f; }
+    if (ch < cpr) {
+      const float4_t g0 = *(const float4_t*)(gamma + ch * 8), g1 = *(const float4_t*)(gamma + ch * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gm[j][e] = g0[e]; gm[j][4 + e] = g1[e]; }
+    }
+  }
+  for (int row = wave; row < M; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    uint4_t rx[NCH], rd[NCH], ra[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int ch = lane + 64 * j;
+      rx[j] = rd[j] = ra[j] = (uint4_t){0u, 0u, 0u, 0u};
+      if (ch < cpr) {
+        rx[j] = *(const uint4_t*)(x + (long)row * C + ch * 8);
+        rd[j] = *(const uint4_t*)(dy + (long)row * C + ch * 8);
+        if (dx_add) ra[j] = *(const uint4_t*)(dx_add + (long)row * C + ch * 8);
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float fx[8], fd[8];
+      unpack8(rx[j], fx);
+      unpack8(rd[j], fd);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {   // lanes past the row hold zeros (dy = 0), so they add nothing
+        const float xh = (fx[e] - mu) * rs;
+        const float d = fd[e] * gm[j][e];
+        s1 += d;
+        s2 += d * xh;
+        sb[j][e] += fd[e];
+        sg[j][e] += fd[e] * xh;
+      }
+    }
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int ch = lane + 64 * j;
+      if (ch < cpr) {
+        float fx[8], fd[8], o[8];
+        unpack8(rx[j], fx);
+        unpack8(rd[j], fd);
+        unpack8(ra[j], o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += rs * (fd[e] * gm[j][e] - s1 - (fx[e] - mu) * rs * s2);
+        *(uint4_t*)(dx + (long)row * C + ch * 8) = pack8(o);
+      }
+    }
+  }
+  // this wave's column partials -> LDS -> one row per block, waves added in index order (bitwise reproducible)
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    int ch = lane + 64 * j;
+    if (ch < cpr) {
+      float* g = red + ((long)wv * 2) * C + ch * 8;
+      *(float4_t*)g = (float4_t){sg[j][0], sg[j][1], sg[j][2], sg[j][3]};
+      *(float4_t*)(g + 4) = (float4_t){sg[j][4], sg[j][5], sg[j][6], sg[j][7]};
+      *(float4_t*)(g + C) = (float4_t){sb[j][0], sb[j][1], sb[j][2], sb[j][3]};
+      *(float4_t*)(g + C + 4) = (float4_t){sb[j][4], sb[j][5], sb[j][6], sb[j][7]};
+    }
+  }
+  __syncthreads();
+  float* out = part + (long)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += LNF_WAVES * 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNF_WAVES; ++w) a += red[(long)w * 2 * C + c];
+    out[c] = a;
+  }
+}
+static int ln_fused_blocks(int M) {
+  int b = (M + LNF_WAVES - 1) / LNF_WAVES;
+  return b < 1 ? 1 : (b > LNF_MAX_BLOCKS ? LNF_MAX_BLOCKS : b);
+}
+
 extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                 float* rstd, int M, int C, float eps, void* stream) {
   NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
@@ -605,7 +706,10 @@ extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* 
   return nk_check_launch("ln_fwd_kernel");
 }
 
-extern "C" long nk_layernorm_ws_floats(int M, int C) { return (long)ln_param_split(M) * 2 * C + 64; }
+extern "C" long nk_layernorm_ws_floats(int M, int C) {
+  const long a = (long)ln_param_split(M), b = LNF_MAX_BLOCKS;
+  return (a > b ? a : b) * 2 * C + 64;
+}
 
 extern "C" int nk_layernorm_bwd_dx(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                    const void* dx_add, void* dx, int M, int C, void* stream_) {
@@ -637,7 +741,24 @@ extern "C" int nk_layernorm_bwd_params(const void* dy, const void* x, const floa
 
 extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
-                                int M, int C, int accumulate, void* stream) {
-  if (int e = nk_layernorm_bwd_dx(dy, x, gamma, mean, rstd, dx_add, dx, M, C, stream)) return e;
-  return nk_layernorm_bwd_params(dy, x, mean, rstd, dgamma, dbeta, ws, M, C, accumulate, stream);
+                                int M, int C, int accumulate, void* stream_) {
+  // one pass over x and dy for the input gradient AND the per-block parameter partials, then the single-writer column reduce
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
+  NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws);
+  const int blocks = ln_fused_blocks(M);
+  const int nch = ((C >> 3) + 63) / 64;
+  const int smem = LNF_WAVES * 2 * C * (int)sizeof(float);
+#define NK_LN_FUSED(NCH_)                                                                                                      \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ln_bwd_fused_kernel<NCH_>, hipFuncAttributeMaxDynamicSharedMemorySize, LNF_WAVES * 2 * 2048 * 4); attr = true; } \
+    hipLaunchKernelGGL(ln_bwd_fused_kernel<NCH_>, dim3(blocks), dim3(LNF_WAVES * 64), smem, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,   \
+                       (const bf16_t*)dx_add, (bf16_t*)dx, ws, M, C);                                                          \
+  } while (0)
+  if (nch <= 2) NK_LN_FUSED(2); else if (nch == 3) NK_LN_FUSED(3); else NK_LN_FUSED(4);
+#undef NK_LN_FUSED
+  if (int e = nk_check_launch("ln_bwd_fused_kernel")) return e;
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, ws, dgamma, dbeta, blocks, C, accumulate);
+  return nk_check_launch("colpart_reduce_kernel");
 }

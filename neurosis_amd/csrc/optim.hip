@@ -513,7 +513,8 @@ extern "C" int nk_adafactor_init(const NkAdafactorArgs* h, void* stream) {
 
 extern "C" int nk_adafactor_chunk(const NkAdafactorArgs* h, void* stream_) {
   if (int e = af_check(h)) return e;
-  if (int e = nk_health_poll()) return e;       // an earlier step's backward was flagged: refuse to go on silently
+  if (h->tensor_lo == 0)                        // first chunk of a step: an EARLIER step's backward was flagged -> refuse to go on silently
+    if (int e = nk_health_poll()) return e;     // (later chunks of the same step must not trip over this step's own snapshot)
   hipStream_t stream = (hipStream_t)stream_;
   NkAfArgs a = af_args(h);
   if (!a.health) { nk_set_error(__FILE__, __LINE__, "health word allocation failed"); return NK_ERR_LAUNCH; }

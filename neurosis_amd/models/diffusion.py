@@ -195,7 +195,7 @@ class DiffusionEngine(nn.Module):
         unet_params = {"name": "UNet", "params": [p for p in self.model.parameters() if p.requires_grad]}
         if getattr(self.model, "base_lr", None) is not None:
             unet_params["initial_lr"] = self.model.base_lr
-        if self.store is not None:
+        if self.store is not None and self.stream_optimizer:
             unet_params["chunk_boundaries"] = self._block_boundaries()     # lets the fused update be streamed block by block
         param_groups = [unet_params]
         for embedder in getattr(self.conditioner, "embedders", ()):
@@ -269,7 +269,8 @@ class DiffusionEngine(nn.Module):
             raise RuntimeError("call setup_flat_params() first")
         from ..optim import FlatAdafactor
 
-        kwargs.setdefault("boundaries", self._block_boundaries())
+        # block-aligned chunks only when the update is streamed behind backward: otherwise few, large chunks are faster
+        kwargs.setdefault("boundaries", self._block_boundaries() if self.stream_optimizer else None)
         self.adafactor = FlatAdafactor(self.store, **kwargs)
         return self.adafactor
 

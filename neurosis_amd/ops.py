@@ -534,11 +534,15 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
         dx = torch.empty_like(x)
+        ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
+        acc = state_of(weight).grad_accumulate
+        if not state_of(weight).norm_params_on_side_stream:
+            # one pass over x and dy: input gradient + per-block partials of the gamma / beta gradients, then a small column reduce
+            call("nk_layernorm_bwd", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add), dx.data_ptr(),
+                 grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, int(acc), _stream())
+            return dx
         call("nk_layernorm_bwd_dx", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
              dx.data_ptr(), M, Cc, _stream())
-        ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
-
-        acc = state_of(weight).grad_accumulate
 
         def params():   # gamma / beta gradients
             call("nk_layernorm_bwd_params", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),

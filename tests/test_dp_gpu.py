@@ -164,7 +164,7 @@ def test_streamed_optimizer_equals_the_one_shot_update():
         eng = _build(fx, shapes)
         eng.stream_optimizer = streamed
         af = eng.configure_adafactor(scale_parameter=True, relative_step=False, warmup_init=False, lr=1e-3)
-        assert len(af.chunks) >= 10                  # one chunk per top-level block at least
+        assert (len(af.chunks) >= 10) is streamed    # one chunk per top-level block at least when streaming, few large ones otherwise
         run = []
         for _ in range(3):
             loss = _loss(eng, fx, slice(0, 2))
