@@ -255,7 +255,10 @@ def pmc_traffic():
     --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; both are KB)."""
     import csv
 
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.csv")
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = os.path.join(prof, "r02_pmc_summary.csv")
+    if not os.path.exists(path):
+        path = os.path.join(prof, "r01_pmc_summary.csv")
     try:
         rows = list(csv.reader(open(path)))[1:]
     except OSError:
@@ -265,7 +268,7 @@ def pmc_traffic():
         if r[0].startswith("void nk_gemm"):
             n += float(r[1])
             b += float(r[1]) * (float(r[2]) + float(r[3]))
-    return (round(b / n), "profiles/r01_pmc_summary.csv") if n else (None, None)
+    return (round(b / n), "profiles/" + os.path.basename(path)) if n else (None, None)
 
 
 def main():
@@ -285,6 +288,9 @@ def main():
                     help="adafactor = the reference example config's optimizer (scale_parameter, relative_step, warmup_init); adamw = fused flat AdamW")
     ap.add_argument("--precomputed-te", action="store_true",
                     help="feed synthetic text-encoder outputs instead of running the frozen conditioner (CLIP-L + OpenCLIP-bigG) in the step")
+    ap.add_argument("--serialize", action="store_true",
+                    help="run EVERY step with the weight-gradient side stream and the optimizer stream disabled (one kernel at a time): the command whose "
+                         "rocprofv3 kernel trace is profiles/r02_gemm_serialized_kernel_stats.csv; not the metric's configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the multi-rank control flow)")
@@ -321,6 +327,9 @@ def main():
     if args.optimizer == "adafactor":
         eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)   # configs/sdxl/sdxl.example.yaml:158-164
     dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if args.wire_dtype == "bf16" else None) if world > 1 else None
+    if args.serialize:
+        eng.store.state.wgrad_stream = None
+        eng.overlap_optimizer = False
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     gen_cpu = torch.Generator().manual_seed(42 + rank)
 
@@ -404,23 +413,39 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        # every rank replays the step (it contains the gradient all-reduce: a collective); only rank 0 reports
-        timer = GemmTimer()
-        timer.install()
+        # Two instrumented replays of the same step (every rank: the step contains the gradient all-reduce, a collective; only
+        # rank 0 reports), HIP events around every tile-engine launch on the stream it is launched on:
+        #   in step     -- exactly as timed above: dgrad chain and weight gradients share the chip on two streams, so a launch's
+        #                  duration includes what the other stream costs it.  This is `achieved` / `frac`: it is what the rocprofv3
+        #                  kernel trace of this same command shows (profiles/r02_bench_kernel_stats.csv).
+        #   serialized  -- side stream off, one kernel at a time: the kernels' own speed (`achieved_serialized` / `frac_serialized`;
+        #                  trace of `bench.py --serialize`: profiles/r02_gemm_serialized_kernel_stats.csv).
         est = eng.store.state
-        side, est.wgrad_stream = est.wgrad_stream, None  # no overlapping launches while timing kernels
-        try:
-            step()
-        finally:
-            est.wgrad_stream = side
-            timer.uninstall()
-        f, ms, n, per = timer.summary()
-        ach = f / (ms * 1e-3) / 1e12
+
+        def replay(serialized: bool):
+            timer = GemmTimer()
+            timer.install()
+            side = est.wgrad_stream
+            if serialized:
+                est.wgrad_stream = None
+            try:
+                step()
+            finally:
+                est.wgrad_stream = side
+                timer.uninstall()
+            return timer.summary()
+
+        f, ms, n, per = replay(serialized=bool(args.serialize))
+        fs, mss, ns, pers = replay(serialized=True)
+        ach, ach_s = f / (ms * 1e-3) / 1e12, fs / (mss * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "nk_gemm_kernel<*> (MFMA tile engine: linear+conv fwd/dgrad/wgrad)", "launches_per_step": n,
-                    "avg_launch_us": round(ms * 1e3 / n, 2), "algorithmic_tflop_per_step": round(f / 1e12, 2), "kernel_ms_per_step": round(ms, 2),
+                    "frac_in_step": round(ach / PEAK_BF16_TFLOPS, 4), "achieved_serialized": round(ach_s, 2), "frac_serialized": round(ach_s / PEAK_BF16_TFLOPS, 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "nk_gemm_*_kernel<*> (MFMA tile engine: linear+conv fwd/dgrad/wgrad)", "launches_per_step": n,
+                    "avg_launch_us": round(ms * 1e3 / n, 2), "avg_launch_us_serialized": round(mss * 1e3 / ns, 2), "algorithmic_tflop_per_step": round(f / 1e12, 2),
+                    "algorithmic_gflop_per_launch": round(f / n / 1e9, 2), "kernel_ms_per_step": round(ms, 2), "kernel_ms_per_step_serialized": round(mss, 2),
                     "by_entry_point": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in per.items()},
+                    "by_entry_point_serialized": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in pers.items()},
                     "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_IMAGE / PEAK_BF16_TFLOPS, 4)}
     if world > 1:
         dist.barrier()

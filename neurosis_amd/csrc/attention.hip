@@ -132,29 +132,77 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p
   float m = NEG_BIG, l = 0.f;
 
   const int nt = (p.Lk + 63) / 64;
-  TileLoader<64, DP, NW * 64> lk, lv;
-  lk.load(Kb, p.sk, 0, p.Lk, p.D, tid);
-  lv.load(Vb, p.sv, 0, p.Lk, p.D, tid);
-  lk.store(smem, tid);
-  lv.store(smem + TILE, tid);
+  // K/V tiles travel global -> registers -> LDS (double-buffered LDS), with the global loads TWO tiles ahead: tile t + 2 is
+  // requested at the top of iteration t and written to LDS at the bottom of iteration t + 1.  One tile ahead (the first version)
+  // left a single iteration of compute (~1 us) to cover a loaded-chip memory latency of 1-2 us: every shape ran ~2-2.9 us per
+  // iteration, whatever its arithmetic (MFMA busy 0.18).  Two register sets, named statically (the loop is unrolled by two).
+  // (head dims > 64 keep one tile ahead: their tiles are larger and a second register set would spill)
+  constexpr int PFD = 1;   // (two ahead, a second register set, measured +1..2 % only: the loop was not waiting on global memory)
+  TileLoader<64, DP, NW * 64> lkA, lvA, lkB, lvB;
+  lkA.load(Kb, p.sk, 0, p.Lk, p.D, tid);
+  lvA.load(Vb, p.sv, 0, p.Lk, p.D, tid);
+  lkA.store(smem, tid);
+  lvA.store(smem + TILE, tid);
+  if (PFD == 2 && nt > 1) {
+    lkA.load(Kb, p.sk, 64, p.Lk, p.D, tid);
+    lvA.load(Vb, p.sv, 64, p.Lk, p.D, tid);
+  }
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
+  auto iteration = [&](int t, TileLoader<64, DP, NW * 64>& useK, TileLoader<64, DP, NW * 64>& useV, TileLoader<64, DP, NW * 64>& pfK,
+                       TileLoader<64, DP, NW * 64>& pfV) {
     const char* kt = smem + (t & 1) * 2 * TILE;
     const char* vt = kt + TILE;
-    const bool more = t + 1 < nt;
-    if (more) {
-      lk.load(Kb, p.sk, (t + 1) * 64, p.Lk, p.D, tid);
-      lv.load(Vb, p.sv, (t + 1) * 64, p.Lk, p.D, tid);
+    if (t + PFD < nt) {
+      pfK.load(Kb, p.sk, (t + PFD) * 64, p.Lk, p.D, tid);
+      pfV.load(Vb, p.sv, (t + PFD) * 64, p.Lk, p.D, tid);
     }
     float16_t s[2];
+    if constexpr (DP == 64) {
+      // All eight K fragments of the tile in ONE batch, one wait, then the eight MFMAs.  Left to hipcc (168-register cap) the
+      // loop was  ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma  eight times over through one fragment register: a full LDS
+      // latency in front of every MFMA.  Inline asm so that the reads stay where they are put (section 5.7 of the cdna guide).
+      typedef __attribute__((address_space(3))) const char* lds_c;
+      const unsigned ka = (unsigned)(size_t)(lds_c)kt + (unsigned)((lane & 31) * RS + 16 * (lane >> 5));
+      bf16x8_t kf[2][4];
+#define ATT_RD128(dst, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ka), "n"(OFF))
+      ATT_RD128(kf[0][0], 0); ATT_RD128(kf[0][1], 32); ATT_RD128(kf[0][2], 64); ATT_RD128(kf[0][3], 96);
+      ATT_RD128(kf[1][0], 32 * RS); ATT_RD128(kf[1][1], 32 * RS + 32); ATT_RD128(kf[1][2], 32 * RS + 64); ATT_RD128(kf[1][3], 32 * RS + 96);
+#undef ATT_RD128
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+      for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[hf][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[hf][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, RS, hf * 32, ks, lane), qf[ks], s[hf], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[hf][ks], qf[ks], s[hf], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[hf][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, RS, hf * 32, ks, lane), qf[ks], s[hf], 0, 0, 0);
+      }
+    }
+    // the V^T fragments of the P.V product are requested NOW (DP == 64): they do not depend on P, and the softmax arithmetic below
+    // (~800 issue cycles) covers their LDS latency
+    short4_t vlo[2][2][2], vhi[2][2][2];
+    if constexpr (DP == 64) {
+      typedef __attribute__((address_space(3))) const char* lds_c;
+      const int g4 = lane >> 4, i16 = lane & 15;
+      const unsigned va = (unsigned)(size_t)(lds_c)vt + (unsigned)((4 * (g4 >> 1) + (i16 >> 2)) * RS + (16 * (g4 & 1) + 4 * (i16 & 3)) * 2);
+#define ATT_RDTR(dst, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(va), "n"(OFF))
+#define ATT_RDV(hf, s2, dt)                                                                                              \
+      ATT_RDTR(vlo[hf][s2][dt], ((hf) * 32 + 16 * (s2)) * RS + (dt) * 64);                                               \
+      ATT_RDTR(vhi[hf][s2][dt], ((hf) * 32 + 16 * (s2) + 8) * RS + (dt) * 64)
+      ATT_RDV(0, 0, 0); ATT_RDV(0, 0, 1); ATT_RDV(0, 1, 0); ATT_RDV(0, 1, 1); ATT_RDV(1, 0, 0); ATT_RDV(1, 0, 1); ATT_RDV(1, 1, 0); ATT_RDV(1, 1, 1);
+#undef ATT_RDV
+#undef ATT_RDTR
     }
     // keys beyond Lk exist only in the last tile (wave-uniform branch); the causal variant (text transformers, L = 77)
     // masks every tile it visits
@@ -196,22 +244,51 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p
     }
     m = mnew;
     l += lsum;
+    if constexpr (DP == 64) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vlo[0][0][0]), "+v"(vlo[0][0][1]), "+v"(vlo[0][1][0]), "+v"(vlo[0][1][1]), "+v"(vlo[1][0][0]), "+v"(vlo[1][0][1]), "+v"(vlo[1][1][0]),
+                     "+v"(vlo[1][1][1]), "+v"(vhi[0][0][0]), "+v"(vhi[0][0][1]), "+v"(vhi[0][1][0]), "+v"(vhi[0][1][1]), "+v"(vhi[1][0][0]), "+v"(vhi[1][0][1]),
+                     "+v"(vhi[1][1][0]), "+v"(vhi[1][1][1]));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+      for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8_t pf = pack_frag(s[hf], s2);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8_t pf = pack_frag(s[hf], s2);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vt, RS, hf * 32 + 16 * s2, dt * 32, lane), pf,
-                                                             oacc[dt], 0, 0, 0);
-      }
-    if (more) {
+          for (int dt = 0; dt < 2; ++dt) {
+            short8_t r;
+            r[0] = vlo[hf][s2][dt][0]; r[1] = vlo[hf][s2][dt][1]; r[2] = vlo[hf][s2][dt][2]; r[3] = vlo[hf][s2][dt][3];
+            r[4] = vhi[hf][s2][dt][0]; r[5] = vhi[hf][s2][dt][1]; r[6] = vhi[hf][s2][dt][2]; r[7] = vhi[hf][s2][dt][3];
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, r), pf, oacc[dt], 0, 0, 0);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8_t pf = pack_frag(s[hf], s2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vt, RS, hf * 32 + 16 * s2, dt * 32, lane), pf,
+                                                               oacc[dt], 0, 0, 0);
+        }
+    }
+    if (t + 1 < nt) {     // tile t + 1 was requested an iteration ago: it has had this whole iteration to arrive
       char* nk_ = smem + ((t + 1) & 1) * 2 * TILE;
-      lk.store(nk_, tid);
-      lv.store(nk_ + TILE, tid);
+      useK.store(nk_, tid);
+      useV.store(nk_ + TILE, tid);
     }
     __syncthreads();
+  };
+  if constexpr (PFD == 2) {
+    for (int t = 0; t < nt; t += 2) {
+      iteration(t, lkA, lvA, lkB, lvB);
+      if (t + 1 < nt) iteration(t + 1, lkB, lvB, lkA, lvA);
+    }
+  } else {
+    for (int t = 0; t < nt; ++t) iteration(t, lkA, lvA, lkA, lvA);
   }
 
   l += __shfl_xor(l, 32, 64);

@@ -19,23 +19,33 @@ def main():
     variants["base"] = lambda: None
     variants["no g2"] = lambda: os.environ.__setitem__("NK_GEMM_G2", "0")
     variants["batch"] = lambda: setattr(est, "batch_wgrads", True)
-    variants["opt streamed"] = lambda: setattr(eng, "stream_optimizer", True)
+    variants["batch+mask7"] = lambda: (setattr(est, "batch_wgrads", True), os.environ.__setitem__("NK_GEMM_G2_MASK", "7"))
+    variants["mask7"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "7")
     for name in sys.argv[1:]:       # extra variants from the command line: ENV=VALUE[,ENV=VALUE...]
         kv = [a.split("=", 1) for a in name.split(",")]
         variants[name] = lambda kv=kv: [os.environ.__setitem__(k, v) for k, v in kv]
     extra_env = sorted({a.split("=", 1)[0] for name in sys.argv[1:] for a in name.split(",")})
     def restore():
         est.wgrad_stream = side; est.batch_wgrads = False; eng.stream_optimizer = False; est.norm_params_on_side_stream = False
-        os.environ["NK_GEMM_G2"] = "1"
+        os.environ["NK_GEMM_G2"] = "1"; os.environ.pop("NK_GEMM_G2_MASK", None)
         for k in extra_env: os.environ.pop(k, None)
     for _ in range(3): step()
     import gc; gc.collect(); gc.freeze()      # (the cyclic GC's full collections otherwise show up as 200+ ms steps: DESIGN section 7)
+    hp = torch.cuda.Stream(priority=-1)       # "main work on a high-priority stream" variants: name starts with "hp"
+    variants["hp main stream"] = lambda: None
+    variants["hp main + mask7"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "7")
     res = {k: [] for k in variants}
     for rnd in range(5):
         for name, setup in variants.items():
             restore(); setup()
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(3): step()
+            if name.startswith("hp"):
+                hp.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(hp):
+                    for _ in range(3): step()
+                torch.cuda.current_stream().wait_stream(hp)
+            else:
+                for _ in range(3): step()
             torch.cuda.synchronize(); res[name].append((time.perf_counter() - t0) / 3 * 1e3)
     restore()
     for k, v in res.items(): print(f"{k:18s} " + " ".join(f"{x:7.1f}" for x in v) + f"   min {min(v):.1f}  median {sorted(v)[len(v) // 2]:.1f} ms")
