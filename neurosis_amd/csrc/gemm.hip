@@ -655,10 +655,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
-  const int per_group = GROUP_M * ntn;
+  const int GMv = p.group_m;      // rows of a tile patch: ~sqrt(tiles per XCD), so that an XCD's tiles share as few operand panels as possible
+  const int per_group = GMv * ntn;
   const int group = wg / per_group;
-  const int first_m = group * GROUP_M;
-  const int gm = min(GROUP_M, ntm - first_m);
+  const int first_m = group * GMv;
+  const int gm = min(GMv, ntm - first_m);
   const int in_group = wg - group * per_group;
   const int nt = in_group / gm;
   const int mt = first_m + (in_group - nt * gm);
@@ -779,10 +780,11 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
-  const int per_group = GROUP_M * ntn;
+  const int GMv = p.group_m;      // rows of a tile patch: ~sqrt(tiles per XCD), so that an XCD's tiles share as few operand panels as possible
+  const int per_group = GMv * ntn;
   const int group = wg / per_group;
-  const int first_m = group * GROUP_M;
-  const int gm = min(GROUP_M, ntm - first_m);
+  const int first_m = group * GMv;
+  const int gm = min(GMv, ntm - first_m);
   const int in_group = wg - group * per_group;
   const int nt = in_group / gm;
   const int mt = first_m + (in_group - nt * gm);
@@ -1764,7 +1766,9 @@ static bool use_v1() {
 }
 
 template <int AMODE, int BMODE, int OUT_F32>
-static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
+static int launch(const NkGemmParams& p_in, int splitk, hipStream_t stream) {
+  NkGemmParams p2 = p_in;
+  const NkGemmParams& p = p2;
   static bool attr_set = false;
   auto kern1 = nk_gemm_kernel<AMODE, BMODE, OUT_F32>;
   auto kern4 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32, 4>;
@@ -1777,6 +1781,13 @@ static int launch(const NkGemmParams& p, int splitk, hipStream_t stream) {
   }
   int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, splitk, p.nbatch ? p.nbatch : 1);
+  {  // patch height: with T tiles over 8 XCDs an XCD runs ~T/8 tiles at a time; a gm x (T/8/gm) patch touches gm + T/8/gm operand
+     // panels, least at gm = sqrt(T/8).  (A fixed 8 gave a 100-tile weight gradient 8 x 1.5 patches: 10 panels per XCD where 7 do.)
+    int per_xcd = (ntm * ntn + 7) / 8, g = 1;
+    while ((g + 1) * (g + 1) <= per_xcd) ++g;
+    if (const char* e = getenv("NK_GEMM_GROUP_M")) g = atoi(e);
+    p2.group_m = g < 1 ? 1 : (g > GROUP_M ? GROUP_M : g);
+  }
   // 8 waves per 128x128 tile by default: measured +4..14 % over 4 waves on every SDXL shape (A/B: NK_GEMM_NW=4)
   int nw = 8;
   if (const char* e = getenv("NK_GEMM_NW")) nw = atoi(e);

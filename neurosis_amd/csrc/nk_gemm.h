@@ -39,6 +39,7 @@ struct NkGemmParams {
   long ld_rowvec;
   FastDiv fRowsPerBatch;
   int ksplit_len;
+  int group_m;              // rows of the XCD-local tile patch (nk_gemm_dma_kernel / nk_gemm_ring_kernel), set by the launcher
   int accumulate;           // fp32 output: 0 = store, 1 = atomic add
   // batched launch: blockIdx.z selects one of nbatch (<= NK_MAX_BATCH) problems of identical shape
   int nbatch;
