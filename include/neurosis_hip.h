@@ -60,6 +60,13 @@ int nk_debug_raise_health(void* stream);
 
 /* `count` (<= 8) weight gradients of identical shape in ONE launch: the three 1280x1280 projections of a transformer
  * block are 100 tiles each, far below one workgroup per CU on their own.  dy / x / dw are HOST arrays of device pointers. */
+/* `count` (<= 8) bias-free nn.Linear forwards of identical shape in ONE launch: y[i] = x[i] @ w[i]^T.  Serves the key / value
+ * projections of cross-attention (reference modules/attention.py:383-385, `k = self.to_k(context); v = self.to_v(context)`): the
+ * context is the same for all 70 transformer blocks of a step and does not depend on the UNet's activations, so UNetModel.fwd
+ * projects it for every block up front, eight blocks per launch (308 x 2560 x 2048 each: 60 tiles alone, 480 together). */
+int nk_linear_fwd_batched(const void* const* x, const void* const* w, void* const* y, int count, int M, int N, int K,
+                          long ldx, long ldw, long ldy, void* stream);
+
 int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, int count, int M, int N, int K,
                             long lddy, long ldx, long lddw, int accumulate, void* stream);
 

@@ -29,6 +29,25 @@ extern "C" int nk_linear_fwd(const void* x, const void* w, const float* bias, co
   return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_KC, 0, 0, (hipStream_t)stream);
 }
 
+extern "C" int nk_linear_fwd_batched(const void* const* x, const void* const* w, void* const* y, int count, int M, int N, int K,
+                                     long ldx, long ldw, long ldy, void* stream) {
+  // `count` (<= 8) bias-free projections of IDENTICAL shape in one launch (blockIdx.z): y[i][M,N] = x[i][M,K] @ w[i][N,K]^T.
+  // Host pointer arrays; the device pointers are copied into the kernel arguments.
+  NK_CHECK_ARG(x && w && y && count >= 1 && count <= NK_MAX_BATCH);
+  NkGemmParams p = zero_params();
+  p.lda = ldx; p.ldb = ldw;
+  p.M = M; p.N = N; p.K = K;
+  p.ldc = ldy;
+  p.nbatch = count;
+  for (int i = 0; i < count; ++i) {
+    p.Ab[i] = (const bf16_t*)x[i];
+    p.Bb[i] = (const bf16_t*)w[i];
+    p.Cb[i] = y[i];
+  }
+  p.A = p.Ab[0]; p.B = p.Bb[0]; p.C = p.Cb[0];
+  return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_KC, 0, 0, (hipStream_t)stream);
+}
+
 extern "C" int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add, void* dx, int M, int N, int K,
                                long lddy, long ldw, long ldadd, long lddx, void* stream) {
   // dx[M,K] = dy[M,N] @ w[N,K]  : reduction over N; w is r-contiguous (r = K index)

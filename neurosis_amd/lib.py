@@ -37,6 +37,7 @@ SIGNATURES: dict[str, list] = {
     "nk_linear_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, f32, vp],
     "nk_linear_dgrad": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "nk_linear_wgrad": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp],
+    "nk_linear_fwd_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, vp],
     "nk_linear_wgrad_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, i32, vp],
     "nk_conv2d_fwd": [cdp, vp, vp, vp, vp, vp, vp, vp],
     "nk_conv2d_dgrad": [cdp, vp, vp, vp, vp],

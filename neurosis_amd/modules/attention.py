@@ -126,7 +126,12 @@ class CrossAttention(nn.Module):
         fused_kv = adjacent(wk, wv)
         if fused_kv:
             w_kv = torch.as_strided(ops.shadow(wk), (2 * inner, wk.shape[1]), (wk.shape[1], 1))
-            kv = ops.gemm_nt(ctx, w_kv)
+            # UNetModel.fwd projects the (block-independent) context for every cross-attention up front, eight blocks per launch,
+            # and leaves the result here; anything else (a lone module, a checkpointed re-run) projects it now
+            pre = self.__dict__.pop("_nk_kv", None) if not self_attn else None
+            kv = pre[0] if pre is not None and pre[1] is ctx else None       # (only the projection of THIS context object)
+            if kv is None:
+                kv = ops.gemm_nt(ctx, w_kv)
             k, v = kv[:, :inner], kv[:, inner:]
         else:
             k = ops.gemm_nt(ctx, ops.w2d(wk))

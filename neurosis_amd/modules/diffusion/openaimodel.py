@@ -8,6 +8,8 @@ autograd node for the whole network), not a PyTorch op graph.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, List, Optional, Union
 
 import torch
@@ -395,6 +397,30 @@ class UNetModel(nn.Module):
         o, b2 = linear_module_fwd(seq[2], s)
         return o, (lambda g: b0(b1(b2(g))))
 
+    def _project_context(self, context: Tensor) -> None:
+        """`to_k(context)`, `to_v(context)` of EVERY cross-attention of the network before the first block runs (reference
+        modules/attention.py:383-385 computes them inside each block): the context does not depend on the UNet's activations, and
+        one 308-row projection is 60 tiles on a 256-CU chip (24-26 us each, 70 per step).  Same-shape projections go out eight per
+        launch (ops.gemm_nt_batched); each module picks its result up in CrossAttention.fwd."""
+        from ..attention import BasicTransformerBlock
+        from ...nn import adjacent
+
+        if getattr(self, "_nk_cross", None) is None:
+            self._nk_cross = [blk.attn2 for blk in self.modules() if isinstance(blk, BasicTransformerBlock)]
+        groups = {}
+        for att in self._nk_cross:
+            wk, wv = att.to_k.weight, att.to_v.weight
+            if wk.shape[1] != context.shape[1] or not adjacent(wk, wv):
+                continue
+            groups.setdefault((wk.shape[0], wk.shape[1]), []).append(att)
+        for (inner, cdim), atts in groups.items():
+            if len(atts) < 2:
+                continue
+            ws = [torch.as_strided(ops.shadow(a.to_k.weight), (2 * inner, cdim), (cdim, 1)) for a in atts]
+            outs = ops.gemm_nt_batched([context] * len(atts), ws)
+            for a, kv in zip(atts, outs):
+                a._nk_kv = (kv, context)
+
     def fwd(self, x: Img, timesteps: Tensor, context: Optional[Tensor], y: Optional[Tensor]):
         """x: Img with channels padded to a multiple of 8.  Returns (out Img (padded channels), bwd);
         bwd(dout tokens) -> dx tokens or None."""
@@ -405,6 +431,8 @@ class UNetModel(nn.Module):
         if self.num_classes is not None:
             lab, b_label = self._mlp_fwd(self.label_emb[0], y, need_dx=False)
             emb = ops.add(emb, lab)
+        if context is not None and os.environ.get("NK_KV_HOIST", "1") != "0":     # (read per call: tools/ab_step.py flips it)
+            self._project_context(context)
         hs: List[Img] = []
         tape = []
         h = x

@@ -365,6 +365,26 @@ def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optio
     return out
 
 
+def gemm_nt_batched(xs, ws, outs=None):
+    """[x_i @ w_i^T] for same-shape bias-free problems, up to eight per launch (nk_linear_fwd_batched).  xs / ws: lists of 2-D bf16
+    matrices (unit inner stride, equal shapes and row strides); returns the list of outputs."""
+    M, K = xs[0].shape
+    N = ws[0].shape[0]
+    for x, w in zip(xs, ws):
+        _check2d(x, "x")
+        _check2d(w, "w")
+        if x.shape != (M, K) or w.shape != (N, K) or x.stride(0) != xs[0].stride(0) or w.stride(0) != ws[0].stride(0):
+            raise ValueError("gemm_nt_batched: every problem must have the same shape and strides")
+    if outs is None:
+        outs = [torch.empty(M, N, dtype=BF16, device=xs[0].device) for _ in xs]
+    for i in range(0, len(xs), 8):
+        n = min(8, len(xs) - i)
+        arr = C.c_void_p * n
+        call("nk_linear_fwd_batched", arr(*[t.data_ptr() for t in xs[i:i + n]]), arr(*[t.data_ptr() for t in ws[i:i + n]]),
+             arr(*[t.data_ptr() for t in outs[i:i + n]]), n, M, N, K, xs[0].stride(0), ws[0].stride(0), outs[0].stride(0), _stream())
+    return outs
+
+
 def gemm_nn(dy: Tensor, w: Tensor, dx_add: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """dx = dy @ w + dx_add ; dy [M,N], w [N,K]."""
     _check2d(dy, "dy")
