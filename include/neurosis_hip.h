@@ -64,6 +64,11 @@ int nk_debug_raise_health(void* stream);
  * projections of cross-attention (reference modules/attention.py:383-385, `k = self.to_k(context); v = self.to_v(context)`): the
  * context is the same for all 70 transformer blocks of a step and does not depend on the UNet's activations, so UNetModel.fwd
  * projects it for every block up front, eight blocks per launch (308 x 2560 x 2048 each: 60 tiles alone, 480 together). */
+/* column sums of `nbatch` consecutive row blocks of M rows each: out[b][N] (+)= sum_rows dy[b*M + r][:].  The per-image gradient of
+ * the ResBlock embedding projection (h += emb_out[:, :, None, None], reference openaimodel.py:331-333 -> d emb_out[n] = sum over
+ * image n's pixels) in one pair of launches instead of one per image.  ws: nbatch * nk_colsum_ws_floats(M, N) floats. */
+int nk_colsum_batched(const void* dy, float* out, float* ws, long M, int N, long ld, int nbatch, int accumulate, void* stream);
+
 int nk_linear_fwd_batched(const void* const* x, const void* const* w, void* const* y, int count, int M, int N, int K,
                           long ldx, long ldw, long ldy, void* stream);
 

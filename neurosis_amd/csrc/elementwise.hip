@@ -317,6 +317,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
   const int cx = tid & 15, ry = tid >> 4;
   const int chunk = blockIdx.y * 16 + cx;
   const bool cok = chunk < (N >> 3);
+  dy += (long)blockIdx.z * M * ld;                     // batched form: blockIdx.z = one of gridDim.z row blocks of M rows each
+  part += (long)blockIdx.z * gridDim.x * N;
   const long row_lo = (long)blockIdx.x * rows_per_block;
   const long row_hi = row_lo + rows_per_block < M ? row_lo + rows_per_block : M;
   float s[8];
@@ -357,6 +359,8 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
   __shared__ float sa[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
+  part += (long)blockIdx.y * nsplit * N;               // batched form: blockIdx.y = row block
+  out += (long)blockIdx.y * N;
   float a = 0.f;
   if (c < N)
 #pragma unroll 4
@@ -371,6 +375,16 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
 }
 static int colsum_split(long M) { const int rows = colsum_rows(M); return (int)((M + rows - 1) / rows); }
 extern "C" long nk_colsum_ws_floats(long M, int N) { return (long)colsum_split(M) * N + 64; }
+extern "C" int nk_colsum_batched(const void* dy, float* out, float* ws, long M, int N, long ld, int nbatch, int accumulate, void* stream_) {
+  // out[b][N] (+)= column sums of rows [b*M, (b+1)*M) of dy, b < nbatch, in ONE pair of launches (ws: nbatch x nk_colsum_ws_floats(M, N))
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(dy && out && ws && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0 && nbatch >= 1 && nbatch <= 65535);
+  const int nsplit = colsum_split(M);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nsplit, (N + 127) / 128, nbatch), dim3(256), 0, stream, (const bf16_t*)dy, ws, M, N, ld, colsum_rows(M));
+  if (int e = nk_check_launch("colsum_partial")) return e;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 63) / 64, nbatch), dim3(1024), 0, stream, ws, out, nsplit, N, accumulate);
+  return nk_check_launch("colsum_reduce");
+}
 extern "C" int nk_colsum(const void* dy, float* out, float* ws, long M, int N, long ld, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(dy && out && ws && M > 0 && N > 0 && (N & 7) == 0 && (ld & 7) == 0);

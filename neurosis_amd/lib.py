@@ -76,6 +76,7 @@ SIGNATURES: dict[str, list] = {
     "nk_cast_f32_to_bf16": [vp, vp, i64, vp],
     "nk_cast_bf16_to_f32": [vp, vp, i64, vp],
     "nk_colsum": [vp, vp, vp, i64, i32, i64, i32, vp],
+    "nk_colsum_batched": [vp, vp, vp, i64, i32, i64, i32, i32, vp],
     "nk_timestep_embedding": [vp, vp, i32, i32, f32, vp],
     "nk_edm_prepare": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "nk_edm_loss": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],

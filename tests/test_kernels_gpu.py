@@ -365,3 +365,23 @@ def test_256x256_kernels_agree_bit_for_bit():
     tool = Path(__file__).resolve().parent.parent / "tools" / "race_screen_xl.py"
     run = subprocess.run([sys.executable, str(tool), "6"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "race screen: clean" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+def test_colsum_batched_and_linear_fwd_batched(ops):
+    """per-image column sums in one pair of launches; eight same-shape projections in one launch (the hoisted key / value
+    projections of cross-attention)"""
+    import ctypes as C
+
+    from neurosis_amd.lib import call, query
+
+    nb, M, N = 4, 1000, 320
+    dy = rnd(nb * M, N)
+    out = torch.full((nb, N), 5.0, device="cuda")
+    ws = torch.empty(nb * query("nk_colsum_ws_floats", M, N), device="cuda")
+    call("nk_colsum_batched", dev(dy).data_ptr(), out.data_ptr(), ws.data_ptr(), M, N, N, nb, 0, ops._stream())
+    assert_close(out, dy.view(nb, M, N).sum(1), TOL_F32, "colsum_batched")
+    x = rnd(308, 2048)
+    ws_ = [rnd(2560, 2048, scale=2048 ** -0.5, seed=i) for i in range(11)]      # 8 + 3: two launches
+    outs = ops.gemm_nt_batched([dev(x)] * 11, [dev(w) for w in ws_])
+    for w, o in zip(ws_, outs):
+        assert_close(o, x @ w.t(), TOL_BF16, "linear_fwd_batched")
