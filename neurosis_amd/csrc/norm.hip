@@ -598,6 +598,7 @@ static int ln_param_split(int M) { return (M + LNP_ROWS - 1) / LNP_ROWS; }
 // one partial row per block (<= 512 rows for colpart_reduce_kernel: 5 MB at C = 1280 against the 21 MB the separate parameter
 // kernel re-read).  Algorithmic traffic 6 B/elem (+2 with dx_add); the two-kernel form moved 10.
 #define LNF_WAVES 8
+#define LNF_SLOTS 2
 #define LNF_MAX_BLOCKS 512      // x 8 waves = one row per wave at M = 4096 (these 10 MB tensors are latency-bound: rows in flight matter more than bytes)
 template <int NCH>
 __global__ __launch_bounds__(LNF_WAVES * 64) void ln_bwd_fused_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
@@ -605,7 +606,8 @@ __global__ __launch_bounds__(LNF_WAVES * 64) void ln_bwd_fused_kernel(const bf16
                                                                         const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
                                                                         bf16_t* __restrict__ dx, float* __restrict__ part, int M, int C) {
   extern __shared__ __attribute__((aligned(16))) char ln_smem[];
-  float* red = (float*)ln_smem;                     // [LNF_WAVES][2][C]
+  float* red = (float*)ln_smem;                     // [LNF_SLOTS][2][C]: the 8 waves fold into 2 slots in 4 rounds (20 KB at C = 1280, not 80:
+                                                    // a block that needs half a CU's LDS cannot slip in beside the GEMMs of the other stream)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * LNF_WAVES + wv;
   const int nwaves = gridDim.x * LNF_WAVES;
@@ -668,26 +670,31 @@ __global__ __launch_bounds__(LNF_WAVES * 64) void ln_bwd_fused_kernel(const bf16
       }
     }
   }
-  // this wave's column partials -> LDS -> one row per block, waves added in index order (bitwise reproducible)
+  // this wave's column partials -> LDS -> one row per block.  Waves 2r and 2r+1 write (round 0) or add (rounds 1..3) into slots 0
+  // and 1, always in the same order, so the sums are bitwise reproducible.
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) {
-    int ch = lane + 64 * j;
-    if (ch < cpr) {
-      float* g = red + ((long)wv * 2) * C + ch * 8;
-      *(float4_t*)g = (float4_t){sg[j][0], sg[j][1], sg[j][2], sg[j][3]};
-      *(float4_t*)(g + 4) = (float4_t){sg[j][4], sg[j][5], sg[j][6], sg[j][7]};
-      *(float4_t*)(g + C) = (float4_t){sb[j][0], sb[j][1], sb[j][2], sb[j][3]};
-      *(float4_t*)(g + C + 4) = (float4_t){sb[j][4], sb[j][5], sb[j][6], sb[j][7]};
+  for (int round = 0; round < LNF_WAVES / LNF_SLOTS; ++round) {
+    if ((wv / LNF_SLOTS) == round) {
+      float* gbase = red + ((long)(wv % LNF_SLOTS) * 2) * C;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        int ch = lane + 64 * j;
+        if (ch < cpr) {
+          float* g = gbase + ch * 8;
+          float4_t g0 = {sg[j][0], sg[j][1], sg[j][2], sg[j][3]}, g1 = {sg[j][4], sg[j][5], sg[j][6], sg[j][7]};
+          float4_t b0 = {sb[j][0], sb[j][1], sb[j][2], sb[j][3]}, b1 = {sb[j][4], sb[j][5], sb[j][6], sb[j][7]};
+          if (round) { g0 += *(const float4_t*)g; g1 += *(const float4_t*)(g + 4); b0 += *(const float4_t*)(g + C); b1 += *(const float4_t*)(g + C + 4); }
+          *(float4_t*)g = g0;
+          *(float4_t*)(g + 4) = g1;
+          *(float4_t*)(g + C) = b0;
+          *(float4_t*)(g + C + 4) = b1;
+        }
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* out = part + (long)blockIdx.x * 2 * C;
-  for (int c = threadIdx.x; c < 2 * C; c += LNF_WAVES * 64) {
-    float a = 0.f;
-#pragma unroll
-    for (int w = 0; w < LNF_WAVES; ++w) a += red[(long)w * 2 * C + c];
-    out[c] = a;
-  }
+  for (int c = threadIdx.x; c < 2 * C; c += LNF_WAVES * 64) out[c] = red[c] + red[2 * C + c];
 }
 static int ln_fused_blocks(int M) {
   int b = (M + LNF_WAVES - 1) / LNF_WAVES;
@@ -748,11 +755,11 @@ extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamm
   NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws);
   const int blocks = ln_fused_blocks(M);
   const int nch = ((C >> 3) + 63) / 64;
-  const int smem = LNF_WAVES * 2 * C * (int)sizeof(float);
+  const int smem = LNF_SLOTS * 2 * C * (int)sizeof(float);
 #define NK_LN_FUSED(NCH_)                                                                                                      \
   do {                                                                                                                          \
     static bool attr = false;                                                                                                   \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ln_bwd_fused_kernel<NCH_>, hipFuncAttributeMaxDynamicSharedMemorySize, LNF_WAVES * 2 * 2048 * 4); attr = true; } \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ln_bwd_fused_kernel<NCH_>, hipFuncAttributeMaxDynamicSharedMemorySize, LNF_SLOTS * 2 * 2048 * 4); attr = true; } \
     hipLaunchKernelGGL(ln_bwd_fused_kernel<NCH_>, dim3(blocks), dim3(LNF_WAVES * 64), smem, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,   \
                        (const bf16_t*)dx_add, (bf16_t*)dx, ws, M, C);                                                          \
   } while (0)

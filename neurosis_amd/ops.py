@@ -13,6 +13,7 @@ Conventions
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Callable, Optional
@@ -556,8 +557,11 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
         dx = torch.empty_like(x)
         ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
         acc = state_of(weight).grad_accumulate
-        if not state_of(weight).norm_params_on_side_stream:
-            # one pass over x and dy: input gradient + per-block partials of the gamma / beta gradients, then a small column reduce
+        if not state_of(weight).norm_params_on_side_stream and os.environ.get("NK_LN_FUSED", "0") == "1":
+            # NK_LN_FUSED=1: ONE pass over x and dy (nk_layernorm_bwd: input gradient + per-block partials of the gamma / beta gradients,
+            # 6 B/elem instead of 10).  Off by default: in the real step it measured 180.6 vs 178.7 ms (tools/ab_step.py) -- these
+            # 10-20 MB tensors are latency-bound, the second read of x, dy by the parameter kernel comes out of the Infinity Cache, and
+            # the fused kernel's 72 extra accumulator registers per lane cost it the waves that hide latency.
             call("nk_layernorm_bwd", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add), dx.data_ptr(),
                  grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, int(acc), _stream())
             return dx
