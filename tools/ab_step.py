@@ -19,6 +19,7 @@ def main():
     variants["base"] = lambda: None
     variants["no g2"] = lambda: os.environ.__setitem__("NK_GEMM_G2", "0")
     variants["batch"] = lambda: setattr(est, "batch_wgrads", True)
+    variants["ln params on side stream"] = lambda: setattr(est, "norm_params_on_side_stream", True)
     variants["batch+mask7"] = lambda: (setattr(est, "batch_wgrads", True), os.environ.__setitem__("NK_GEMM_G2_MASK", "7"))
     variants["mask7"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "7")
     for name in sys.argv[1:]:       # extra variants from the command line: ENV=VALUE[,ENV=VALUE...]
