@@ -42,10 +42,11 @@ class EngineState:
         # 80 tiles of 128 x 160 each) as ONE batched launch (nk_linear_wgrad_batched): 240 tiles = one full round of the two-group
         # kernel, 49.7 us for the three against 3 x 45.4 us one by one (tools/bench_g2.py).  (Round 1 measured batching -2 % with the
         # 128 x 128 kernels, which gained nothing from the fuller grid, and with the block's LARGE weight gradients deferred too.)
-        # In the real two-stream step batching still LOSES, by a lot: 199.4 vs 189.1 ms (tools/ab_step.py, interleaved; 202.9 vs
-        # 190.7 with the 128 x 128 kernels): a 240-workgroup launch that needs whole CUs starves behind the main stream's kernels and
-        # the deferred gradients pile up into the tail of backward.  So off; the serialized figure above is what a single-stream
-        # backward would get.
+        # In the real two-stream step batching buys nothing measurable (tools/ab_step.py, interleaved rounds with the cyclic GC
+        # frozen: 184.9 vs 185.6 ms, inside the round-to-round spread; an earlier "+10 ms" reading was GC pauses landing in the
+        # deferred-launch path): the side stream is not the step's critical path, so its kernel time is hidden either way, and a
+        # 240-workgroup launch that wants whole CUs takes more from the dgrad chain than three small ones.  Off by default
+        # because the deferred launches lengthen the host path of a loop that does NOT freeze the GC.
         self.batch_wgrads = False
         # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):
         # 210 more cross-stream waits per step delay the weight-gradient GEMMs queued behind them.  Off.

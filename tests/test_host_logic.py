@@ -70,3 +70,28 @@ def test_product_path_never_imports_the_oracle():
             elif isinstance(node, ast.ImportFrom) and node.module:
                 names = [node.module]
             assert not any(n.split(".")[0] == "oracle" for n in names), f"{f} imports the oracle"
+
+
+def test_two_engines_keep_their_own_state():
+    """ADVICE r1 (module-global training flags): the accumulate flag, the zeroed-gradients promise and the side stream belong
+    to ONE engine (`ops.EngineState`, reached through the parameter a kernel wrapper is handed), not to the process."""
+    from types import SimpleNamespace
+
+    from neurosis_amd import ops
+
+    a, b = ops.EngineState(), ops.EngineState()
+    pa, pb, free = torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))
+    pa._nk_store = SimpleNamespace(state=a)
+    pb._nk_store = SimpleNamespace(state=b)
+    assert ops.state_of(pa) is a and ops.state_of(pb) is b and ops.state_of(free) is ops.state and ops.state_of(None) is ops.state
+    a.grad_accumulate = True
+    assert ops.wgrad_mode(pa) == 1 and ops.wgrad_mode(pb) == 0 and ops.wgrad_mode(free) == 0
+    b.assume_zeroed = True
+    assert ops.wgrad_mode(pb) == 2 and ops.wgrad_mode(pa) == 1
+    # a channel-padded stand-in parameter: shares its engine's side stream, never accumulates
+    a.wgrad_stream = object()
+    d = a.derived()
+    pad = torch.nn.Parameter(torch.zeros(2))
+    pad._nk_state = d
+    assert ops.state_of(pad) is d and d.wgrad_stream is a.wgrad_stream and ops.wgrad_mode(pad) == 0
+    assert b.wgrad_stream is None and ops.state.wgrad_stream is None
