@@ -428,11 +428,17 @@ def main():
             side = est.wgrad_stream
             if serialized:
                 est.wgrad_stream = None
+            graph_env = os.environ.get("NK_GRAPH")
+            os.environ["NK_GRAPH"] = "0"      # the timer wraps the Python-side launches: this step runs the eager chain
             try:
                 step()
             finally:
                 est.wgrad_stream = side
                 timer.uninstall()
+                if graph_env is None:
+                    os.environ.pop("NK_GRAPH", None)
+                else:
+                    os.environ["NK_GRAPH"] = graph_env
             return timer.summary()
 
         f, ms, n, per = replay(serialized=bool(args.serialize))

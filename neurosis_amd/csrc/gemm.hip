@@ -1919,6 +1919,14 @@ static int launch_sk(NkGemmParams& p, hipStream_t stream) {
   return nk_check_launch("nk_gemm_sk_kernel");
 }
 
+// zero-fill of a split-K destination (grid-stride, 16 B per lane; n need not be a multiple of 4)
+__global__ __launch_bounds__(256) void nk_zero_f32_kernel(float* __restrict__ dst, size_t n) {
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * 256;
+  float4_t* d4 = (float4_t*)dst;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) d4[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = 0.f;
+}
+
 static int pick_splitk(int M, int N, int K, int max_split) {
   // Split K only for grids far below one workgroup per CU.  Each extra split costs M*N*4 bytes of fp32 atomics at the
   // chip-wide ~1.3 TB/s atomic rate (MI355X_MICROARCH.md), which is 923/K_red of the GEMM's own time per split -- 22 %
@@ -1991,8 +1999,15 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   if (out_f32 && splitk > 1 && p.accumulate == 0) {
     // split-K partials are summed with fp32 atomics, which need a zeroed destination
     NK_CHECK_ARG(p.ldc == p.N);
-    for (int z = 0; z < (p.nbatch ? p.nbatch : 1); ++z)
-      if (hipMemsetAsync(p.nbatch ? p.Cb[z] : p.C, 0, (size_t)p.M * p.N * sizeof(float), stream) != hipSuccess) return NK_ERR_LAUNCH;
+    // (a kernel, not hipMemsetAsync: as a node of a captured hipGraph the memset of a multi-MB buffer was not ordered before the
+    // kernel behind it on this ROCm -- replayed weight gradients of the 320/640-channel layers came out as garbage)
+    for (int z = 0; z < (p.nbatch ? p.nbatch : 1); ++z) {
+      const size_t n = (size_t)p.M * p.N;
+      float* dst = (float*)(p.nbatch ? p.Cb[z] : p.C);
+      const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
+      hipLaunchKernelGGL(nk_zero_f32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, n);
+    }
+    if (hipGetLastError() != hipSuccess) return NK_ERR_LAUNCH;
     p.accumulate = 1;
   } else if (p.accumulate == 2) {
     p.accumulate = splitk > 1 ? 1 : 0;

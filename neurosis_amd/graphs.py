@@ -1,0 +1,234 @@
+"""hipGraph replay of an explicit forward / backward closure chain.
+
+The UNet is driven from Python: ~2 700 C-ABI launches per training step, ~28 us of host time each (closure bookkeeping, ctypes
+marshalling, `hipLaunchKernel`), against kernels that take 2-100 us.  A launch sequence whose shapes repeat needs no host at
+all: `tools/micro/graph_cost.py` measures 0.3 us of host and 2.1 us of GPU time per dependent small kernel replayed from a
+hipGraph on this ROCm, against 8.5 us launched one by one.
+
+`ChainGraphs.run(fwd, inputs)` keeps, per input signature, one forward graph and a SEGMENTED backward over private memory pools:
+
+* call 1 runs `fwd(*inputs)` eagerly on the capture stream (every lazily created per-stream resource of the C-ABI -- stream-K
+  workspaces, function attributes -- exists afterwards);
+* call 2 captures the forward (`fwd` on static input copies) into `g_f`, replays it, and hands back the chain's own output
+  object plus a backward stub; the stub's first call captures `bwd(dout)` -- the closure that came out of the captured forward,
+  so it reads the activations where `g_f` writes them;
+* from then on a call is: copy the inputs into the static buffers, `g_f.replay()`; backward: copy `dout`, replay the segments.
+
+Why the backward is not ONE graph.  The eager backward runs the dgrad chain on the main stream and every weight gradient on a
+side stream; captured together they become two branches of one graph, and this ROCm's graph executor gives those branches almost
+no overlap (198 ms/step against 185 eager on the metric's configuration; `DEBUG_HIP_FORCE_GRAPH_QUEUES` 1/2/3/8 all within 3 ms of
+the fully serial 199.6).  So the capture cuts the chain where it already reports progress -- the end of each top-level block,
+`EngineState.segment_hook` -- and keeps TWO single-stream graphs per segment: `M_k`, the main chain of block k, and `W_k`, the
+weight-gradient launches of block k, which `ops.on_wgrad_stream` parks in `EngineState.deferred` during the capture instead of
+issuing.  The replay launches M_k on the main stream and W_k on the side stream behind it, so W_k overlaps M_(k+1) exactly as the
+eager streams do, at block granularity.  Between segments the replay calls the chain's gradient-ready hook (the data-parallel
+exchange), as the eager chain does.
+
+Memory safety of that arrangement: W_k reads tensors of the main pool (activations, output gradients) while M_(k+1) runs, so
+nothing W_k reads may be recycled by a later M capture -- the parked closures, which hold those tensors, are kept alive until the
+whole backward is captured; and W graphs allocate their workspaces from a pool of their own, which only the side stream's order
+touches.  The price is the eager step's peak plus the gradient tensors that would otherwise have been recycled.
+
+All signatures share the pools (a pair's activations are dead once its backward has run, and pairs never overlap), so a set of
+aspect buckets costs the largest bucket's memory, not the sum.
+"""
+from __future__ import annotations
+
+import gc
+import os
+from typing import Callable, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+__all__ = ["ChainGraphs", "graphs_enabled"]
+
+
+def graphs_enabled() -> bool:
+    """NK_GRAPH=0 keeps every chain eager (read per call, so tools/ab_step.py can flip it)."""
+    return os.environ.get("NK_GRAPH", "1") != "0"
+
+
+class _Pair:
+    __slots__ = ("g_f", "segments", "static_in", "out", "closure", "dout", "dx", "gen", "warm")
+
+    def __init__(self):
+        self.g_f = None
+        self.segments = None        # [(M_k, W_k or None, module_k or None)]
+        self.static_in = None
+        self.out = None
+        self.closure = None
+        self.dout = self.dx = None
+        self.gen = 0
+        self.warm = False
+
+
+def _sig(t: Optional[Tensor]):
+    return None if t is None else (tuple(t.shape), t.dtype, tuple(t.stride()))
+
+
+class ChainGraphs:
+    """Graphs for one chain (`fwd(*tensors) -> (out, bwd)`, `bwd(dout) -> dx or None`), keyed by input signature.
+    `hook()` returns the chain's current gradient-ready hook (or None)."""
+
+    def __init__(self, owner: Tensor, hook: Optional[Callable] = None):
+        self.owner = owner              # any parameter of the chain: names the engine (side stream, accumulate flag)
+        self.hook = hook or (lambda: None)
+        self.pairs = {}
+        self.pool = self.pool_w = None
+        self.stream: Optional[torch.cuda.Stream] = None
+        self.replays = 0                # graph launches so far (tests)
+
+    def clear(self) -> None:
+        self.pairs.clear()
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, fwd: Callable, inputs: Sequence[Optional[Tensor]], extra_key=()):
+        key = (extra_key, tuple(_sig(t) for t in inputs), ops.wgrad_mode(self.owner), torch.is_grad_enabled())
+        pair = self.pairs.get(key)
+        if pair is None:
+            pair = self.pairs[key] = _Pair()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.owner.device)
+            self.pool, self.pool_w = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+            self.ticks = torch.zeros(1, dtype=torch.int32, device=self.owner.device)   # backward replays so far, counted on the device
+        if not pair.warm:
+            return self._warm(pair, fwd, inputs)
+        if pair.g_f is None:
+            self._capture_forward(pair, fwd, inputs)
+        else:
+            for s, t in zip(pair.static_in, inputs):
+                if t is not None:
+                    s.copy_(t, non_blocking=True)
+            pair.g_f.replay()
+            self.replays += 1
+        pair.gen += 1
+        gen = pair.gen
+
+        def bwd(dout: Tensor):
+            if gen != pair.gen:
+                raise RuntimeError("neurosis_amd.graphs: backward of a forward that has since been replayed (its activations were overwritten)")
+            if pair.segments is None:
+                self._capture_backward(pair, dout)
+            else:
+                pair.dout.copy_(dout, non_blocking=True)
+            self._replay_backward(pair)
+            return pair.dx
+
+        return pair.out, bwd
+
+    # ------------------------------------------------------------------------------------------------
+    def _warm(self, pair: _Pair, fwd: Callable, inputs):
+        """The first pass of a signature: eager, but on the capture stream, so that whatever the C-ABI creates lazily per
+        stream exists before a capture (which may not allocate device memory behind torch's back) needs it."""
+        main = torch.cuda.current_stream()
+        cs = self.stream
+        cs.wait_stream(main)
+        with torch.cuda.stream(cs):
+            out, closure = fwd(*inputs)
+        main.wait_stream(cs)
+        for t in inputs:
+            if t is not None:
+                t.record_stream(cs)
+        pair.warm = True
+
+        def bwd(dout: Tensor):
+            cs.wait_stream(torch.cuda.current_stream())
+            dout.record_stream(cs)
+            with torch.cuda.stream(cs):
+                dx = closure(dout)
+                ops.join_wgrad_stream(self.owner)
+            torch.cuda.current_stream().wait_stream(cs)
+            return dx
+
+        return out, bwd
+
+    @staticmethod
+    def _quiesce() -> None:
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def _capture_forward(self, pair: _Pair, fwd: Callable, inputs) -> None:
+        pair.static_in = [None if t is None else t.clone() for t in inputs]
+        self._quiesce()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.stream):
+            g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+            try:
+                pair.out, pair.closure = fwd(*pair.static_in)
+            finally:
+                g.capture_end()
+        pair.g_f = g
+        g.replay()
+        self.replays += 1
+
+    def _capture_backward(self, pair: _Pair, dout: Tensor) -> None:
+        st = ops.state_of(self.owner)
+        side = st.wgrad_stream
+        pair.dout = dout.clone()
+        closure, pair.closure = pair.closure, None
+        segments, held = [], []
+        cur = [None]
+        self._quiesce()
+
+        def begin():
+            cur[0] = torch.cuda.CUDAGraph()
+            cur[0].capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+        def cut(module=None):
+            """End of a segment of the main chain: close M_k, capture what the segment parked for the side stream as W_k."""
+            if module is None:
+                self.ticks.add_(1)        # (the tail after the last block may hold no launch at all: an empty graph cannot be instantiated)
+            cur[0].capture_end()
+            g_m, g_w = cur[0], None
+            parked, st.deferred = st.deferred, ([] if side is not None else None)
+            if parked:
+                g_w = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    g_w.capture_begin(pool=self.pool_w, capture_error_mode="thread_local")
+                    try:
+                        for fn, _reads in parked:
+                            fn()
+                    finally:
+                        g_w.capture_end()
+                held.append(parked)       # the closures hold what W_k reads: nothing of it may be recycled by a later M capture
+            segments.append((g_m, g_w, module))
+
+        def boundary(module):
+            cut(module)
+            begin()
+
+        st.deferred = [] if side is not None else None
+        st.segment_hook = boundary
+        try:
+            with torch.cuda.stream(self.stream):
+                begin()
+                try:
+                    pair.dx = closure(pair.dout)
+                finally:
+                    cut(None)
+        finally:
+            st.deferred = None
+            st.segment_hook = None
+        del closure
+        held.clear()
+        pair.segments = segments
+
+    def _replay_backward(self, pair: _Pair) -> None:
+        side = ops.state_of(self.owner).wgrad_stream
+        main = torch.cuda.current_stream()
+        hook = self.hook()
+        for g_m, g_w, module in pair.segments:
+            g_m.replay()
+            if g_w is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    g_w.replay()
+            if hook is not None and module is not None:
+                hook(module)
+            self.replays += 1
+        if side is not None:
+            main.wait_stream(side)

@@ -133,8 +133,27 @@ class DiffusionEngine(nn.Module):
             self.configure_ema(self.ema_decay_rate)
         if self.optimizer is not None and self._torch_optimizer is None:
             self.configure_optimizers()
-        self.model.diffusion_model.grad_ready_hook = self._grads_ready     # (a FlatDataParallel wrapper takes the hook over: N > 1)
+        self.stream_optimizer = self.stream_optimizer      # (re-)installs the UNet's gradient-ready hook if streaming is on
         return self.store
+
+    @property
+    def stream_optimizer(self) -> bool:
+        """Apply the fused Adafactor block by block behind backward (NK_OPT_STREAM=1; measured slower, off by default).  It
+        needs the UNet's gradient-ready hook, and a hook keeps the chain out of hipGraph replay (a FlatDataParallel wrapper
+        takes the hook over when N > 1)."""
+        return self._stream_optimizer
+
+    @stream_optimizer.setter
+    def stream_optimizer(self, on: bool) -> None:
+        self._stream_optimizer = bool(on)
+        unet = getattr(getattr(self, "model", None), "diffusion_model", None)
+        if unet is None or getattr(self, "store", None) is None:
+            return
+        if on:
+            if unet.grad_ready_hook is None:
+                unet.grad_ready_hook = self._grads_ready
+        elif unet.grad_ready_hook == self._grads_ready:
+            unet.grad_ready_hook = None
 
     def _block_boundaries(self) -> list:
         """first tensor index (in store order) of every top-level UNet block: where the fused optimizer may cut its chunks"""

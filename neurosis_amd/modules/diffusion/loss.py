@@ -93,7 +93,7 @@ class StandardDiffusionLoss(DiffusionLoss):
             zt = torch.empty_like(x)
             net_in = torch.empty(B * H * W, cpad, dtype=BF16, device=dev)
             call("nk_edm_prepare", x.data_ptr(), eps.data_ptr(), sig.data_ptr(), c_in.data_ptr(), zt.data_ptr(), net_in.data_ptr(), B, Cc, H * W, cpad, ops._stream())
-            out, unet_bwd = unet.fwd(Img(net_in, B, H, W), c_noise, None if context is None else as_tokens(context), None if y is None else as_tokens(y))
+            out, unet_bwd = unet.fwd_graphed(Img(net_in, B, H, W), c_noise, None if context is None else as_tokens(context), None if y is None else as_tokens(y))
             loss = torch.empty(B, dtype=torch.float32, device=dev)
             call("nk_edm_loss", out.t.data_ptr(), zt.data_ptr(), target.data_ptr(), c_out.data_ptr(), c_skip.data_ptr(), w.data_ptr(), loss.data_ptr(), None,
                  B, Cc, H * W, out.C, 1.0, ops._stream())

@@ -389,6 +389,7 @@ class UNetModel(nn.Module):
         # on the current stream and on ops.state.wgrad_stream: a consumer must order itself after both streams.  The
         # data-parallel wrapper uses it to start reducing that slice of the flat gradient buffer
         self.grad_ready_hook: Optional[Callable[[nn.Module], None]] = None
+        self._nk_graphs = None   # neurosis_amd.graphs.ChainGraphs: hipGraph pairs of fwd / its backward, per input signature
 
     # -- the network as an explicit forward / backward chain over HIP kernels --------------------
     def _mlp_fwd(self, seq: nn.Sequential, x: Tensor, need_dx: bool):
@@ -421,6 +422,21 @@ class UNetModel(nn.Module):
             for a, kv in zip(atts, outs):
                 a._nk_kv = (kv, context)
 
+    def fwd_graphed(self, x: Img, timesteps: Tensor, context: Optional[Tensor], y: Optional[Tensor]):
+        """`fwd`, replayed from a hipGraph once this input signature has been seen twice (neurosis_amd/graphs.py): the training
+        step's ~2 700 launches cost the host nothing.  NK_GRAPH=0 keeps the eager chain.  A gradient-ready hook (the
+        data-parallel exchange) is called between the backward's per-block graph segments, as the eager chain calls it."""
+        from ...graphs import ChainGraphs, graphs_enabled
+
+        if not x.t.is_cuda or not graphs_enabled():
+            return self.fwd(x, timesteps, context, y)
+        if self._nk_graphs is None:
+            self._nk_graphs = ChainGraphs(self.out[2].weight, hook=lambda: self.grad_ready_hook)
+        N, H, W = x.N, x.H, x.W
+        store = getattr(self.out[2].weight, "_nk_store", None)
+        return self._nk_graphs.run(lambda t, ts, c, yy: self.fwd(Img(t, N, H, W), ts, c, yy), [x.t, timesteps, context, y],
+                                   extra_key=(N, H, W, id(store), self.training, os.environ.get("NK_KV_HOIST", "1")))
+
     def fwd(self, x: Img, timesteps: Tensor, context: Optional[Tensor], y: Optional[Tensor]):
         """x: Img with channels padded to a multiple of 8.  Returns (out Img (padded channels), bwd);
         bwd(dout tokens) -> dx tokens or None."""
@@ -451,7 +467,10 @@ class UNetModel(nn.Module):
         out, b_conv = self.out[2].fwd(hn)
 
         def bwd(dout: Tensor):
-            if hook_raw is not None:
+            est = ops.state_of(self.out[2].weight)
+            if est.segment_hook is not None:
+                hook = est.segment_hook       # a hipGraph capture cuts the chain here; the replay calls the gradient-ready hook itself
+            elif hook_raw is not None:
                 def hook(m):
                     # the block's weight gradients may still be in flight on the side stream: the hook's owner waits for that
                     # stream itself (FlatDataParallel does, on its exchange stream), so backward is not stalled here
@@ -497,7 +516,7 @@ class UNetModel(nn.Module):
             b_time(demb)
             if hook:
                 hook(self.time_embed)
-            ops.join_wgrad_stream()
+            ops.join_wgrad_stream(self.out[2].weight)
             return dh
 
         return out, bwd

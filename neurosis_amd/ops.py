@@ -51,6 +51,11 @@ class EngineState:
         # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):
         # 210 more cross-stream waits per step delay the weight-gradient GEMMs queued behind them.  Off.
         self.norm_params_on_side_stream = False
+        # hipGraph capture of a backward chain (neurosis_amd/graphs.py): while `deferred` is a list, on_wgrad_stream() parks the
+        # side-stream work there instead of launching it, and the chain reports the end of each top-level block to
+        # `segment_hook`, which captures the parked launches as that segment's own graph
+        self.deferred: Optional[list] = None
+        self.segment_hook: Optional[Callable] = None
         EngineState._live.add(self)
 
     def derived(self) -> "EngineState":
@@ -90,9 +95,13 @@ def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None) -> None:
     their own (e.g. 1280x1280 outputs = 100 tiles).  Issuing them on a second HIP stream lets the hardware co-schedule
     both kernels' workgroups, which recovers the tile-quantisation tail of each without split-K atomics.
     `reads` are the activation tensors fn consumes: they are pinned to the side stream for the caching allocator."""
-    side = state_of(owner).wgrad_stream
+    st = state_of(owner)
+    side = st.wgrad_stream
     if side is None:
         fn()
+        return
+    if st.deferred is not None:
+        st.deferred.append((fn, reads))
         return
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -173,14 +182,15 @@ def join_wgrad_stream(owner=None) -> None:
     """Make the current stream wait for every weight-gradient kernel issued so far (on `owner`'s engine's side stream, or, with
     no owner, on every live engine's)."""
     if owner is not None:
-        side = state_of(owner).wgrad_stream
-        if side is not None:
+        st = state_of(owner)
+        side = st.wgrad_stream
+        if side is not None and st.deferred is None:
             torch.cuda.current_stream().wait_stream(side)
         return
     seen = set()
     for st in list(EngineState._live):
         side = st.wgrad_stream
-        if side is not None and id(side) not in seen:
+        if side is not None and st.deferred is None and id(side) not in seen:
             seen.add(id(side))
             torch.cuda.current_stream().wait_stream(side)
 

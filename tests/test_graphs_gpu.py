@@ -1,0 +1,181 @@
+"""hipGraph replay of the UNet chain (neurosis_amd/graphs.py) against the eager chain it was captured from: same kernels, same
+order, so the per-sample loss must be bit-identical and the gradients equal up to the fp32 atomics of the few split-K
+weight gradients ("no change in loss bits")."""
+import json
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+from tests.golden.make_golden import UNET_TINY, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+
+
+def _setup():
+    import neurosis_amd.modules.diffusion as D
+    from neurosis_amd.nn import FlatParamStore
+
+    net = D.UNetModel(**UNET_TINY)
+    net.load_state_dict(synth_state_dict(json.loads((G / "unet_sdxl_tiny_keys.json").read_text())))
+    net = net.cuda()
+    store = FlatParamStore(net.parameters())
+    store.state.wgrad_stream = torch.cuda.Stream()
+    den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization()).cuda()
+    lossfn = D.StandardDiffusionLoss(sigma_generator=D.InjectedSigmaGenerator(), loss_weighting=D.EpsWeighting())
+    return net, store, den, lossfn, D.OpenAIWrapper(net)
+
+
+def _batches(n, hw=(16, 16)):
+    g = torch.Generator().manual_seed(7)
+    out = []
+    for _ in range(n):
+        out.append(dict(x=torch.randn(2, 4, *hw, generator=g).cuda(), noise=torch.randn(2, 4, *hw, generator=g).cuda(),
+                        sigma=(torch.rand(2, generator=g) * 5 + 0.1).cuda(), ctx=torch.randn(2, 77, UNET_TINY["context_dim"], generator=g).cuda(),
+                        y=torch.randn(2, UNET_TINY["adm_in_channels"], generator=g).cuda()))
+    return out
+
+
+def _steps(batches, graph: bool):
+    os.environ["NK_GRAPH"] = "1" if graph else "0"
+    try:
+        net, store, den, lossfn, wrapped = _setup()
+        losses, grads = [], []
+        for b in batches:
+            loss = lossfn._forward(wrapped, den, {"crossattn": b["ctx"], "vector": b["y"]}, b["x"], {}, sigmas=b["sigma"], noise=b["noise"])
+            loss.mean().backward()
+            torch.cuda.synchronize()
+            losses.append(loss.detach().clone())
+            grads.append(store.grad.clone())
+        return net, losses, grads
+    finally:
+        os.environ.pop("NK_GRAPH", None)
+
+
+def test_graph_replay_reproduces_the_eager_chain_bit_for_bit():
+    batches = _batches(5)
+    net_e, loss_e, grad_e = _steps(batches, graph=False)
+    net_g, loss_g, grad_g = _steps(batches, graph=True)
+    assert net_e._nk_graphs is None
+    cg = net_g._nk_graphs
+    assert cg is not None and len(cg.pairs) == 1
+    pair = next(iter(cg.pairs.values()))
+    assert pair.g_f is not None and pair.segments is not None and pair.closure is None
+    # one M graph per top-level block (+ head and tail); the blocks that own weights also have a side-stream graph W
+    assert len(pair.segments) >= len(net_g.input_blocks) + len(net_g.output_blocks) + 2 and sum(w is not None for _, w, _ in pair.segments) >= len(net_g.input_blocks)
+    assert int(cg.ticks) == 4 and cg.replays == 4 * (1 + len(pair.segments))     # warm-up step eager; capture step and three more replayed
+    for i, (a, b) in enumerate(zip(loss_e, loss_g)):
+        assert torch.equal(a, b), (i, a.tolist(), b.tolist())
+    for i, (a, b) in enumerate(zip(grad_e, grad_g)):
+        assert float((a - b).norm() / a.norm()) <= 1e-5, i
+        assert float(a.norm()) > 0
+
+
+def test_each_input_signature_gets_its_own_pair_and_they_share_one_pool():
+    """Aspect buckets: two resolutions alternate; each is captured on its second appearance and replayed afterwards."""
+    sizes = [(16, 16), (8, 24), (16, 16), (8, 24), (16, 16), (8, 24)]
+    batches = [_batches(1, hw)[0] for hw in sizes]
+    net_e, loss_e, grad_e = _steps(batches, graph=False)
+    net_g, loss_g, grad_g = _steps(batches, graph=True)
+    cg = net_g._nk_graphs
+    assert len(cg.pairs) == 2 and all(p.segments is not None for p in cg.pairs.values()) and int(cg.ticks) == 4
+    for a, b in zip(loss_e, loss_g):
+        assert torch.equal(a, b)
+    for a, b in zip(grad_e, grad_g):
+        assert float((a - b).norm() / a.norm()) <= 1e-5
+
+
+def test_the_gradient_ready_hook_fires_between_replayed_segments_as_in_the_eager_chain():
+    """The data-parallel exchange hangs on UNetModel.grad_ready_hook: the replay must call it once per top-level block, in
+    backward order, like the eager chain (and not at all while capturing)."""
+    batches = _batches(4)
+    seen = {}
+    for graph in (False, True):
+        os.environ["NK_GRAPH"] = "1" if graph else "0"
+        try:
+            net, store, den, lossfn, wrapped = _setup()
+            per_step = []
+            net.grad_ready_hook = lambda m: per_step[-1].append(id(m))
+            order = {id(m): i for i, m in enumerate(net.modules())}
+            for b in batches:
+                per_step.append([])
+                lossfn._forward(wrapped, den, {"crossattn": b["ctx"], "vector": b["y"]}, b["x"], {}, sigmas=b["sigma"], noise=b["noise"]).mean().backward()
+            torch.cuda.synchronize()
+            seen[graph] = [[order[i] for i in s] for s in per_step]
+            assert (net._nk_graphs is not None) is graph
+        finally:
+            os.environ.pop("NK_GRAPH", None)
+    assert seen[True] == seen[False] and len(seen[True][0]) >= 6 and all(s == seen[True][0] for s in seen[True])
+
+
+def test_accumulate_mode_is_part_of_the_signature():
+    """The overwrite / add mode of the weight-gradient kernels is a launch argument: a graph captured in one mode must not be
+    replayed in the other."""
+    batches = _batches(6)
+    os.environ["NK_GRAPH"] = "1"
+    try:
+        net, store, den, lossfn, wrapped = _setup()
+        ref_net, ref_store, *_ = _setup()
+
+        def run(n, st, w, b, acc):
+            st.state.grad_accumulate = acc
+            lossfn._forward(w, den, {"crossattn": b["ctx"], "vector": b["y"]}, b["x"], {}, sigmas=b["sigma"], noise=b["noise"]).mean().backward()
+            torch.cuda.synchronize()
+
+        import neurosis_amd.modules.diffusion as D
+        for i, b in enumerate(batches):
+            run(net, store, wrapped, b, acc=bool(i % 2))
+        os.environ["NK_GRAPH"] = "0"
+        for i, b in enumerate(batches):
+            run(ref_net, ref_store, D.OpenAIWrapper(ref_net), b, acc=bool(i % 2))
+        assert len(net._nk_graphs.pairs) == 2
+        assert float((store.grad - ref_store.grad).norm() / ref_store.grad.norm()) <= 1e-5
+    finally:
+        os.environ.pop("NK_GRAPH", None)
+
+
+def test_split_k_weight_gradient_with_a_multi_megabyte_destination_survives_replay():
+    """A 640 x 640 weight gradient over 16 384 rows is a 25-tile grid: split-K with fp32 atomics into a zeroed 1.6 MB destination.
+    With `hipMemsetAsync` as the zero-fill, the captured memset node was not ordered before the GEMM on this ROCm and replayed
+    gradients were garbage (only beyond ~1 MB: the tiny UNet never showed it); the fill is a kernel now."""
+    from neurosis_amd import ops
+    from neurosis_amd.graphs import ChainGraphs
+    from neurosis_amd.nn import FlatParamStore
+
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(640, 640).cuda()
+    store = FlatParamStore(lin.parameters())
+    store.state.wgrad_stream = torch.cuda.Stream()
+    cg = ChainGraphs(lin.weight)
+
+    def fwd(x):
+        y, b = ops.linear_fwd(x, lin.weight, lin.bias)
+
+        def bwd(dy):
+            est = ops.state_of(lin.weight)
+            dx = b(dy)
+            if est.segment_hook is not None:
+                est.segment_hook(lin)
+            ops.join_wgrad_stream(lin.weight)
+            return dx
+
+        return y, bwd
+
+    g = torch.Generator().manual_seed(1)
+    for step in range(4):
+        x = torch.randn(16384, 640, generator=g).cuda().bfloat16()
+        dy = torch.randn(16384, 640, generator=g).cuda().bfloat16()
+        store.grad.fill_(float("nan"))
+        y, bwd = cg.run(fwd, [x])
+        dx = bwd(dy)
+        torch.cuda.synchronize()
+        want = dy.float().t() @ x.float()
+        got = lin.weight.grad
+        assert torch.isfinite(got).all(), step
+        assert float((got - want).norm() / want.norm()) <= 1e-2, step
+        assert float((lin.bias.grad - dy.float().sum(0)).norm() / dy.float().sum(0).norm()) <= 1e-2, step
+        assert float((y.float() - (x.float() @ lin.weight.detach().bfloat16().float().t() + lin.bias.detach())).abs().max()) <= 0.25
+        assert float((dx.float() - dy.float() @ lin.weight.detach().bfloat16().float()).abs().max()) <= 0.5
+    assert next(iter(cg.pairs.values())).segments is not None and int(cg.ticks) == 3

@@ -11,7 +11,7 @@ def step():
     sig = bench.draw_sigmas(4, gen_cpu, dev)
     loss = eng.training_step(batch, 0, sigmas=sig); loss.backward(); eng.optimizer_step(lr=1e-6)
 eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)
-for _ in range(2): step()
+for _ in range(3): step()      # warm-up, graph capture, first replay
 torch.cuda.synchronize()
 for _ in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
