@@ -43,12 +43,18 @@ from torch import Tensor
 
 from . import ops
 
-__all__ = ["ChainGraphs", "graphs_enabled"]
+__all__ = ["ChainGraphs", "ForwardGraphs", "frozen_stamp", "graphs_enabled"]
 
 
-def graphs_enabled() -> bool:
-    """NK_GRAPH=0 keeps every chain eager (read per call, so tools/ab_step.py can flip it)."""
-    return os.environ.get("NK_GRAPH", "1") != "0"
+def graphs_enabled(kind: str = "unet") -> bool:
+    """NK_GRAPH=0 keeps every chain eager, 1 graphs them all, a comma list names the kinds to graph ("unet", "vae", "te").  Read
+    per call, so tools/ab_step.py can flip it.  Default "unet": the training chain's 2 700 launches are where the host time is
+    (90 -> 15 ms per step); the frozen VAE encoder and text towers replayed from graphs measured 0.9 ms SLOWER each on the
+    metric's configuration (184.9 / 185.8 / 185.75 / 186.5 ms for unet / +te / +vae / all, one box), so they stay eager unless asked."""
+    v = os.environ.get("NK_GRAPH", "unet")
+    if v in ("0", "1"):
+        return v == "1"
+    return kind in v.split(",")
 
 
 class _Pair:
@@ -232,3 +238,70 @@ class ChainGraphs:
             self.replays += 1
         if side is not None:
             main.wait_stream(side)
+
+
+def _tree_map(fn: Callable, obj):
+    if isinstance(obj, Tensor):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _tree_map(fn, v) for k, v in obj.items()}
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(_tree_map(fn, v) for v in obj)
+    return obj
+
+
+def frozen_stamp(module: torch.nn.Module):
+    """What a captured forward of a FROZEN module is valid for: the identity and version of every parameter (a checkpoint load
+    or `.to()` re-creates the cached bf16 shadows the captured kernels read, ops.shadow)."""
+    return hash(tuple((p._version, p.data_ptr()) for p in module.parameters()))
+
+
+class ForwardGraphs:
+    """hipGraph replay of a forward-only launch sequence (the frozen VAE encoder, the frozen text towers): `run(fn, inputs)` with
+    `fn(*tensors) -> tensor | tuple | dict of tensors`.  First call of a signature: eager on the capture stream; second: capture;
+    then replay.  The outputs live in the graph's pool and are overwritten by the next replay, so every call hands out clones
+    (they are a few MB: latents, text embeddings)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}
+        self.pool = None
+        self.stream: Optional[torch.cuda.Stream] = None
+        self.replays = 0
+
+    def run(self, fn: Callable, inputs: Sequence[Optional[Tensor]], extra_key=()):
+        key = (extra_key, tuple(_sig(t) for t in inputs))
+        e = self.entries.get(key)
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.device)
+            self.pool = torch.cuda.graph_pool_handle()
+        if e is None:                                     # warm-up pass, eager, on the capture stream (see ChainGraphs._warm)
+            self.entries[key] = {"g": None}
+            main = torch.cuda.current_stream()
+            self.stream.wait_stream(main)
+            with torch.cuda.stream(self.stream):
+                out = fn(*inputs)
+            main.wait_stream(self.stream)
+            for t in inputs:
+                if t is not None:
+                    t.record_stream(self.stream)
+            _tree_map(lambda t: t.record_stream(main), out)
+            return out
+        if e["g"] is None:
+            e["in"] = [None if t is None else t.clone() for t in inputs]
+            ChainGraphs._quiesce()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(self.stream):
+                g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+                try:
+                    e["out"] = fn(*e["in"])
+                finally:
+                    g.capture_end()
+            e["g"] = g
+        else:
+            for s, t in zip(e["in"], inputs):
+                if t is not None:
+                    s.copy_(t, non_blocking=True)
+        e["g"].replay()
+        self.replays += 1
+        return _tree_map(torch.clone, e["out"])

@@ -27,6 +27,7 @@ import torch
 from torch import Tensor, nn
 
 from ... import ops
+from ...graphs import ForwardGraphs, frozen_stamp, graphs_enabled
 from ...modules.encoders.embedding import AbstractEmbModel
 
 logger = logging.getLogger(__name__)
@@ -61,6 +62,19 @@ def _embed(ids: Tensor, table: Tensor, positions: Tensor) -> Tensor:
         raise ValueError(f"token ids must be [batch, <= {positions.shape[0]}], got {tuple(ids.shape)}")
     summed = table[ids] + positions[: ids.shape[1]]
     return ops.cast_bf16(summed.reshape(-1, summed.shape[-1]).float())
+
+
+def _graphable(tower: nn.Module, ids: Tensor) -> bool:
+    """A frozen tower on the GPU runs its ~250-450 dependent small launches from a hipGraph (neurosis_amd/graphs.py): they are
+    launch-latency, not work (4-5 ms of the SDXL step for both towers)."""
+    return ids.is_cuda and graphs_enabled("te") and not any(p.requires_grad for p in tower.parameters())
+
+
+def _forward_graphs(tower: nn.Module) -> ForwardGraphs:
+    fg = tower.__dict__.get("_nk_fgraphs")
+    if fg is None:
+        fg = tower.__dict__["_nk_fgraphs"] = ForwardGraphs(next(tower.parameters()).device)
+    return fg
 
 
 def _check_ids(ids: Tensor, device) -> Tensor:
@@ -138,6 +152,12 @@ class CLIPTextTower(nn.Module):
         what CLIPTextModel returns (hidden_states[0] = embeddings, [i] = output of layer i, none of them final-normed)."""
         tm = self.text_model
         ids = _check_ids(input_ids, tm.embeddings.token_embedding.weight.device)
+        if _graphable(self, ids):
+            return _forward_graphs(self).run(lambda t: self._forward_ids(t, output_hidden_states), [ids], extra_key=(output_hidden_states, frozen_stamp(self)))
+        return self._forward_ids(ids, output_hidden_states)
+
+    def _forward_ids(self, ids: Tensor, output_hidden_states: bool) -> dict:
+        tm = self.text_model
         B, L = ids.shape
         x = _embed(ids, tm.embeddings.token_embedding.weight, tm.embeddings.position_embedding.weight)
         states = [x] if output_hidden_states else None
@@ -217,6 +237,11 @@ class OpenCLIPTextTower(nn.Module):
         """{"last", "penultimate": [B, L, width] (neither final-normed), "pooled": [B, embed_dim]}, fp32 -- the dictionary the
         reference's encode_with_transformer builds (models/text_encoder/clip.py:311-343)."""
         ids = _check_ids(text, self.token_embedding.weight.device)
+        if _graphable(self, ids):
+            return _forward_graphs(self).run(self._forward_ids, [ids], extra_key=(frozen_stamp(self),))
+        return self._forward_ids(ids)
+
+    def _forward_ids(self, ids: Tensor) -> dict:
         B, L = ids.shape
         x = _embed(ids, self.token_embedding.weight, self.positional_embedding)
         width = x.shape[1]

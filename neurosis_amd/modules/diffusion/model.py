@@ -17,6 +17,7 @@ import torch
 from torch import Tensor, nn
 
 from ... import ops
+from ...graphs import ForwardGraphs, frozen_stamp, graphs_enabled
 from ...nn import Conv2d
 from ...ops import BF16, Img
 
@@ -303,13 +304,24 @@ class Encoder(nn.Module):
         for i in range(0, N, bs):
             xb = x[i:i + bs]
             n = xb.shape[0]
-            img = Img(ops.nchw_to_tokens(xb.float() if xb.dtype not in (torch.float32, BF16) else xb, (Cin + 7) // 8 * 8), n, H, W)
-            h = self.fwd(img)
-            zc = h.C if not self.standalone else self.quant_conv.out_channels
-            zc_real = self.conv_out.out_channels if not self.standalone else self.quant_conv.out_channels
-            keep = zc_real // 2 if (regularize and self.double_z) else zc_real
-            outs.append(ops.tokens_to_nchw(h.t, n, keep, h.H, h.W, dtype=torch.float32))
+            xb = xb.float() if xb.dtype not in (torch.float32, BF16) else xb
+            if xb.is_cuda and graphs_enabled("vae") and not any(p.requires_grad for p in self.parameters()):
+                # the frozen encoder of the training step: ~600 launches replayed from a hipGraph (neurosis_amd/graphs.py)
+                fg = self.__dict__.get("_nk_fgraphs")
+                if fg is None:
+                    fg = self.__dict__["_nk_fgraphs"] = ForwardGraphs(xb.device)
+                outs.append(fg.run(lambda t: self._encode_chunk(t, regularize), [xb.contiguous()], extra_key=(regularize, frozen_stamp(self))))
+            else:
+                outs.append(self._encode_chunk(xb, regularize))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    def _encode_chunk(self, xb: Tensor, regularize: bool) -> Tensor:
+        n, Cin, H, W = xb.shape
+        img = Img(ops.nchw_to_tokens(xb, (Cin + 7) // 8 * 8), n, H, W)
+        h = self.fwd(img)
+        zc_real = self.conv_out.out_channels if not self.standalone else self.quant_conv.out_channels
+        keep = zc_real // 2 if (regularize and self.double_z) else zc_real
+        return ops.tokens_to_nchw(h.t, n, keep, h.H, h.W, dtype=torch.float32)
 
 
 class Decoder(nn.Module):

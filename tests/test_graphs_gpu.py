@@ -179,3 +179,56 @@ def test_split_k_weight_gradient_with_a_multi_megabyte_destination_survives_repl
         assert float((y.float() - (x.float() @ lin.weight.detach().bfloat16().float().t() + lin.bias.detach())).abs().max()) <= 0.25
         assert float((dx.float() - dy.float() @ lin.weight.detach().bfloat16().float()).abs().max()) <= 0.5
     assert next(iter(cg.pairs.values())).segments is not None and int(cg.ticks) == 3
+
+
+def test_frozen_encoder_and_text_towers_replay_bit_for_bit_and_follow_a_weight_reload():
+    """ForwardGraphs: the frozen VAE encoder and both text towers.  Outputs handed out are clones (a later replay must not change
+    them), and reloading weights invalidates the captured graphs (they read cached bf16 shadows of the old tensors)."""
+    from neurosis_amd.models.text_encoder.clip import CLIPTextTower, OpenCLIPTextTower
+    from neurosis_amd.modules.diffusion.model import Encoder
+    from tests.golden.make_golden import VAE_TINY
+
+    torch.manual_seed(0)
+    enc = Encoder(**{k: v for k, v in VAE_TINY.items() if k != "embed_dim"}).cuda().requires_grad_(False)
+    hf = CLIPTextTower(vocab_size=1000, hidden_size=64, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2).cuda().requires_grad_(False)
+    oc = OpenCLIPTextTower(vocab_size=1000, width=64, layers=2, heads=2, embed_dim=64).cuda().requires_grad_(False)
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.rand(2, 3, 32, 32, generator=g).cuda() * 2 - 1 for _ in range(4)]
+    ids = [torch.randint(1, 999, (2, 77), generator=g).cuda() for _ in range(4)]
+
+    def run_all(graph):
+        os.environ["NK_GRAPH"] = "1" if graph else "0"
+        try:
+            outs = []
+            for im, tk in zip(imgs, ids):
+                a = enc(im, regularize=True)
+                b = hf(tk, output_hidden_states=True)
+                c = oc(tk)
+                outs.append((a, b["last_hidden_state"], b["pooler_output"], b["hidden_states"][1], c["penultimate"], c["pooled"]))
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            os.environ.pop("NK_GRAPH", None)
+
+    eager = run_all(False)
+    graphed = run_all(True)
+    for m in (enc, hf, oc):
+        assert m.__dict__["_nk_fgraphs"].replays == 3          # warm-up eager, then capture + two replays
+    for i, (e, gq) in enumerate(zip(eager, graphed)):
+        for a, b in zip(e, gq):
+            assert torch.equal(a, b), i
+    # new weights -> new stamp -> a fresh warm-up / capture, and the new weights' outputs
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.mul_(1.5)
+    os.environ["NK_GRAPH"] = "1"
+    try:
+        after = [hf(ids[0])["last_hidden_state"] for _ in range(3)]
+    finally:
+        os.environ.pop("NK_GRAPH", None)
+    os.environ["NK_GRAPH"] = "0"
+    try:
+        want = hf(ids[0])["last_hidden_state"]
+    finally:
+        os.environ.pop("NK_GRAPH", None)
+    assert all(torch.equal(a, want) for a in after) and not torch.equal(want, eager[0][1])

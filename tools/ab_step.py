@@ -1,4 +1,5 @@
 """In-process A/B of training-step variants (same device, interleaved rounds): prints ms/step per variant."""
+import os; os.environ.setdefault("NK_GRAPH", "0")   # this tool watches / flips the Python-side launches: keep the eager chain
 import os, sys, time, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench

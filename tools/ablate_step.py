@@ -2,6 +2,7 @@
 outputs stay uninitialised) and times the real two-stream training step, interleaved rounds in one process.  What a
 family "costs" here is what the step would gain if it were free -- overlap with the other stream included -- which is the
 bound on what optimising it can buy.  (Outputs are garbage while something is skipped; only the clock is read.)"""
+import os; os.environ.setdefault("NK_GRAPH", "0")   # this tool watches / flips the Python-side launches: keep the eager chain
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench

@@ -1,4 +1,5 @@
 """Per-shape time of the tile engine inside one real training step (serialized launches, HIP events)."""
+import os; os.environ.setdefault("NK_GRAPH", "0")   # this tool watches / flips the Python-side launches: keep the eager chain
 import sys, torch, collections
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench

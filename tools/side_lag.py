@@ -1,5 +1,6 @@
 """How far does the weight-gradient stream lag behind the dgrad chain when backward ends?  Events on both streams at every
 ops.join_wgrad_stream(); prints, per step, main-arrival -> side-done for the joins (the last one is the end of the UNet backward)."""
+import os; os.environ.setdefault("NK_GRAPH", "0")   # this tool watches / flips the Python-side launches: keep the eager chain
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench

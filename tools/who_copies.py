@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("NK_GRAPH", "0")   # this tool watches / flips the Python-side launches: keep the eager chain
 import sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select stream_id, name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()

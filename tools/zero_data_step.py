@@ -1,6 +1,7 @@
 """Is the step bound by the clock the chip holds under load?  Times the same training step on the normal random data / weights and
 again with every UNet / VAE weight and every input zeroed (same kernels, same launch sequence, same cycles; MFMA and data paths
 toggle far less, so DVFS holds a higher clock: cdna guide section 5.4 rule 25, MI355X_MICROARCH 'DVFS give-back')."""
+import os; os.environ.setdefault("NK_GRAPH", "0")   # this tool watches / flips the Python-side launches: keep the eager chain
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
