@@ -336,7 +336,7 @@ def main():
     step_marks = []    # one event per timed step start (+ one at the end): step-time percentiles without host syncs
     comm_marks = []    # N > 1: (backward done, exchange joined, first collective start, last collective end) per step
 
-    def step(mark=False):
+    def step(mark=False, force_hw=None):
         if mark:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -345,6 +345,8 @@ def main():
             hw = (args.res, args.res)
             if args.mixed_res:   # (H, W) of this rank's bucket for this step (N/dataset/aspect/lists.py:14-56)
                 hw = MIXED_BUCKETS[int(torch.randint(len(MIXED_BUCKETS), (1,), generator=gen_cpu))]
+            if force_hw is not None:
+                hw = force_hw
             batch = synthetic_batch(device, args.batch, hw, gen, args.precomputed_te)
             sig = draw_sigmas(args.batch, gen_cpu, device)
             eng.accumulate(mb, dp, last=mb == args.accumulate - 1)
@@ -368,6 +370,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Setup, before the W warm-up steps: the UNet chain is replayed from hipGraphs (neurosis_amd/graphs.py), which are captured on
+    # the SECOND step of each input signature -- two untimed priming steps per resolution, so that no capture (a device
+    # synchronisation and ~1 s of host work) can land in the warm-up-then-timed region whatever W is.
+    from neurosis_amd.graphs import graphs_enabled
+    priming = 0
+    if graphs_enabled("unet"):
+        for hw in (MIXED_BUCKETS if args.mixed_res else [(args.res, args.res)]):
+            for _ in range(2):
+                step(force_hw=hw)
+                priming += 1
     for _ in range(args.warmup):
         step()
     # The long-lived object graph (modules, parameters, descriptor tables) goes to the permanent generation: a full
@@ -466,6 +478,7 @@ def main():
                        "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}", "allreduce_dtype": args.wire_dtype, "activation_checkpointing": False, "accumulate_grad_batches": args.accumulate},
             "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "step_ms_in_order": [round(t, 1) for t in in_order], "comm": comm,
+            "host": {"unet_chain": "hipGraph replay" if priming else "eager launches", "graph_priming_steps": priming},
             "stream_k_fixup_timeouts": lib.query("nk_gemm_sk_status"),   # 0: every K-split tile was joined (gemm.hip)
             "roofline": roofline, "cpu_baseline": cpu,
         }
