@@ -251,9 +251,15 @@ def _tree_map(fn: Callable, obj):
 
 
 def frozen_stamp(module: torch.nn.Module):
-    """What a captured forward of a FROZEN module is valid for: the identity and version of every parameter (a checkpoint load
-    or `.to()` re-creates the cached bf16 shadows the captured kernels read, ops.shadow)."""
-    return hash(tuple((p._version, p.data_ptr()) for p in module.parameters()))
+    """What a captured launch sequence over `module`'s weights is valid for.  Kernels read bf16 shadows by ADDRESS: a
+    store-managed parameter's shadow is a view of the store's flat buffer, rewritten in place by the fused optimizers and by
+    refresh() (stable: the store's identity is enough); any other parameter's shadow is a cached cast keyed on the tensor's
+    version and address (ops.shadow), re-created when a checkpoint load or `.to()` changes either."""
+    out = []
+    for p in module.parameters():
+        st = getattr(p, "_nk_store", None)
+        out.append(("store", id(st), st.shadow.data_ptr()) if st is not None else (p._version, p.data_ptr()))
+    return hash(tuple(out))
 
 
 class ForwardGraphs:

@@ -426,16 +426,17 @@ class UNetModel(nn.Module):
         """`fwd`, replayed from a hipGraph once this input signature has been seen twice (neurosis_amd/graphs.py): the training
         step's ~2 700 launches cost the host nothing.  NK_GRAPH=0 keeps the eager chain.  A gradient-ready hook (the
         data-parallel exchange) is called between the backward's per-block graph segments, as the eager chain calls it."""
-        from ...graphs import ChainGraphs, graphs_enabled
+        from ...graphs import ChainGraphs, frozen_stamp, graphs_enabled
 
         if not x.t.is_cuda or not graphs_enabled():
             return self.fwd(x, timesteps, context, y)
         if self._nk_graphs is None:
             self._nk_graphs = ChainGraphs(self.out[2].weight, hook=lambda: self.grad_ready_hook)
         N, H, W = x.N, x.H, x.W
-        store = getattr(self.out[2].weight, "_nk_store", None)
+        # (frozen_stamp: the captured kernels read the weights' bf16 shadows by address -- a flat store keeps them in place, free
+        # parameters get new ones whenever they change; ~0.4 ms of host time per call for the SDXL UNet's 1 700 tensors)
         return self._nk_graphs.run(lambda t, ts, c, yy: self.fwd(Img(t, N, H, W), ts, c, yy), [x.t, timesteps, context, y],
-                                   extra_key=(N, H, W, id(store), self.training, os.environ.get("NK_KV_HOIST", "1")))
+                                   extra_key=(N, H, W, frozen_stamp(self), self.training, os.environ.get("NK_KV_HOIST", "1")))
 
     def fwd(self, x: Img, timesteps: Tensor, context: Optional[Tensor], y: Optional[Tensor]):
         """x: Img with channels padded to a multiple of 8.  Returns (out Img (padded channels), bwd);

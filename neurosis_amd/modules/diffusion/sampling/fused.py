@@ -27,6 +27,7 @@ import torch
 from torch import Tensor
 
 from .... import ops
+from ....graphs import frozen_stamp
 from ....lib import call
 from ....nn import as_tokens
 from ....ops import BF16, Img
@@ -139,9 +140,9 @@ class FusedDenoiser:
         if not self.use_graph:
             return self._euler_eager(x, sigma_hat, next_sigma, cond, uc, guider, out=torch.empty_like(x))
         tensors = {k: v for k, v in cond.items() if torch.is_tensor(v)}
-        # the graph holds ADDRESSES: of the weights' bf16 shadows too, which move (or go stale) when the parameters change --
-        # an optimizer step or an EMA swap bumps ops.state.param_epoch, and the step is captured again
-        key = (tuple(x.shape), x.device, type(guider), float(getattr(guider, "scale", 1.0)), ops.state.param_epoch,
+        # the graph holds ADDRESSES, of the weights' bf16 shadows too: a flat store rewrites its shadows in place (its identity is
+        # the key), free parameters get a new shadow buffer whenever their version or address changes (graphs.frozen_stamp)
+        key = (tuple(x.shape), x.device, type(guider), float(getattr(guider, "scale", 1.0)), frozen_stamp(self.network.diffusion_model),
                tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())))
         step = self._captured.get(key)
         if step is None:
@@ -149,7 +150,8 @@ class FusedDenoiser:
             step = self._captured[key] = CapturedEulerStep(self, x, cond, uc, guider)
             self._loaded = None
         # conditioning is copied into the graph's buffers once per (cond, uc) pair, not per step
-        ident = (key, tuple(v.data_ptr() for v in tensors.values()), tuple(uc[k].data_ptr() for k in tensors), tuple(v._version for v in tensors.values()))
+        ident = (key, tuple(v.data_ptr() for v in tensors.values()), tuple(uc[k].data_ptr() for k in tensors), tuple(v._version for v in tensors.values()),
+                 tuple(uc[k]._version for k in tensors))
         if self._loaded != ident:
             step.load_conditioning(cond, uc)
             self._loaded = ident

@@ -100,3 +100,42 @@ def test_transformer_block_4096_tokens_640_channels_values():
         want = sd[f"t.{kname}"].grad
         floor = 0.99 if p.dim() == 1 else 0.995
         assert cosine(p.grad, want) >= floor, (kname, cosine(p.grad, want))
+
+
+def test_bucket_832x1216_level_chain_values():
+    """BASELINE config 4 at a REAL bucket size: an 832 x 1216 image is a 104 x 152 latent, ragged against every
+    tile size of the engine (15 808 rows = 123.5 x 128).  One level of the UNet at that size -- ResBlock(320) -> Downsample (3 x 3,
+    stride 2) -> ResBlock(320 -> 640) at 52 x 76 -> Upsample (nearest 2x + 3 x 3) -- forward and backward against the oracle."""
+    from neurosis_amd.modules.diffusion.openaimodel import Downsample, ResBlock, Upsample
+    from oracle import sdxl_oracle as O
+
+    torch.set_num_threads(16)
+    rb1, down, rb2, up = ResBlock(320, 1280, 0.0, out_channels=320), Downsample(320, True), ResBlock(320, 1280, 0.0, out_channels=640), Upsample(640, True)
+    mods = {"a": rb1, "d": down, "b": rb2, "u": up}
+    for i, m in enumerate(mods.values()):
+        _init(m, 31 + i)
+    sd = {f"{k}.{n}": v.detach().clone().contiguous().requires_grad_(True) for k, m in mods.items() for n, v in m.state_dict().items()}
+    x, emb = _rnd(2, 320, 104, 152, seed=12), _rnd(2, 1280, seed=13)
+    xr = x.clone().requires_grad_(True)
+    h = O.resblock(sd, "a", xr, emb)
+    h = O.conv(sd, "d.op", h, stride=2)
+    h = O.resblock(sd, "b", h, emb)
+    ref = O.conv(sd, "u.conv", F.interpolate(h, scale_factor=2, mode="nearest"))
+    assert ref.shape == (2, 640, 104, 152)
+    dy = _rnd(*ref.shape, seed=14)
+    ref.backward(dy)
+    for m in mods.values():
+        m.cuda()
+    xg = x.cuda().requires_grad_(True)
+    e = emb.cuda()
+    out = up(rb2(down(rb1(xg, e)), e))
+    out.backward(dy.cuda())
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and rel_err(out, ref) <= 3e-2 and cosine(out, ref) >= 0.999
+    assert rel_err(xg.grad, xr.grad) <= 3e-2 and cosine(xg.grad, xr.grad) >= 0.999
+    for k, m in mods.items():
+        for kname, p in m.named_parameters():
+            want = sd[f"{k}.{kname}"].grad
+            floor = 0.99 if p.dim() == 1 else 0.995
+            assert cosine(p.grad, want) >= floor, (k, kname, cosine(p.grad, want))
+            assert abs(float(p.grad.norm()) - float(want.norm())) <= 5e-2 * float(want.norm()), (k, kname)
