@@ -1,4 +1,6 @@
-"""In-process A/B of training-step variants (same device, interleaved rounds): prints ms/step per variant."""
+"""In-process A/B of training-step variants (same device, interleaved rounds): prints ms/step per variant.
+usage: ab_step.py [variant ...]   a variant is a built-in name ("no g2", "batch", "mask7", "hp main stream", ...) or ENV=VALUE[,ENV=VALUE...];
+"base" always runs.  With no arguments every built-in runs."""
 import os; os.environ.setdefault("NK_GRAPH", "0")   # this tool watches / flips the Python-side launches: keep the eager chain
 import os, sys, time, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -23,10 +25,15 @@ def main():
     variants["ln params on side stream"] = lambda: setattr(est, "norm_params_on_side_stream", True)
     variants["batch+mask7"] = lambda: (setattr(est, "batch_wgrads", True), os.environ.__setitem__("NK_GEMM_G2_MASK", "7"))
     variants["mask7"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "7")
-    for name in sys.argv[1:]:       # extra variants from the command line: ENV=VALUE[,ENV=VALUE...]
+    variants["hp main stream"] = lambda: None
+    variants["hp main + mask7"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "7")
+    asked = [a for a in sys.argv[1:] if "=" in a]
+    for name in asked:              # extra variants from the command line: ENV=VALUE[,ENV=VALUE...]
         kv = [a.split("=", 1) for a in name.split(",")]
         variants[name] = lambda kv=kv: [os.environ.__setitem__(k, v) for k, v in kv]
-    extra_env = sorted({a.split("=", 1)[0] for name in sys.argv[1:] for a in name.split(",")})
+    extra_env = sorted({a.split("=", 1)[0] for name in asked for a in name.split(",")})
+    if sys.argv[1:]:
+        variants = {k: v for k, v in variants.items() if k == "base" or k in sys.argv[1:]}
     def restore():
         est.wgrad_stream = side; est.batch_wgrads = False; eng.stream_optimizer = False; est.norm_params_on_side_stream = False
         os.environ["NK_GEMM_G2"] = "1"; os.environ.pop("NK_GEMM_G2_MASK", None)
@@ -34,8 +41,6 @@ def main():
     for _ in range(3): step()
     import gc; gc.collect(); gc.freeze()      # (the cyclic GC's full collections otherwise show up as 200+ ms steps: DESIGN section 7)
     hp = torch.cuda.Stream(priority=-1)       # "main work on a high-priority stream" variants: name starts with "hp"
-    variants["hp main stream"] = lambda: None
-    variants["hp main + mask7"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "7")
     res = {k: [] for k in variants}
     for rnd in range(5):
         for name, setup in variants.items():

@@ -12,12 +12,12 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 6 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace -d $OUT/kt -o kt -- python3 bench.py $ARGS > $OUT/${R}_bench_under_rocprof.json 2> $OUT/kt.err
-python3 tools/kstats.py $(ls $OUT/kt/*.db | head -1) 8 $OUT/${R}_bench_kernel_stats.csv > $OUT/kt_top.txt 2>&1
-python3 tools/stream_stats.py $(ls $OUT/kt/*.db | head -1) 8 > $OUT/${R}_streams.txt 2>&1
+python3 tools/kstats.py $(ls $OUT/kt/*.db | head -1) 12 $OUT/${R}_bench_kernel_stats.csv > $OUT/kt_top.txt 2>&1
+python3 tools/stream_stats.py $(ls $OUT/kt/*.db | head -1) 12 > $OUT/${R}_streams.txt 2>&1
 rm -rf $OUT/kt
 echo "pass 1 done"
 rocprofv3 --kernel-trace -d $OUT/ks -o ks -- python3 bench.py $ARGS --serialize > $OUT/${R}_bench_serialized_under_rocprof.json 2> $OUT/ks.err
-python3 tools/kstats.py $(ls $OUT/ks/*.db | head -1) 8 $OUT/${R}_gemm_serialized_kernel_stats.csv > $OUT/ks_top.txt 2>&1
+python3 tools/kstats.py $(ls $OUT/ks/*.db | head -1) 12 $OUT/${R}_gemm_serialized_kernel_stats.csv > $OUT/ks_top.txt 2>&1
 rm -rf $OUT/ks
 echo "pass 2 done"
 PARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
