@@ -161,7 +161,7 @@ class ChainGraphs:
         pair.static_in = [None if t is None else t.clone() for t in inputs]
         self._quiesce()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(self.stream), ops.capture_scope():
             g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
             try:
                 pair.out, pair.closure = fwd(*pair.static_in)
@@ -210,7 +210,7 @@ class ChainGraphs:
         st.deferred = [] if side is not None else None
         st.segment_hook = boundary
         try:
-            with torch.cuda.stream(self.stream):
+            with torch.cuda.stream(self.stream), ops.capture_scope():
                 begin()
                 try:
                     pair.dx = closure(pair.dout)
@@ -297,7 +297,7 @@ class ForwardGraphs:
             e["in"] = [None if t is None else t.clone() for t in inputs]
             ChainGraphs._quiesce()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(self.stream):
+            with torch.cuda.stream(self.stream), ops.capture_scope():
                 g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
                 try:
                     e["out"] = fn(*e["in"])

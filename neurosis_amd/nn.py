@@ -110,8 +110,28 @@ class Conv2d(nn.Module):
     def _padded_params(self):
         """(weight, bias) stand-ins with channels padded to multiples of 8 (tiny tensors, rebuilt per param epoch)."""
         stamp = (ops._param_stamp(self.weight), None if self.bias is None else ops._param_stamp(self.bias), self.weight.requires_grad)
-        if self._pad_cache is not None and self._pad_cache[0] == stamp and self._pad_cache[1].device == self.weight.device:
-            return self._pad_cache[1], self._pad_cache[2]
+        cache = self._pad_cache
+        same = cache is not None and cache[1].device == self.weight.device and cache[0][2] == stamp[2]
+        # Under a hipGraph capture the stand-ins are ALWAYS refilled, in place: a replay runs none of this Python, so the refill
+        # has to be part of every captured forward (a graph captured while the cache happened to be valid would read last
+        # step's weights for ever -- or freed memory), and the buffers have to stay where the other graphs expect them.
+        if same and cache[0] == stamp and not ops.capturing():
+            return cache[1], cache[2]
+        if same:
+            wp, bp = cache[1], cache[2]
+            with torch.no_grad():
+                wv = wp.data.permute(0, 2, 3, 1)
+                wv.zero_()
+                wv[: self.out_channels, :, :, : self.in_channels].copy_(self.weight.detach().permute(0, 2, 3, 1))
+                if bp is not None:
+                    bp.data.zero_()
+                    bp.data[: self.out_channels].copy_(self.bias.detach())
+            # (writes through .data do not move the tensors' version counters, which is what ops.shadow goes by: say so)
+            wp._nk_shadow_stamp = None
+            if bp is not None:
+                bp._nk_shadow_stamp = None
+            self._pad_cache = (stamp, wp, bp)
+            return wp, bp
         ci, co, k = _pad8(self.in_channels), _pad8(self.out_channels), self.kernel_size
         with torch.no_grad():
             w = torch.zeros(co, k, k, ci, device=self.weight.device)

@@ -63,6 +63,25 @@ class EngineState:
         return EngineState(self.wgrad_stream)
 
 
+_capture_depth = 0
+
+
+def capturing() -> bool:
+    """True while neurosis_amd.graphs records a launch sequence: caches of weight-derived tensors must be refilled (in place)
+    rather than trusted, so that the refill is part of the graph."""
+    return _capture_depth > 0
+
+
+class capture_scope:
+    def __enter__(self):
+        global _capture_depth
+        _capture_depth += 1
+
+    def __exit__(self, *exc):
+        global _capture_depth
+        _capture_depth -= 1
+
+
 state = EngineState()
 state.param_epoch = 0  # process-wide "some parameter changed" counter (keys of captured graphs); bumped by every store
 
@@ -261,8 +280,13 @@ def shadow(p: Tensor) -> Tensor:
     if s is not None and getattr(p, "_nk_shadow_stamp", None) == stamp:
         return s
     flat = _phys_flat(p)
-    s = torch.empty(flat.numel(), dtype=BF16, device=p.device)
     n = flat.numel()
+    if s is not None and n % 8 == 0 and s.numel() == n and s.device == p.device:
+        # same tensor, new values (an in-place update): re-cast into the SAME buffer -- captured graphs hold its address
+        call("nk_cast_f32_to_bf16", flat.data_ptr(), s.data_ptr(), n, _stream())
+        p._nk_shadow_stamp = stamp
+        return s
+    s = torch.empty(flat.numel(), dtype=BF16, device=p.device)
     if n % 8 == 0:
         call("nk_cast_f32_to_bf16", flat.data_ptr(), s.data_ptr(), n, _stream())
     else:  # tiny odd-sized parameters
