@@ -56,13 +56,24 @@ def _worker(rank, world, port, out, backend="gloo"):
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     eng = _build(fx, shapes)
     dp = FlatDataParallel(eng.model.diffusion_model, eng.store)
-    _loss(eng, fx, slice(rank, rank + 1)).mean().backward()
-    scale = dp.finish()
+    # four steps with a parameter update in between: the first runs the eager chain, the second captures the hipGraphs, the
+    # last two REPLAY them -- forward graph, per-block backward segments, the exchange hooked in between (neurosis_amd/graphs.py)
+    STEPS = 4
+    for it in range(STEPS):
+        _loss(eng, fx, slice(rank, rank + 1)).mean().backward()
+        scale = dp.finish()
+        if it < STEPS - 1:
+            eng.store.adamw_step(1e-4, (0.9, 0.999), 1e-8, 0.0, scale)
     torch.cuda.synchronize()
     mine = (eng.store.grad * scale).cpu()
+    graphs = eng.model.diffusion_model._nk_graphs
+    out[f"replayed{rank}"] = graphs is not None and int(graphs.ticks) == STEPS - 1
     if rank == 0:
         eng2 = _build(fx, shapes)
-        _loss(eng2, fx, slice(0, world)).mean().backward()
+        for it in range(STEPS):
+            _loss(eng2, fx, slice(0, world)).mean().backward()
+            if it < STEPS - 1:
+                eng2.store.adamw_step(1e-4, (0.9, 0.999), 1e-8, 0.0, 1.0)
         torch.cuda.synchronize()
         full = eng2.store.grad.cpu()
         err = float((mine - full).abs().max() / full.abs().max())
@@ -77,7 +88,7 @@ def test_flat_data_parallel_two_ranks_one_gpu():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert out["scale"] == 0.5
+    assert out["scale"] == 0.5 and out["replayed0"] and out["replayed1"]
     # bf16 activations: per-rank batches of 1 vs one batch of 2 round differently; same bound as the golden-vector test
     assert out["cos"] >= 0.999 and out["err"] <= 5e-2, dict(out)
 
@@ -93,7 +104,7 @@ def test_flat_data_parallel_rccl_one_gpu_per_rank():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out, "nccl"), nprocs=world, join=True)
-    assert out["scale"] == 0.5
+    assert out["scale"] == 0.5 and out["replayed0"] and out["replayed1"]
     assert out["cos"] >= 0.999 and out["err"] <= 5e-2, dict(out)
 
 
