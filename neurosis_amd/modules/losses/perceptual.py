@@ -11,12 +11,13 @@ is ONE kernel (`nk_lpips_layer_fwd`) instead of six feature-map-sized passes.  `
 image (the reconstruction): the trunk is frozen, so its convolutions only pass gradients through (no weight gradients).
 
 Weights: there is no hub access here.  `lin_weights` takes a state dict / .safetensors path with the `linN.model.1.weight`
-tensors (the reference ships them as neurosis/data/lpips/{alex,vgg}_lpips_v0.1.safetensors; when that package is importable they
-are found automatically); the trunk's ImageNet weights load through `load_state_dict` (torchvision's alexnet / vgg16 keys) --
+tensors (the reference ships them as neurosis/data/lpips/{alex,vgg}_lpips_v0.1.safetensors; NK_LPIPS_WEIGHTS may name that file
+or its directory -- the reference package itself is never imported); the trunk's ImageNet weights load through `load_state_dict` (torchvision's alexnet / vgg16 keys) --
 without them the trunk is random, which `pnet_rand=True` makes explicit.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -124,14 +125,14 @@ class LPIPS(nn.Module):
 
     def _load_pretrained(self, source) -> None:
         if source is None:
-            try:
-                from neurosis.data import lpips_checkpoint        # the reference package, when it is installed next to this one
-
-                with lpips_checkpoint(self.pnet_type) as state_dict:
-                    source = state_dict
-            except Exception as err:
+            source = os.environ.get("NK_LPIPS_WEIGHTS")             # a directory holding {alex,vgg}_lpips_v0.1.safetensors, or one such file
+            if source and os.path.isdir(source):
+                source = os.path.join(source, f"{self.pnet_type}_lpips_v0.1.safetensors")
+            if not source or not os.path.exists(source):
+                # (the product path never imports the reference package: the weights are named, not looked up through it)
                 raise RuntimeError("LPIPS(pretrained=True) needs the calibrated lin weights: pass lin_weights= (a state dict or the path of "
-                                   "{alex,vgg}_lpips_v0.1.safetensors), or pretrained=False") from err
+                                   "{alex,vgg}_lpips_v0.1.safetensors; the reference ships them under neurosis/data/lpips/), set NK_LPIPS_WEIGHTS "
+                                   "to that file or its directory, or use pretrained=False")
         if not isinstance(source, dict):
             from safetensors.torch import load_file
 

@@ -70,6 +70,8 @@ def test_product_path_never_imports_the_oracle():
             elif isinstance(node, ast.ImportFrom) and node.module:
                 names = [node.module]
             assert not any(n.split(".")[0] == "oracle" for n in names), f"{f} imports the oracle"
+            # ... nor the reference package (LPIPS used to look its weights up through `neurosis.data`)
+            assert not any(n.split(".")[0] == "neurosis" for n in names), f"{f} imports the reference package"
 
 
 def test_two_engines_keep_their_own_state():
