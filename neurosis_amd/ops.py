@@ -42,12 +42,12 @@ class EngineState:
         # 80 tiles of 128 x 160 each) as ONE batched launch (nk_linear_wgrad_batched): 240 tiles = one full round of the two-group
         # kernel, 49.7 us for the three against 3 x 45.4 us one by one (tools/bench_g2.py).  (Round 1 measured batching -2 % with the
         # 128 x 128 kernels, which gained nothing from the fuller grid, and with the block's LARGE weight gradients deferred too.)
-        # In the real two-stream step batching buys nothing measurable (tools/ab_step.py, interleaved rounds with the cyclic GC
-        # frozen: 184.9 vs 185.6 ms, inside the round-to-round spread; an earlier "+10 ms" reading was GC pauses landing in the
-        # deferred-launch path): the side stream is not the step's critical path, so its kernel time is hidden either way, and a
-        # 240-workgroup launch that wants whole CUs takes more from the dgrad chain than three small ones.  Off by default
-        # because the deferred launches lengthen the host path of a loop that does NOT freeze the GC.
-        self.batch_wgrads = False
+        # In the real two-stream step the step TIME does not move (tools/ab_step.py, interleaved rounds, GC frozen: 184.4 vs 185.3,
+        # 188.0 vs 187.8, 188.4 vs 188.0 ms; bench.py with graph replay 186.4 / 188.8 vs 186.9 / 187.1): the side stream is not the
+        # critical path.  What moves is the kernel time behind it: 210 fewer launches per step, linear weight gradients 504 -> 590
+        # TFLOP/s serialized, the tile engine 644 -> 666 serialized and 499 -> 519 in the step.  On by default since the chain
+        # replays from hipGraphs (the deferred launches used to lengthen the host path); NK_BATCH_WGRADS=0 turns it off.
+        self.batch_wgrads = os.environ.get("NK_BATCH_WGRADS", "1") != "0"
         # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):
         # 210 more cross-stream waits per step delay the weight-gradient GEMMs queued behind them.  Off.
         self.norm_params_on_side_stream = False

@@ -21,9 +21,9 @@ def main():
     side = est.wgrad_stream
     variants["base"] = lambda: None
     variants["no g2"] = lambda: os.environ.__setitem__("NK_GEMM_G2", "0")
-    variants["batch"] = lambda: setattr(est, "batch_wgrads", True)
+    variants["no batch"] = lambda: setattr(est, "batch_wgrads", False)
     variants["ln params on side stream"] = lambda: setattr(est, "norm_params_on_side_stream", True)
-    variants["batch+mask7"] = lambda: (setattr(est, "batch_wgrads", True), os.environ.__setitem__("NK_GEMM_G2_MASK", "7"))
+    variants["mask7, no batch"] = lambda: (setattr(est, "batch_wgrads", False), os.environ.__setitem__("NK_GEMM_G2_MASK", "7"))
     variants["mask7"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "7")
     variants["hp main stream"] = lambda: None
     variants["hp main + mask7"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "7")
@@ -35,7 +35,7 @@ def main():
     if sys.argv[1:]:
         variants = {k: v for k, v in variants.items() if k == "base" or k in sys.argv[1:]}
     def restore():
-        est.wgrad_stream = side; est.batch_wgrads = False; eng.stream_optimizer = False; est.norm_params_on_side_stream = False
+        est.wgrad_stream = side; est.batch_wgrads = True; eng.stream_optimizer = False; est.norm_params_on_side_stream = False
         os.environ["NK_GEMM_G2"] = "1"; os.environ.pop("NK_GEMM_G2_MASK", None)
         for k in extra_env: os.environ.pop(k, None)
     for _ in range(3): step()
