@@ -1972,6 +1972,8 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
     if (p.accumulate == 2) p.accumulate = 0;       // no K split here: "destination known zero" means plain stores
     if (amode == OP_KC && bmode == OP_KC) return out_f32 ? launch_g2<OP_KC, OP_KC, 1>(p, stream) : launch_g2<OP_KC, OP_KC, 0>(p, stream);
     if (amode == OP_KC && bmode == OP_MC) return out_f32 ? launch_g2<OP_KC, OP_MC, 1>(p, stream) : launch_g2<OP_KC, OP_MC, 0>(p, stream);
+    if (amode == OP_KCG && bmode == OP_KC) return out_f32 ? launch_g2<OP_KCG, OP_KC, 1>(p, stream) : launch_g2<OP_KCG, OP_KC, 0>(p, stream);
+    if (amode == OP_KCG && bmode == OP_MCT) return out_f32 ? launch_g2<OP_KCG, OP_MCT, 1>(p, stream) : launch_g2<OP_KCG, OP_MCT, 0>(p, stream);
     return out_f32 ? launch_g2<OP_MC, OP_MC, 1>(p, stream) : launch_g2<OP_MC, OP_MC, 0>(p, stream);
   }
 

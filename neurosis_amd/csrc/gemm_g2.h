@@ -46,20 +46,50 @@ struct OpG2 {
   static constexpr int NPC = ROWS / 8;                 // 1 KiB pieces per slab
   static constexpr int NPW = (NPC + 7) / 8;            // pieces per wave (waves past NPC - 8*(NPW-1) issue one fewer)
   static constexpr int CH = ROWS / 8;                  // MC: 16-byte chunks per k-row
-  const bf16_t* rp[NPW];                               // running source pointer of each piece of this lane
+  const bf16_t* rp[NPW];                               // running source pointer of each piece of this lane (KCG / MCT: the operand's base)
   int kk[NPW];                                         // KC: k offset of the lane's chunk (same for all pieces); MC: k row of the piece
   bool ok[NPW];                                        // row / r-chunk in range
   long step;                                           // pointer advance per slab
   int kcur;
+  int pn[NPW], pbh[NPW], pbw[NPW];                     // KCG: pixel of the piece's row (image, top-left input row / column of its window)
+  long cofs[NPW];                                      // MCT: r-chunk offset of the piece
+  const NkGather* g;                                   // KCG
+  const NkTapW* tw;                                    // MCT
 
   __device__ __forceinline__ int pieces(int wave) const { return wave + 8 * (NPW - 1) < NPC ? NPW : NPW - 1; }
 
-  __device__ __forceinline__ void init(const bf16_t* P, long ld, int R, int r0, int wave, int lane) {
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int R, int r0, int wave, int lane, const NkGather* g_ = nullptr,
+                                       const NkTapW* tw_ = nullptr) {
     kcur = 0;
+    g = g_; tw = tw_;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       const int pc = wave + 8 * i;
-      if constexpr (MODE == OP_KC) {
+      if constexpr (MODE == OP_KCG) {                               // conv activations: the KC image, rows = output pixels
+        const int row = pc * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (lane >> 3);
+        ok[i] = (pc < NPC) && (r0 + row < R);
+        kk[i] = chunk * 8;
+        rp[i] = P;
+        const unsigned p_ = ok[i] ? (unsigned)(r0 + row) : 0u;
+        const unsigned n = fdiv(p_, g->fHoWo);
+        const unsigned rem = p_ - n * g->fHoWo.d;
+        const unsigned ph = fdiv(rem, g->fWo);
+        const unsigned pw = rem - ph * g->fWo.d;
+        pn[i] = (int)n;
+        pbh[i] = (int)ph * g->rs + g->off_h;
+        pbw[i] = (int)pw * g->rs + g->off_w;
+        step = 0;
+      } else if constexpr (MODE == OP_MCT) {                        // conv-dgrad weights: the MC image, k = (tap, co), r = ci
+        const int S = 64 * pc + lane;
+        const int k = S / CH, c = S - k * CH;
+        const int src = CH == 16 ? (c ^ mc_swz(k)) : (c ^ (((k >> 3) & 1) << 1));
+        ok[i] = (pc < NPC) && (r0 + src * 8 < R);
+        kk[i] = k;
+        rp[i] = P;
+        cofs[i] = (long)k * tw->co_stride + r0 + src * 8;
+        step = 0;
+      } else if constexpr (MODE == OP_KC) {
         const int row = pc * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (lane >> 3);                 // slot (lane&7) of row (lane>>3) holds source chunk slot ^ (row & 7)
         ok[i] = (pc < NPC) && (r0 + row < R);
@@ -80,10 +110,35 @@ struct OpG2 {
   // sources of the next slab (advances the running state); past K or out of range: the zero page
   __device__ __forceinline__ void next_sources(int K, const bf16_t* (&src)[NPW]) {
     const bf16_t* zp = (const bf16_t*)nk_zero_page;
+    if constexpr (MODE == OP_KCG) {
+      // (channel counts here are multiples of 64 -- use_g2() asks for it -- so a 64-deep slab lies inside ONE tap: the tap
+      // decode is wave-uniform scalar work, and only the window's bounds test and the address are per lane)
+      const bool kv = kcur < K;
+      const unsigned ku = kv ? (unsigned)kcur : 0u;
+      const unsigned tap = fdiv(ku, g->fC);
+      const int c = (int)(ku - tap * g->fC.d) + kk[0];
+      const unsigned kh = fdiv(tap, g->fKW);
+      const int kw = (int)(tap - kh * g->fKW.d);
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      src[i] = (ok[i] && kcur + kk[i] < K) ? rp[i] : zp;
-      rp[i] += step;
+      for (int i = 0; i < NPW; ++i) {
+        bool v = kv && ok[i];
+        const long off = gather_offset(*g, pn[i], pbh[i], pbw[i], (int)kh, kw, c, v);
+        src[i] = v ? rp[i] + off : zp;
+      }
+    } else if constexpr (MODE == OP_MCT) {
+      const bool kv = kcur < K;                                     // (K and Cout are multiples of 64: a slab is one tap, all of it in range)
+      const unsigned ku = kv ? (unsigned)kcur : 0u;
+      const unsigned tap = fdiv(ku, tw->fCout);
+      const unsigned co0 = ku - tap * tw->fCout.d;
+      const bf16_t* base = rp[0] + (long)co0 * tw->co_stride + (long)tap * tw->tap_stride;
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) src[i] = (kv && ok[i]) ? base + cofs[i] : zp;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        src[i] = (ok[i] && kcur + kk[i] < K) ? rp[i] : zp;
+        rp[i] += step;
+      }
     }
     kcur += BK;
   }
@@ -238,14 +293,16 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
   const bf16_t* Bp = p.nbatch ? p.Bb[blockIdx.z] : p.B;
   void* Cp = p.nbatch ? p.Cb[blockIdx.z] : p.C;
 
+  constexpr int AF = (AMODE == OP_KC || AMODE == OP_KCG) ? OP_KC : OP_MC;               // the LDS image: the gathers stage the dense layouts
+  constexpr int BF = (BMODE == OP_KC || BMODE == OP_KCG) ? OP_KC : OP_MC;
   OpG2<AMODE, 128> oa;
   OpG2<BMODE, BN_> ob;
-  oa.init(Ap, p.lda, p.M, m0, wave, lane);
-  ob.init(Bp, p.ldb, p.N, n0, wave, lane);
+  oa.init(Ap, p.lda, p.M, m0, wave, lane, &p.ga, &p.tw);
+  ob.init(Bp, p.ldb, p.N, n0, wave, lane, &p.gb, &p.tw);
   typedef __attribute__((address_space(3))) const char* lds_c;
   const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
-  FragG2<AMODE, 128, 2> fa;
-  FragG2<BMODE, BN_, NJ> fb;
+  FragG2<AF, 128, 2> fa;
+  FragG2<BF, BN_, NJ> fb;
   fa.init(lds0, wq * 32, lane);
   fb.init(lds0 + 16384u, grp * HN, lane);
 
@@ -297,8 +354,8 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
     // ---- R: fragment reads of slab t, DMA of slab t + 2, wait for slab t + 1 ----
     __builtin_amdgcn_sched_barrier(0);
 #if G2_ABL != 2
-    g2_read<BMODE, BN_, NJ>(bfr, fb, so);
-    g2_read<AMODE, 128, 2>(af, fa, so);
+    g2_read<BF, BN_, NJ>(bfr, fb, so);
+    g2_read<AF, 128, 2>(af, fa, so);
 #endif
 #if G2_ABL != 1 && G2_ABL != 6
     oa.fire(sa, smem + sn, wave);                        // the two A pieces here, the two or three B pieces behind the barrier, in the
@@ -374,12 +431,20 @@ static int g2_bn(int N) {
 static bool use_g2(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
   const int mode = g2_mode();
   if (!mode || splitk != 1) return false;
-  if (!((amode == OP_KC && bmode == OP_KC) || (amode == OP_KC && bmode == OP_MC) || (amode == OP_MC && bmode == OP_MC))) return false;
+  const bool conv = amode == OP_KCG;
+  if (conv) {   // the gather modes decode the tap once per slab: channels in whole 64-deep slabs, full slabs only
+    if (p.ga.C % 64 || p.K % 64) return false;
+    if (bmode == OP_MCT && p.tw.fCout.d % 64) return false;
+  }
+  if (!((amode == OP_KC && bmode == OP_KC) || (amode == OP_KC && bmode == OP_MC) || (amode == OP_MC && bmode == OP_MC) ||
+        (conv && (bmode == OP_KC || bmode == OP_MCT))))
+    return false;
   if (p.K < 2 * BK) return false;
-  {  // NK_GEMM_G2_MASK (A/B runs): bit 0 forward (KC x KC), bit 1 dgrad (KC x MC), bit 2 wgrad (MC x MC); default 3
-    int mask = 3;   // default: forward and dgrad (in the two-stream step the weight gradients do better with the co-resident 128 x 128 kernels: 187.6 vs 189.0 ms)
+  {  // NK_GEMM_G2_MASK (A/B runs): bit 0 forward (KC x KC), bit 1 dgrad (KC x MC), bit 2 wgrad (MC x MC), bit 3 conv forward
+     // (KCG x KC), bit 4 conv dgrad (KCG x MCT); default 27
+    int mask = 27;  // not the weight gradients (in the two-stream step they do better with the co-resident 128 x 128 kernels: 187.6 vs 189.0 ms)
     if (const char* e = getenv("NK_GEMM_G2_MASK")) mask = atoi(e);
-    const int bit = (amode == OP_KC && bmode == OP_KC) ? 1 : (amode == OP_KC ? 2 : 4);
+    const int bit = conv ? (bmode == OP_KC ? 8 : 16) : (amode == OP_KC && bmode == OP_KC) ? 1 : (amode == OP_KC ? 2 : 4);
     if (!(mask & bit)) return false;
   }
   const int bn = g2_bn(p.N);

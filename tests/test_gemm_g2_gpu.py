@@ -120,3 +120,24 @@ def test_g2_race_screen_bitwise_repeatable_under_load():
             out = run()
             assert torch.equal(out, ref), (kind, M, N, K, it)
         torch.cuda.synchronize()
+
+
+# the UNet's 3 x 3 convolutions on the same kernel (gather A operand; conv-dgrad weights as the transposed (tap, co) x ci operand):
+# stride 1 / stride 2 (Downsample) / fused nearest-2x (Upsample), with the ResBlock's row vector and residual, ragged pixel counts
+CONV_CASES = [  # N, H, W, Cin, Cout, stride, upsample, rowvec, residual
+    (2, 32, 32, 320, 320, 1, False, True, False),
+    (2, 16, 16, 640, 1280, 1, False, False, True),
+    (1, 24, 40, 1280, 640, 1, False, True, True),        # 960 pixels: 7.5 row tiles
+    (2, 32, 32, 320, 320, 2, False, False, False),
+    (2, 16, 16, 640, 640, 1, True, False, False),
+    (4, 32, 32, 1280, 1280, 1, False, False, False),     # the real 1280-channel level: 256 tiles, one round
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_g2_conv3x3(case):
+    from neurosis_amd import ops
+    from tests.test_kernels_gpu import _conv_case
+
+    N, H, W, Cin, Cout, stride, up, rowvec, residual = case
+    _conv_case(ops, N, H, W, Cin, Cout, 3, stride, 1, upsample=up, rowvec=rowvec, residual=residual)
