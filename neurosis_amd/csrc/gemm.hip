@@ -527,11 +527,23 @@ struct OperandDMA {
     } else if constexpr (MODE == OP_KCG) {
       int k = k0 + kc_chunk() * 8;
       bool kv = k < kend;
-      unsigned kk = kv ? (unsigned)k : 0u;
-      unsigned tap = fdiv(kk, g.fC);
-      int c = (int)(kk - tap * g.fC.d);
-      unsigned kh = fdiv(tap, g.fKW);
-      int kw = (int)(tap - kh * g.fKW.d);
+      unsigned tap, kh;
+      int c, kw;
+      if (((g.C | k0) & 63) == 0) {
+        // channel counts in whole 64-deep slabs (every 3 x 3 convolution of the UNet and the VAE except the image / latent
+        // ends): the slab [k0, k0 + 64) lies inside ONE tap, so its decode is wave-uniform scalar work
+        const unsigned k0u = (unsigned)k0;
+        tap = fdiv(k0u, g.fC);
+        c = (int)(k0u - tap * g.fC.d) + kc_chunk() * 8;
+        kh = fdiv(tap, g.fKW);
+        kw = (int)(tap - kh * g.fKW.d);
+      } else {
+        unsigned kk = kv ? (unsigned)k : 0u;
+        tap = fdiv(kk, g.fC);
+        c = (int)(kk - tap * g.fC.d);
+        kh = fdiv(tap, g.fKW);
+        kw = (int)(tap - kh * g.fKW.d);
+      }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         bool ok = kv && rvalid[i];
@@ -546,15 +558,28 @@ struct OperandDMA {
         src[i] = (k < kend && mc_valid(v)) ? P + (long)k * ld + r0 + mc_chunk(v) * 8 : zp;
       }
     } else if constexpr (MODE == OP_MCT) {
+      if (((tw.fCout.d | (unsigned)k0) & 63) == 0) {       // a slab is one tap (see OP_KCG): scalar decode, one address per piece
+        const unsigned k0u = (unsigned)k0;
+        const unsigned tap = fdiv(k0u, tw.fCout);
+        const unsigned co0 = k0u - tap * tw.fCout.d;
+        const bf16_t* base = P + (long)co0 * tw.co_stride + (long)tap * tw.tap_stride + r0;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        int k = k0 + mc_k(i);
-        const int v = mc_var(i);
-        bool ok = k < kend && mc_valid(v);
-        unsigned kk = ok ? (unsigned)k : 0u;
-        unsigned tap = fdiv(kk, tw.fCout);
-        unsigned co = kk - tap * tw.fCout.d;
-        src[i] = ok ? P + (long)co * tw.co_stride + (long)tap * tw.tap_stride + r0 + mc_chunk(v) * 8 : zp;
+        for (int i = 0; i < NP; ++i) {
+          const int v = mc_var(i);
+          const bool ok = k0 + mc_k(i) < kend && mc_valid(v);
+          src[i] = ok ? base + (long)mc_k(i) * tw.co_stride + mc_chunk(v) * 8 : zp;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          int k = k0 + mc_k(i);
+          const int v = mc_var(i);
+          bool ok = k < kend && mc_valid(v);
+          unsigned kk = ok ? (unsigned)k : 0u;
+          unsigned tap = fdiv(kk, tw.fCout);
+          unsigned co = kk - tap * tw.fCout.d;
+          src[i] = ok ? P + (long)co * tw.co_stride + (long)tap * tw.tap_stride + r0 + mc_chunk(v) * 8 : zp;
+        }
       }
     } else {  // OP_MCG
 #pragma unroll
