@@ -114,7 +114,10 @@ class GemmTimer:
     """HIP events around every launch of the MFMA tile engine (all nk_linear_* / nk_conv2d_* entry points), on the
     stream the kernels are launched on; algorithmic FLOPs = 2*M*N*K per launch."""
 
-    NAMES = ("nk_linear_fwd", "nk_linear_dgrad", "nk_linear_wgrad", "nk_conv2d_fwd", "nk_conv2d_dgrad", "nk_conv2d_wgrad")
+    NAMES = ("nk_linear_fwd", "nk_linear_dgrad", "nk_linear_wgrad", "nk_conv2d_fwd", "nk_conv2d_dgrad", "nk_conv2d_wgrad",
+             "nk_linear_fwd_batched", "nk_linear_wgrad_batched")
+    # the batched entry points (several same-shape GEMMs per launch) are reported with the family they belong to
+    FAMILY = {"nk_linear_fwd_batched": "nk_linear_fwd", "nk_linear_wgrad_batched": "nk_linear_wgrad"}
 
     def __init__(self):
         self.records = []
@@ -127,6 +130,8 @@ class GemmTimer:
             return 2.0 * args[4] * args[5] * args[6]
         if name == "nk_linear_wgrad":
             return 2.0 * args[3] * args[4] * args[5]
+        if name in ("nk_linear_fwd_batched", "nk_linear_wgrad_batched"):     # (ptrs, ptrs, ptrs, count, M, N, K, ...)
+            return 2.0 * args[3] * args[4] * args[5] * args[6]
         d = args[0]._obj
         up = 2 if d.upsample else 1
         if name == "nk_conv2d_dgrad":  # rows = input pixels (virtual 2x grid when upsampling), algorithmic = same MACs as fwd
@@ -172,7 +177,7 @@ class GemmTimer:
             ms = s.elapsed_time(e)
             tot_f += f
             tot_ms += ms
-            a = per.setdefault(name, [0, 0.0, 0.0])
+            a = per.setdefault(self.FAMILY.get(name, name), [0, 0.0, 0.0])
             a[0] += 1
             a[1] += f
             a[2] += ms

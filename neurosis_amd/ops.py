@@ -44,8 +44,8 @@ class EngineState:
         # 128 x 128 kernels, which gained nothing from the fuller grid, and with the block's LARGE weight gradients deferred too.)
         # In the real two-stream step the step TIME does not move (tools/ab_step.py, interleaved rounds, GC frozen: 184.4 vs 185.3,
         # 188.0 vs 187.8, 188.4 vs 188.0 ms; bench.py with graph replay 186.4 / 188.8 vs 186.9 / 187.1): the side stream is not the
-        # critical path.  What moves is the kernel time behind it: 210 fewer launches per step, linear weight gradients 504 -> 590
-        # TFLOP/s serialized, the tile engine 644 -> 666 serialized and 499 -> 519 in the step.  On by default since the chain
+        # critical path.  What moves is the kernel time behind it: 140 fewer launches per step, linear weight gradients 500 -> 570
+        # TFLOP/s serialized (314 -> 339 in the step), the tile engine 644 -> 662 serialized and 498 -> 508 in the step.  On by default since the chain
         # replays from hipGraphs (the deferred launches used to lengthen the host path); NK_BATCH_WGRADS=0 turns it off.
         self.batch_wgrads = os.environ.get("NK_BATCH_WGRADS", "1") != "0"
         # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):

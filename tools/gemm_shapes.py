@@ -16,7 +16,9 @@ timer = bench.GemmTimer()
 orig_flops = timer.flops
 shapes = []
 def flops(name, args):
-    if name.startswith("nk_linear"):
+    if name in ("nk_linear_fwd_batched", "nk_linear_wgrad_batched"):      # key carries the count: "x3 per launch"
+        key = (f"{name[:-8]}[x{args[3]}]", args[4], args[5], args[6])
+    elif name.startswith("nk_linear"):
         key = (name, args[5], args[6], args[7]) if name == "nk_linear_fwd" else ((name, args[4], args[5], args[6]) if name == "nk_linear_dgrad" else (name, args[3], args[4], args[5]))
     else:
         d = args[0]._obj
