@@ -705,9 +705,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+  opa.start(kbeg);            // running source pointers, as in the ring and stream-K kernels
+  opb.start(kbeg);
   if (nk > 0) {
-    opa.issue(kbeg, kend, smem, p.ga, p.tw);
-    opb.issue(kbeg, kend, smem + V2_OPND_BYTES, p.gb, p.tw);
+    opa.issue_next(kend, smem, p.ga, p.tw);
+    opb.issue_next(kend, smem + V2_OPND_BYTES, p.gb, p.tw);
   }
 #ifdef NK_CLOCK_STAMPS
   unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -734,8 +736,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * V2_STAGE_BYTES;
-      opa.issue(kbeg + (kt + 1) * BK, kend, nxt, p.ga, p.tw);
-      opb.issue(kbeg + (kt + 1) * BK, kend, nxt + V2_OPND_BYTES, p.gb, p.tw);
+      opa.issue_next(kend, nxt, p.ga, p.tw);
+      opb.issue_next(kend, nxt + V2_OPND_BYTES, p.gb, p.tw);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -830,11 +832,15 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+  // running source pointers (slabs are issued in k order): a k-step costs one 64-bit add and one select per piece instead of
+  // the k * ld products -- this loop had 65 vector instructions per 16 MFMAs, 12 of them integer multiplies
+  opa.start(kbeg);
+  opb.start(kbeg);
 #pragma unroll
   for (int t = 0; t < RING_NS - 1; ++t)
     if (t < nk) {
-      opa.issue(kbeg + t * BK, kend, smem + t * V2_STAGE_BYTES, p.ga, p.tw);
-      opb.issue(kbeg + t * BK, kend, smem + t * V2_STAGE_BYTES + V2_OPND_BYTES, p.gb, p.tw);
+      opa.issue_next(kend, smem + t * V2_STAGE_BYTES, p.ga, p.tw);
+      opb.issue_next(kend, smem + t * V2_STAGE_BYTES + V2_OPND_BYTES, p.gb, p.tw);
     }
   int cur_stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -856,8 +862,8 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams
     __builtin_amdgcn_sched_barrier(0);
     if (kt + RING_NS - 1 < nk) {
       int ns = cur_stage + RING_NS - 1; if (ns >= RING_NS) ns -= RING_NS;
-      opa.issue(kbeg + (kt + RING_NS - 1) * BK, kend, smem + ns * V2_STAGE_BYTES, p.ga, p.tw);
-      opb.issue(kbeg + (kt + RING_NS - 1) * BK, kend, smem + ns * V2_STAGE_BYTES + V2_OPND_BYTES, p.gb, p.tw);
+      opa.issue_next(kend, smem + ns * V2_STAGE_BYTES, p.ga, p.tw);
+      opb.issue_next(kend, smem + ns * V2_STAGE_BYTES + V2_OPND_BYTES, p.gb, p.tw);
     }
     // the asm reads are invisible to hipcc's wait insertion: wait here, with the fragments as operands so the MFMAs below
     // cannot be scheduled above it
