@@ -456,7 +456,9 @@ struct OperandDMA {
   const bf16_t* P;
   long ld;
   int R, r0, wave, lane;
-  int pn[NP], pbh[NP], pbw[NP];   // KCG: pixel decode of this thread's rows
+  int pn[NP], pbh[NP], pbw[NP];   // KCG: pixel decode of this thread's rows.  For plain (non-transposed) windows pn holds, instead of
+                                  // the image index, the ELEMENT offset of (n, bh, bw, this lane's 8-channel chunk): a tap then adds
+                                  // one wave-uniform offset to it (see sources(); tensors are < 2^31 elements: check_conv)
   int tkh0, tkh1, tkw0, tkw1, tc0, tc1;   // MCG: tap / channel of this thread's r-chunk (two swizzle variants; scalars, not
                                           // arrays: hipcc put the arrays in scratch and re-read them every k-step)
   bool rvalid[NP < 2 ? 2 : NP];  // KC*: row valid ; MC*: [0],[1] r-chunk variant valid
@@ -486,6 +488,7 @@ struct OperandDMA {
           pn[i] = (int)n;
           pbh[i] = (int)ph * g.rs + g.off_h;
           pbw[i] = (int)pw * g.rs + g.off_w;
+          if (g.div == 1 && (g.C & 63) == 0) pn[i] = ((pn[i] * g.H + pbh[i]) * g.W + pbw[i]) * g.C + kc_chunk() * 8;
         }
       }
     } else {
@@ -534,15 +537,39 @@ struct OperandDMA {
         // ends): the slab [k0, k0 + 64) lies inside ONE tap, so its decode is wave-uniform scalar work
         const unsigned k0u = (unsigned)k0;
         tap = fdiv(k0u, g.fC);
-        c = (int)(k0u - tap * g.fC.d) + kc_chunk() * 8;
+        const int c0 = (int)(k0u - tap * g.fC.d);
+        c = c0 + kc_chunk() * 8;
         kh = fdiv(tap, g.fKW);
         kw = (int)(tap - kh * g.fKW.d);
+        if (g.div == 1) {
+          // ... and for a plain window the tap is ONE scalar offset on top of the pixel's own (pbase): a piece costs two
+          // adds and two compares for the bounds and one 64-bit add for the address (the general form below: ~25 vector
+          // instructions per piece, six of them integer multiplies)
+          const int dh = (int)kh * g.ks, dw = kw * g.ks;
+          const int tapoff = (dh * g.W + dw) * g.C + c0;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            const bool ok = kv && rvalid[i] && (unsigned)(pbh[i] + dh) < (unsigned)g.H && (unsigned)(pbw[i] + dw) < (unsigned)g.W;
+            src[i] = ok ? P + (long)(pn[i] + tapoff) : zp;
+          }
+          return;
+        }
       } else {
         unsigned kk = kv ? (unsigned)k : 0u;
         tap = fdiv(kk, g.fC);
         c = (int)(kk - tap * g.fC.d);
         kh = fdiv(tap, g.fKW);
         kw = (int)(tap - kh * g.fKW.d);
+        if (g.div == 1 && (g.C & 63) == 0) {   // (pn holds the plain-window base: a slab that does not start on a 64-channel boundary decodes per lane)
+          const int dh = (int)kh * g.ks, dw = kw * g.ks;
+          const int tapoff = (dh * g.W + dw) * g.C + c - kc_chunk() * 8;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            const bool ok = kv && rvalid[i] && (unsigned)(pbh[i] + dh) < (unsigned)g.H && (unsigned)(pbw[i] + dw) < (unsigned)g.W;
+            src[i] = ok ? P + (long)(pn[i] + tapoff) : zp;
+          }
+          return;
+        }
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) {

@@ -51,7 +51,8 @@ struct OpG2 {
   bool ok[NPW];                                        // row / r-chunk in range
   long step;                                           // pointer advance per slab
   int kcur;
-  int pn[NPW], pbh[NPW], pbw[NPW];                     // KCG: pixel of the piece's row (image, top-left input row / column of its window)
+  int pn[NPW], pbh[NPW], pbw[NPW];                     // KCG: pixel of the piece's row (image, top-left input row / column of its window);
+                                                       // for plain windows pn is the element offset of (n, bh, bw, the lane's chunk) instead
   long cofs[NPW];                                      // MCT: r-chunk offset of the piece
   const NkGather* g;                                   // KCG
   const NkTapW* tw;                                    // MCT
@@ -79,6 +80,7 @@ struct OpG2 {
         pn[i] = (int)n;
         pbh[i] = (int)ph * g->rs + g->off_h;
         pbw[i] = (int)pw * g->rs + g->off_w;
+        if (g->div == 1) pn[i] = ((pn[i] * g->H + pbh[i]) * g->W + pbw[i]) * g->C + chunk * 8;    // plain window: element offset instead
         step = 0;
       } else if constexpr (MODE == OP_MCT) {                        // conv-dgrad weights: the MC image, k = (tap, co), r = ci
         const int S = 64 * pc + lane;
@@ -116,14 +118,25 @@ struct OpG2 {
       const bool kv = kcur < K;
       const unsigned ku = kv ? (unsigned)kcur : 0u;
       const unsigned tap = fdiv(ku, g->fC);
-      const int c = (int)(ku - tap * g->fC.d) + kk[0];
+      const int c0 = (int)(ku - tap * g->fC.d);
       const unsigned kh = fdiv(tap, g->fKW);
       const int kw = (int)(tap - kh * g->fKW.d);
+      if (g->div == 1) {        // plain window: the tap is one scalar offset on top of the pixel's own (OperandDMA::sources)
+        const int dh = (int)kh * g->ks, dw = kw * g->ks;
+        const int tapoff = (dh * g->W + dw) * g->C + c0;
 #pragma unroll
-      for (int i = 0; i < NPW; ++i) {
-        bool v = kv && ok[i];
-        const long off = gather_offset(*g, pn[i], pbh[i], pbw[i], (int)kh, kw, c, v);
-        src[i] = v ? rp[i] + off : zp;
+        for (int i = 0; i < NPW; ++i) {
+          const bool v = kv && ok[i] && (unsigned)(pbh[i] + dh) < (unsigned)g->H && (unsigned)(pbw[i] + dw) < (unsigned)g->W;
+          src[i] = v ? rp[i] + (long)(pn[i] + tapoff) : zp;
+        }
+      } else {
+        const int c = c0 + kk[0];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          bool v = kv && ok[i];
+          const long off = gather_offset(*g, pn[i], pbh[i], pbw[i], (int)kh, kw, c, v);
+          src[i] = v ? rp[i] + off : zp;
+        }
       }
     } else if constexpr (MODE == OP_MCT) {
       const bool kv = kcur < K;                                     // (K and Cout are multiples of 64: a slab is one tap, all of it in range)
