@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dkdv_kernel(const AttnPar
       int qr = acc_row(r, h5);
       float pv = EXP2(s[r] * c - s_lse[qr]);
       s[r] = pv;
-      dp[r] = pv * (dp[r] - s_dl[qr]) * p.scale;
+      dp[r] = pv * (dp[r] - s_dl[qr]);          // (the softmax scale multiplies dK once, after the loop)
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -426,6 +426,10 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dkdv_kernel(const AttnPar
     __syncthreads();
   }
 
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[dt][r] *= p.scale;
   const int key = k0 + kl;
   if (key < p.Lk) {
     if (p.qsplit > 1) {
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float pv = EXP2(s[r] * c - lse2);
-        dp[r] = pv * (dp[r] - dlt) * p.scale;
+        dp[r] = pv * (dp[r] - dlt);             // (the softmax scale multiplies dQ once, after the loop)
       }
       if (t * 64 + hf * 32 + 32 > p.Lk) {   // keys beyond Lk exist only in the last tile (wave-uniform branch)
 #pragma unroll
@@ -595,6 +599,10 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParam
     __syncthreads();
   }
 
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] *= p.scale;
   if (q < p.Lq) {
     bf16_t* dQb = p.dQ + (long)b * p.bdq + (long)q * p.sdq + (long)hd * p.D;
 #pragma unroll
