@@ -23,10 +23,10 @@ def main():
     variants["no g2"] = lambda: os.environ.__setitem__("NK_GEMM_G2", "0")
     variants["no batch"] = lambda: setattr(est, "batch_wgrads", False)
     variants["ln params on side stream"] = lambda: setattr(est, "norm_params_on_side_stream", True)
-    variants["g2 wgrad, no batch"] = lambda: (setattr(est, "batch_wgrads", False), os.environ.__setitem__("NK_GEMM_G2_MASK", "31"))
-    variants["g2 wgrad"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "31")
+    variants["g2 wgrad, no batch"] = lambda: (setattr(est, "batch_wgrads", False), os.environ.__setitem__("NK_GEMM_G2_MASK", "63"))
+    variants["g2 wgrad"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "63")
     variants["hp main stream"] = lambda: None
-    variants["hp main + g2 wgrad"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "31")
+    variants["hp main + g2 wgrad"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "63")
     asked = [a for a in sys.argv[1:] if "=" in a]
     for name in asked:              # extra variants from the command line: ENV=VALUE[,ENV=VALUE...]
         kv = [a.split("=", 1) for a in name.split(",")]
