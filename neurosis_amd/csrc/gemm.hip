@@ -614,6 +614,10 @@ struct OperandDMA {
         int k = k0 + mc_k(i);
         const int v = mc_var(i);
         bool ok = (k < kend) && mc_valid(v);
+#ifdef NK_ABL_MCG_CHEAP     // tools/ablate: what would the conv weight gradient cost with a free pixel decode?  (wrong addresses, clock only)
+        src[i] = ok ? P + (long)((k & 4095) * 64 + mc_chunk(v) * 8) : zp;
+        continue;
+#endif
         unsigned p_ = ok ? (unsigned)k : 0u;
         unsigned n = fdiv(p_, g.fHoWo);
         unsigned rem = p_ - n * g.fHoWo.d;
@@ -630,6 +634,31 @@ struct OperandDMA {
   // inside the k loop there, which keeps hipcc from hoisting the row * ld products the way it does for issue()) ----
   int kcur;
   const bf16_t* rp[NP];
+  // MCG running state (plain windows): the piece's pixel as input row / column WITH this lane's tap applied, and the element
+  // offset of (n, row, column, channel chunk).  A slab moves every pixel 64 places along the (n, ph, pw) raster: two carries.
+  int mh[NP], mw[NP], moff[NP];
+  bool mplain;
+  __device__ __forceinline__ void start(int k_begin, const NkGather& g) {
+    start(k_begin);
+    if constexpr (MODE == OP_MCG) {
+      const int q = (int)fdiv(64u, g.fWo);
+      mplain = g.div == 1 && q + 1 < g.Ho;
+      if (mplain) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int v = mc_var(i);
+          const unsigned p_ = (unsigned)(k_begin + mc_k(i));
+          const unsigned n = fdiv(p_, g.fHoWo);
+          const unsigned rem = p_ - n * g.fHoWo.d;
+          const unsigned ph = fdiv(rem, g.fWo);
+          const unsigned pw = rem - ph * g.fWo.d;
+          mh[i] = (int)ph * g.rs + g.off_h + sel(tkh0, tkh1, v) * g.ks;
+          mw[i] = (int)pw * g.rs + g.off_w + sel(tkw0, tkw1, v) * g.ks;
+          moff[i] = (((int)n * g.H + mh[i]) * g.W + mw[i]) * g.C + sel(tc0, tc1, v);
+        }
+      }
+    }
+  }
   __device__ __forceinline__ void start(int k_begin) {
     kcur = k_begin;
     if constexpr (MODE == OP_KC) {
@@ -650,6 +679,35 @@ struct OperandDMA {
         else ok = (kcur + mc_k(i) < kend) && mc_valid(mc_var(i));
         src[i] = ok ? rp[i] : zp;
         rp[i] += MODE == OP_KC ? (long)BK : (long)BK * ld;   // (ld is wave-uniform: a scalar multiply)
+      }
+    } else if constexpr (MODE == OP_MCG) {
+      if (mplain) {
+        // (the general form below costs ~45 vector instructions per piece and slab -- two magic-number divisions and a five-term
+        // 64-bit offset; with a free decode the conv weight gradients ran 20-32 % faster, tools/ablate NK_ABL_MCG_CHEAP)
+        const bf16_t* zp = (const bf16_t*)nk_zero_page;
+        const int q = (int)fdiv(64u, g.fWo);
+        const int rm = 64 - q * g.Wo;
+        const int wspan = g.Wo * g.rs, hspan = g.Ho * g.rs;
+        const int A = (q * g.rs * g.W + rm * g.rs) * g.C, Bc = (g.rs * g.W - wspan) * g.C, Ci = (g.H - hspan) * g.W * g.C;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int v = mc_var(i);
+          const bool ok = (kcur + mc_k(i) < kend) && mc_valid(v) && (unsigned)mh[i] < (unsigned)g.H && (unsigned)mw[i] < (unsigned)g.W;
+          src[i] = ok ? P + (long)moff[i] : zp;
+          // 64 pixels on: the tapped column / row keep their offset from the untapped ones, so the carries are tested against
+          // limits shifted by this lane's tap
+          const int dw = sel(tkw0, tkw1, v) * g.ks + g.off_w, dh = sel(tkh0, tkh1, v) * g.ks + g.off_h;
+          int w = mw[i] + rm * g.rs;
+          const bool c1 = w - dw >= wspan;
+          w -= c1 ? wspan : 0;
+          int h = mh[i] + (q + (c1 ? 1 : 0)) * g.rs;
+          const bool c2 = h - dh >= hspan;
+          h -= c2 ? hspan : 0;
+          mw[i] = w; mh[i] = h;
+          moff[i] += A + (c1 ? Bc : 0) + (c2 ? Ci : 0);
+        }
+      } else {
+        sources(kcur, kend, src, g, tw);
       }
     } else {
       sources(kcur, kend, src, g, tw);
@@ -732,8 +790,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-  opa.start(kbeg);            // running source pointers, as in the ring and stream-K kernels
-  opb.start(kbeg);
+  opa.start(kbeg, p.ga);      // running source pointers, as in the ring and stream-K kernels
+  opb.start(kbeg, p.gb);
   if (nk > 0) {
     opa.issue_next(kend, smem, p.ga, p.tw);
     opb.issue_next(kend, smem + V2_OPND_BYTES, p.gb, p.tw);
@@ -861,8 +919,8 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams
 
   // running source pointers (slabs are issued in k order): a k-step costs one 64-bit add and one select per piece instead of
   // the k * ld products -- this loop had 65 vector instructions per 16 MFMAs, 12 of them integer multiplies
-  opa.start(kbeg);
-  opb.start(kbeg);
+  opa.start(kbeg, p.ga);
+  opb.start(kbeg, p.gb);
 #pragma unroll
   for (int t = 0; t < RING_NS - 1; ++t)
     if (t < nk) {
@@ -1139,8 +1197,8 @@ __global__ __launch_bounds__(SK_NT, 4) void nk_gemm_sk_kernel(const NkGemmParams
     sk_decode(p, t, ntm, ntn, m0, n0, z);
     opa.init(p.nbatch ? p.Ab[z] : p.A, p.lda, p.M, m0, tid, p.ga);
     opb.init(p.nbatch ? p.Bb[z] : p.B, p.ldb, p.N, n0, tid, p.gb);
-    opa.start(p_k * BK);
-    opb.start(p_k * BK);
+    opa.start(p_k * BK, p.ga);
+    opb.start(p_k * BK, p.gb);
   };
   auto p_issue = [&](char* stage) {
     opa.issue_next(p.K, stage, p.ga, p.tw);
