@@ -86,6 +86,7 @@ class ChainGraphs:
         self.pool = self.pool_w = None
         self.stream: Optional[torch.cuda.Stream] = None
         self.replays = 0                # graph launches so far (tests)
+        self.broken = False             # a capture failed: the chain stays eager (still HIP kernels, launched from Python)
 
     def clear(self) -> None:
         self.pairs.clear()
@@ -100,10 +101,19 @@ class ChainGraphs:
             self.stream = torch.cuda.Stream(device=self.owner.device)
             self.pool, self.pool_w = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
             self.ticks = torch.zeros(1, dtype=torch.int32, device=self.owner.device)   # backward replays so far, counted on the device
-        if not pair.warm:
+        if not pair.warm or self.broken:
             return self._warm(pair, fwd, inputs)
         if pair.g_f is None:
-            self._capture_forward(pair, fwd, inputs)
+            try:
+                self._capture_forward(pair, fwd, inputs)
+            except Exception as err:      # a runtime that cannot capture this chain: say so, once, and keep launching from Python
+                import warnings
+
+                warnings.warn(f"neurosis_amd.graphs: hipGraph capture of the forward chain failed ({type(err).__name__}: {err}); "
+                              "this chain stays on the eager launch path (NK_GRAPH=0 silences the attempt)")
+                self.broken = True
+                torch.cuda.synchronize()
+                return self._warm(pair, fwd, inputs)
         else:
             for s, t in zip(pair.static_in, inputs):
                 if t is not None:

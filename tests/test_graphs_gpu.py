@@ -261,3 +261,22 @@ def test_frozen_encoder_and_text_towers_replay_bit_for_bit_and_follow_a_weight_r
     finally:
         os.environ.pop("NK_GRAPH", None)
     assert all(torch.equal(a, want) for a in after) and not torch.equal(want, eager[0][1])
+
+
+def test_a_failed_capture_leaves_the_chain_on_the_eager_launch_path(monkeypatch):
+    """A runtime that cannot capture (here: capture_begin made to fail) must not take the training step down: the chain warns
+    once and keeps launching its HIP kernels from Python; results unchanged."""
+    batches = _batches(4)
+    net_e, loss_e, grad_e = _steps(batches, graph=False)
+
+    def boom(self, *a, **k):
+        raise RuntimeError("simulated: stream capture unsupported")
+
+    monkeypatch.setattr(torch.cuda.CUDAGraph, "capture_begin", boom)
+    with pytest.warns(UserWarning, match="hipGraph capture of the forward chain failed"):
+        net_g, loss_g, grad_g = _steps(batches, graph=True)
+    assert net_g._nk_graphs.broken and net_g._nk_graphs.replays == 0
+    for a, b in zip(loss_e, loss_g):
+        assert torch.equal(a, b)
+    for a, b in zip(grad_e, grad_g):
+        assert float((a - b).norm() / a.norm()) <= 1e-5
