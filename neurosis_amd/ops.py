@@ -48,9 +48,12 @@ class EngineState:
         # TFLOP/s serialized (314 -> 339 in the step), the tile engine 644 -> 662 serialized and 498 -> 508 in the step.  On by default since the chain
         # replays from hipGraphs (the deferred launches used to lengthen the host path); NK_BATCH_WGRADS=0 turns it off.
         self.batch_wgrads = os.environ.get("NK_BATCH_WGRADS", "1") != "0"
-        # LayerNorm gamma / beta gradients on the weight-gradient stream: measured SLOWER (217.6 vs 203.9 ms/step, in-process A/B):
-        # 210 more cross-stream waits per step delay the weight-gradient GEMMs queued behind them.  Off.
-        self.norm_params_on_side_stream = False
+        # LayerNorm gamma / beta gradients on the weight-gradient stream.  Launched from Python this measured SLOWER (217.6 vs
+        # 203.9 ms/step in round 1, +5.5 ms in round 2: 210 more cross-stream event waits per step delay the weight-gradient GEMMs
+        # queued behind them).  Under hipGraph replay those waits are gone -- the parked launches become part of each segment's
+        # side-stream graph -- and the main chain sheds ~4 ms of small kernels: 177.2 / 177.1 vs 178.2 / 178.7 ms/step (bench.py,
+        # alternating).  So: on where the chain replays from graphs (the default), off with NK_GRAPH=0; NK_LN_SIDE=0|1 overrides.
+        self.norm_params_on_side_stream = os.environ.get("NK_LN_SIDE", "0" if os.environ.get("NK_GRAPH", "unet") == "0" else "1") == "1"
         # hipGraph capture of a backward chain (neurosis_amd/graphs.py): while `deferred` is a list, on_wgrad_stream() parks the
         # side-stream work there instead of launching it, and the chain reports the end of each top-level block to
         # `segment_hook`, which captures the parked launches as that segment's own graph
