@@ -60,6 +60,7 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
 
         def bwd(dy: Tensor):
             demb = None
+            cut = ops.fine_cut(next(self.parameters(), None))      # (hipGraph capture: cut after every layer of the block)
             for kind, b in reversed(bwds):
                 if dy is None:
                     break
@@ -71,6 +72,8 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 else:
                     dyi, _ = b(dy)
                     dy = None if dyi is None else dyi.t
+                if cut is not None:
+                    cut(None)
             bwds.clear()
             return dy, demb
 

@@ -89,6 +89,17 @@ state = EngineState()
 state.param_epoch = 0  # process-wide "some parameter changed" counter (keys of captured graphs); bumped by every store
 
 
+def fine_cut(p):
+    """The hipGraph capture's segment hook for cuts INSIDE a top-level block (after every layer, after every transformer block), or
+    None.  With cuts at top-level blocks only (23 segments) a block's weight gradients start when the whole block's chain is done
+    and the side stream ends 4.0 ms after the main chain; with the fine cuts (126 segments) 0.1-0.3 ms after it
+    (tools/side_lag_graph.py) -- but the main chain is that much slower beside the busier side stream, and the step does not move
+    (182.4 / 182.2 fine vs 182.1 / 183.0 coarse, alternating on one box).  NK_GRAPH_FINE=1 selects the fine cuts; default coarse."""
+    if p is None or os.environ.get("NK_GRAPH_FINE", "0") != "1":
+        return None
+    return state_of(p).segment_hook
+
+
 def state_of(p) -> EngineState:
     """The engine state that governs parameter `p`: its own tag, its store's, or the default."""
     if p is not None:
