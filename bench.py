@@ -169,12 +169,27 @@ class GemmTimer:
         for m, a in self._mods:
             setattr(m, a, self._orig)
 
+    @staticmethod
+    def event_overhead_ms() -> float:
+        """What an event pair with NOTHING between its two records reads on this stream (median of 200): the timestamp writes
+        themselves.  Subtracted from every launch interval, so that a launch's figure is the kernel's, as rocprofv3 reports it."""
+        torch.cuda.synchronize()
+        pairs = []
+        for _ in range(200):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); e.record()
+            pairs.append((s, e))
+        torch.cuda.synchronize()
+        v = sorted(s.elapsed_time(e) for s, e in pairs)
+        return v[len(v) // 2]
+
     def summary(self):
         torch.cuda.synchronize()
+        self.overhead_ms = self.event_overhead_ms()
         tot_f = tot_ms = 0.0
         per = {}
         for name, f, s, e in self.records:
-            ms = s.elapsed_time(e)
+            ms = max(s.elapsed_time(e) - self.overhead_ms, 1e-4)
             tot_f += f
             tot_ms += ms
             a = per.setdefault(self.FAMILY.get(name, name), [0, 0.0, 0.0])
@@ -456,10 +471,10 @@ def main():
                     os.environ.pop("NK_GRAPH", None)
                 else:
                     os.environ["NK_GRAPH"] = graph_env
-            return timer.summary()
+            return timer.summary() + (timer.overhead_ms,)
 
-        f, ms, n, per = replay(serialized=bool(args.serialize))
-        fs, mss, ns, pers = replay(serialized=True)
+        f, ms, n, per, ovh = replay(serialized=bool(args.serialize))
+        fs, mss, ns, pers, ovh_s = replay(serialized=True)
         ach, ach_s = f / (ms * 1e-3) / 1e12, fs / (mss * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
@@ -469,7 +484,12 @@ def main():
                     "algorithmic_gflop_per_launch": round(f / n / 1e9, 2), "kernel_ms_per_step": round(ms, 2), "kernel_ms_per_step_serialized": round(mss, 2),
                     "by_entry_point": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in per.items()},
                     "by_entry_point_serialized": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in pers.items()},
-                    "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_IMAGE / PEAK_BF16_TFLOPS, 4)}
+                    "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_IMAGE / PEAK_BF16_TFLOPS, 4),
+                    "event_pair_overhead_us": round(0.5 * (ovh + ovh_s) * 1e3, 2),
+                    "note": "launch intervals are HIP event pairs on the launch stream minus the measured empty-pair overhead. Serialized intervals are the "
+                            "kernels' own durations (compare profiles/rNN_gemm_serialized_kernel_stats.csv). In-step intervals also contain the time a "
+                            "launch waits for compute units held by the other stream's workgroups, which a kernel trace does not count as kernel "
+                            "time: the trace's in-step average is shorter than avg_launch_us (DESIGN section 5)"}
     if world > 1:
         dist.barrier()
 
