@@ -45,8 +45,9 @@ class FlatGradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
-            if also_wait is not None:
-                self.stream.wait_stream(also_wait)
+            for other in (also_wait if isinstance(also_wait, (list, tuple)) else [also_wait]):
+                if other is not None:
+                    self.stream.wait_stream(other)
             if self.record_timing and self.ev_first is None:
                 self.ev_first = torch.cuda.Event(enable_timing=True)
                 self.ev_first.record(self.stream)
@@ -112,7 +113,8 @@ class FlatDataParallel:
                 ops.join_wgrad_stream(self.store.params[0])
                 self.reducer.reduce_range(lo, hi)
             else:
-                self.reducer.reduce_range(lo, hi, also_wait=self.store.state.wgrad_stream)
+                # (under graph replay the small parameter-gradient reductions of the slice run on a third stream)
+                self.reducer.reduce_range(lo, hi, also_wait=[self.store.state.wgrad_stream, self.store.state.aux_stream])
 
     def no_sync(self, flag: bool = True) -> None:
         """Gradient accumulation: skip the exchange on all but the last micro-batch (DDP's no_sync)."""

@@ -62,7 +62,7 @@ class _Pair:
 
     def __init__(self):
         self.g_f = None
-        self.segments = None        # [(M_k, W_k or None, module_k or None)]
+        self.segments = None        # [(M_k, W_k or None, A_k or None, module_k or None)]
         self.static_in = None
         self.out = None
         self.closure = None
@@ -83,7 +83,7 @@ class ChainGraphs:
         self.owner = owner              # any parameter of the chain: names the engine (side stream, accumulate flag)
         self.hook = hook or (lambda: None)
         self.pairs = {}
-        self.pool = self.pool_w = None
+        self.pool = self.pool_w = self.pool_a = None
         self.stream: Optional[torch.cuda.Stream] = None
         self.replays = 0                # graph launches so far (tests)
         self.broken = False             # a capture failed: the chain stays eager (still HIP kernels, launched from Python)
@@ -99,7 +99,15 @@ class ChainGraphs:
             pair = self.pairs[key] = _Pair()
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=self.owner.device)
-            self.pool, self.pool_w = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+            self.pool, self.pool_w, self.pool_a = (torch.cuda.graph_pool_handle() for _ in range(3))
+            # NK_GRAPH_AUX=1: a third stream for the few-microsecond reductions (bias column sums, LayerNorm parameter gradients),
+            # ~600 per step that otherwise queue between the weight-gradient GEMMs of the side stream.  Measured: the side stream
+            # then ends 1.0-1.5 ms after the main chain instead of 4.0, the main chain is 2.4 ms slower, the step does not move
+            # (177.9 / 177.5 vs 178.0 / 177.3 ms, alternating): off by default.
+            st = ops.state_of(self.owner)
+            if st.wgrad_stream is not None and os.environ.get("NK_GRAPH_AUX", "0") == "1":
+                if st.aux_stream is None:
+                    st.aux_stream = torch.cuda.Stream(device=self.owner.device)
             self.ticks = torch.zeros(1, dtype=torch.int32, device=self.owner.device)   # backward replays so far, counted on the device
         if not pair.warm or self.broken:
             return self._warm(pair, fwd, inputs)
@@ -199,19 +207,28 @@ class ChainGraphs:
             if module is None:
                 self.ticks.add_(1)        # (the tail after the last block may hold no launch at all: an empty graph cannot be instantiated)
             cur[0].capture_end()
-            g_m, g_w = cur[0], None
+            g_m, g_w, g_a = cur[0], None, None
             parked, st.deferred = st.deferred, ([] if side is not None else None)
             if parked:
-                g_w = torch.cuda.CUDAGraph()
-                with torch.cuda.stream(side):
-                    g_w.capture_begin(pool=self.pool_w, capture_error_mode="thread_local")
-                    try:
-                        for fn, _reads in parked:
-                            fn()
-                    finally:
-                        g_w.capture_end()
-                held.append(parked)       # the closures hold what W_k reads: nothing of it may be recycled by a later M capture
-            segments.append((g_m, g_w, module))
+                aux = st.aux_stream
+                for stream, pool, part in ((side, self.pool_w, [e for e in parked if aux is None or not e[2]]),
+                                           (aux, self.pool_a, [e for e in parked if aux is not None and e[2]])):
+                    if not part:
+                        continue
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(stream):
+                        g.capture_begin(pool=pool, capture_error_mode="thread_local")
+                        try:
+                            for fn, _reads, _small in part:
+                                fn()
+                        finally:
+                            g.capture_end()
+                    if stream is side:
+                        g_w = g
+                    else:
+                        g_a = g
+                held.append(parked)       # the closures hold what W_k / A_k read: nothing of it may be recycled by a later M capture
+            segments.append((g_m, g_w, g_a, module))
 
         def boundary(module):
             cut(module)
@@ -234,20 +251,27 @@ class ChainGraphs:
         pair.segments = segments
 
     def _replay_backward(self, pair: _Pair) -> None:
-        side = ops.state_of(self.owner).wgrad_stream
+        st = ops.state_of(self.owner)
+        side, aux = st.wgrad_stream, st.aux_stream
         main = torch.cuda.current_stream()
         hook = self.hook()
-        for g_m, g_w, module in pair.segments:
+        for g_m, g_w, g_a, module in pair.segments:
             g_m.replay()
             if g_w is not None:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     g_w.replay()
+            if g_a is not None:
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    g_a.replay()
             if hook is not None and module is not None:
                 hook(module)
             self.replays += 1
         if side is not None:
             main.wait_stream(side)
+        if aux is not None:
+            main.wait_stream(aux)
 
 
 def _tree_map(fn: Callable, obj):

@@ -59,6 +59,7 @@ class EngineState:
         # `segment_hook`, which captures the parked launches as that segment's own graph
         self.deferred: Optional[list] = None
         self.segment_hook: Optional[Callable] = None
+        self.aux_stream = None      # graph replay: a third stream for the small parameter-gradient reductions (graphs.py)
         EngineState._live.add(self)
 
     def derived(self) -> "EngineState":
@@ -120,7 +121,7 @@ def wgrad_mode(p=None) -> int:
     return 2 if st.assume_zeroed else 0
 
 
-def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None) -> None:
+def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None, small: bool = False) -> None:
     """Run `fn` (kernels that only WRITE parameter gradients of `owner`'s engine) on that engine's side stream if it has one.
 
     Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads them until the optimizer /
@@ -134,7 +135,9 @@ def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None) -> None:
         fn()
         return
     if st.deferred is not None:
-        st.deferred.append((fn, reads))
+        # `small`: a few-microsecond reduction (bias column sums, LayerNorm parameter gradients).  Under graph replay those go to a
+        # third stream of their own (neurosis_amd/graphs.py): ~600 of them per step otherwise sit between the weight-gradient GEMMs
+        st.deferred.append((fn, reads, small))
         return
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -219,6 +222,8 @@ def join_wgrad_stream(owner=None) -> None:
         side = st.wgrad_stream
         if side is not None and st.deferred is None:
             torch.cuda.current_stream().wait_stream(side)
+            if st.aux_stream is not None:
+                torch.cuda.current_stream().wait_stream(st.aux_stream)
         return
     seen = set()
     for st in list(EngineState._live):
@@ -482,14 +487,10 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
 
         acc = state_of(weight).grad_accumulate   # every parameter gradient is OVERWRITTEN by its (single) producer unless accumulating
 
-        def wg():
-            if not queued:
-                gemm_tn_f32(dy, x, g2d(weight), wgrad_mode(weight))
-            if bias is not None:
-                colsum(dy, grad_flat(bias), acc)
-
-        if not queued or bias is not None:
-            on_wgrad_stream(wg, dy, x, owner=weight)
+        if not queued:
+            on_wgrad_stream(lambda: gemm_tn_f32(dy, x, g2d(weight), wgrad_mode(weight)), dy, x, owner=weight)
+        if bias is not None:
+            on_wgrad_stream(lambda: colsum(dy, grad_flat(bias), acc), dy, owner=weight, small=True)
         if not need_dx:
             return None
         return gemm_nn(dy, w2d(weight), dx_add)
@@ -537,13 +538,11 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
             raise ValueError("conv2d bwd: dy must be dense")
         acc = state_of(weight).grad_accumulate
 
-        def wg():
-            call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(weight), _stream())
-            if bias is not None:
-                colsum(dy, grad_flat(bias), acc)
-
         if weight.requires_grad:          # frozen convolutions (the LPIPS trunk) only pass the gradient through
-            on_wgrad_stream(wg, dy, x.t, owner=weight)
+            on_wgrad_stream(lambda: call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(weight), _stream()),
+                            dy, x.t, owner=weight)
+            if bias is not None:
+                on_wgrad_stream(lambda: colsum(dy, grad_flat(bias), acc), dy, owner=weight, small=True)
         drow = None
         if rowvec is not None:
             drow32 = torch.empty(x.N, Cout, dtype=torch.float32, device=dy.device)
@@ -622,7 +621,7 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
                  grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, int(acc), _stream())
 
         if state_of(weight).norm_params_on_side_stream:
-            on_wgrad_stream(params, dy, x, mean, rstd, ws, owner=weight)
+            on_wgrad_stream(params, dy, x, mean, rstd, ws, owner=weight, small=True)
         else:
             params()
         return dx

@@ -65,7 +65,8 @@ def test_graph_replay_reproduces_the_eager_chain_bit_for_bit():
     pair = next(iter(cg.pairs.values()))
     assert pair.g_f is not None and pair.segments is not None and pair.closure is None
     # one M graph per top-level block (+ head and tail); the blocks that own weights also have a side-stream graph W
-    assert len(pair.segments) >= len(net_g.input_blocks) + len(net_g.output_blocks) + 2 and sum(w is not None for _, w, _ in pair.segments) >= len(net_g.input_blocks)
+    assert len(pair.segments) >= len(net_g.input_blocks) + len(net_g.output_blocks) + 2 and sum(w is not None for _, w, _, _ in pair.segments) >= len(net_g.input_blocks)
+    assert all(a is None for _, _, a, _ in pair.segments)      # (the third-stream graphs for the small reductions are opt-in: NK_GRAPH_AUX=1)
     assert int(cg.ticks) == 4 and cg.replays == 4 * (1 + len(pair.segments))     # warm-up step eager; capture step and three more replayed
     for i, (a, b) in enumerate(zip(loss_e, loss_g)):
         assert torch.equal(a, b), (i, a.tolist(), b.tolist())

@@ -17,17 +17,24 @@ def timed(self, pair):
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record(main)
     hook = self.hook()
-    for g_m, g_w, module in pair.segments:
+    aux = ops.state_of(self.owner).aux_stream
+    for g_m, g_w, g_a, module in pair.segments:
         g_m.replay()
         if g_w is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 g_w.replay()
+        if g_a is not None:
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                g_a.replay()
         if hook is not None and module is not None:
             hook(module)
     e1.record(main)
     e2.record(side)
     main.wait_stream(side)
+    if aux is not None:
+        main.wait_stream(aux)
     marks.append((e0, e1, e2))
 graphs.ChainGraphs._replay_backward = timed
 def step():
