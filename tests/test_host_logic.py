@@ -97,3 +97,16 @@ def test_two_engines_keep_their_own_state():
     pad._nk_state = d
     assert ops.state_of(pad) is d and d.wgrad_stream is a.wgrad_stream and ops.wgrad_mode(pad) == 0
     assert b.wgrad_stream is None and ops.state.wgrad_stream is None
+
+
+def test_graph_kind_selection_from_the_environment(monkeypatch):
+    from neurosis_amd.graphs import graphs_enabled
+
+    monkeypatch.delenv("NK_GRAPH", raising=False)
+    assert graphs_enabled("unet") and not graphs_enabled("vae") and not graphs_enabled("te")      # default: the training chain only
+    monkeypatch.setenv("NK_GRAPH", "0")
+    assert not graphs_enabled("unet")
+    monkeypatch.setenv("NK_GRAPH", "1")
+    assert graphs_enabled("unet") and graphs_enabled("vae") and graphs_enabled("te")
+    monkeypatch.setenv("NK_GRAPH", "unet,te")
+    assert graphs_enabled("unet") and graphs_enabled("te") and not graphs_enabled("vae")
