@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
 
 
-def _setup():
+def _setup(**unet_kw):
     import neurosis_amd.modules.diffusion as D
     from neurosis_amd.nn import FlatParamStore
 
-    net = D.UNetModel(**UNET_TINY)
+    net = D.UNetModel(**{**UNET_TINY, **unet_kw})
     net.load_state_dict(synth_state_dict(json.loads((G / "unet_sdxl_tiny_keys.json").read_text())))
     net = net.cuda()
     store = FlatParamStore(net.parameters())
@@ -38,10 +38,10 @@ def _batches(n, hw=(16, 16)):
     return out
 
 
-def _steps(batches, graph: bool):
+def _steps(batches, graph: bool, **unet_kw):
     os.environ["NK_GRAPH"] = "1" if graph else "0"
     try:
-        net, store, den, lossfn, wrapped = _setup()
+        net, store, den, lossfn, wrapped = _setup(**unet_kw)
         losses, grads = [], []
         for b in batches:
             loss = lossfn._forward(wrapped, den, {"crossattn": b["ctx"], "vector": b["y"]}, b["x"], {}, sigmas=b["sigma"], noise=b["noise"])
@@ -306,6 +306,19 @@ def test_optional_replay_arrangements_give_the_same_results(env):
         assert len(pair.segments) > 2 * (len(net_g.input_blocks) + len(net_g.output_blocks))
     if env.get("NK_GRAPH_AUX") == "1":
         assert any(a is not None for _, _, a, _ in pair.segments)
+    for a, b in zip(loss_e, loss_g):
+        assert torch.equal(a, b)
+    for a, b in zip(grad_e, grad_g):
+        assert float((a - b).norm() / a.norm()) <= 1e-5
+
+
+def test_activation_checkpointing_replays_too():
+    """use_checkpoint=True (the reference's flag): blocks drop their activations and re-run their forward inside backward -- under a
+    capture those recomputations are simply more launches of the backward segments."""
+    batches = _batches(4)
+    net_e, loss_e, grad_e = _steps(batches, graph=False, use_checkpoint=True)
+    net_g, loss_g, grad_g = _steps(batches, graph=True, use_checkpoint=True)
+    assert next(iter(net_g._nk_graphs.pairs.values())).segments is not None
     for a, b in zip(loss_e, loss_g):
         assert torch.equal(a, b)
     for a, b in zip(grad_e, grad_g):
