@@ -1009,7 +1009,9 @@ __device__ __forceinline__ void sk_decode(const NkGemmParams& p, int t, int ntm,
 // accumulators -> global, fused bias / rowvec / residual.  acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)]
 //                                                                           [n0 + wn*32 + j*16 + (lane>>4)*4 + r]
 template <int OUT_F32, int MI = 4>     // MI 16-row blocks x one pair of 16-column blocks
-__device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI][2], int mbase, int nbase, int lane) {
+__device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI][2], int mbase, int nbase, int lane,
+                                                   int mlimit = -1) {   // mlimit >= 0: rows at or past it are not stored (instead of p.M)
+  const int Mrows = mlimit >= 0 ? mlimit : p.M;
   const int g = lane >> 4;
   // after the row swap: lanes g=0 hold columns 0-7 of the wave's 32, g=1 16-23, g=2 8-15, g=3 24-31
   const int n = nbase + (g & 1) * 16 + (g >> 1) * 8;
@@ -1041,7 +1043,7 @@ __device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* 
       v[4 + r] = __uint_as_float(sw[1]) * p.alpha;
     }
     const int m = mrow + i * 16;
-    if (!(n_ok && m < p.M)) continue;
+    if (!(n_ok && m < Mrows)) continue;
     if constexpr (OUT_F32) {
       float* dst = (float*)Cv + (long)m * p.ldc + n;
       if ((p.N & 3) == 0 && (p.ldc & 3) == 0 && n + 8 <= p.N) {
@@ -1788,6 +1790,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
 
 static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk);
 #include "gemm_g2.h"
+#include "conv_halo.h"
 
 static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
   static int on = -1;
@@ -2081,6 +2084,9 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   if (p.residual) NK_CHECK_ARG(((uintptr_t)p.residual & 15) == 0 && ((p.ldr & 7) == 0 || (p.N & 7) != 0));
   if (!out_f32) NK_CHECK_ARG((p.ldc & 7) == 0 || (p.N & 7) != 0);
   if (p.fRowsPerBatch.d == 0) p.fRowsPerBatch = make_fastdiv(1);
+
+  // 3 x 3 / stride 1 / padding 1 convolutions over whole 64-channel slabs: the halo-tile kernel (conv_halo.h)
+  if (!use_v1() && use_halo(p, amode, bmode, out_f32)) return launch_halo(p, stream);
 
   // two-group staggered ring at one workgroup per CU (gemm_g2.h): Linear forward / dgrad / wgrad shapes whose 128 x 160 (or
   // 128 x 128) tiles come out in whole rounds of 256

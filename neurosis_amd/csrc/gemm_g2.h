@@ -230,14 +230,16 @@ __device__ __forceinline__ void g2_read(bf16x8_t (&f)[2 * NF], const FragG2<MODE
 
 // a lone 16-column block of the wave tile (the fifth of the 80-column half): the lane holds 4 consecutive columns of one row
 template <int OUT_F32, int MI>
-__device__ __forceinline__ void reg_epilogue_col16(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI], int mbase, int nbase, int lane) {
+__device__ __forceinline__ void reg_epilogue_col16(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI], int mbase, int nbase, int lane,
+                                                   int mlimit = -1) {
+  const int Mrows = mlimit >= 0 ? mlimit : p.M;
   const int n = nbase + (lane >> 4) * 4;
   const int mrow = mbase + (lane & 15);
   if (n >= p.N) return;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = mrow + i * 16;
-    if (m >= p.M) continue;
+    if (m >= Mrows) continue;
     float v[4] = {acc[i][0] * p.alpha, acc[i][1] * p.alpha, acc[i][2] * p.alpha, acc[i][3] * p.alpha};
     if constexpr (OUT_F32) {
       float* dst = (float*)Cv + (long)m * p.ldc + n;

@@ -55,6 +55,16 @@ struct NkGemmParams {
   int sk_chunked;           // 1: each XCD owns a contiguous eighth of the tile list
   int sk_debug;             // NK_SK_DEBUG: 1 = no epilogue stores (ablation), 2 = every fix-up wait gives up at once (tests the fail-closed path)
   unsigned* sk_health;      // backward-health word (errors.hip): raised when a fix-up wait gives up
+  // halo-tile 3 x 3 convolution (conv_halo.h)
+  int halo_nb;              // images in the batch (0: not a convolution the halo kernel may take)
+  const float* gn_sums;     // prologue GroupNorm of the INPUT: [halo_nb][groups][2] sum, sum of squares over (H*W, channels of the group)
+  const float* gn_gamma;    // [Cin]
+  const float* gn_beta;     // [Cin]
+  float gn_eps;
+  int gn_groups;
+  int gn_silu;
+  float* stats_part;        // statistics epilogue: [halo_nb][pixel tiles per image][2 * stats_groups] partial sums of the OUTPUT
+  int stats_groups;
 };
 #define NK_MAX_BATCH 8
 

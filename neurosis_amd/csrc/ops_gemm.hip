@@ -135,6 +135,7 @@ extern "C" int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, 
   p.rowvec = (const bf16_t*)rowvec; p.ld_rowvec = d->Cout;
   p.fRowsPerBatch = make_fastdiv(d->Ho * d->Wo);
   p.residual = (const bf16_t*)residual; p.ldr = d->Cout;
+  p.halo_nb = (d->KH == 3 && d->KW == 3) ? d->N : 0;       // 3 x 3 / stride 1 / padding 1 shapes may take the halo-tile kernel
   return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_KC, 0, 0, (hipStream_t)stream);
 }
 

@@ -130,28 +130,51 @@ class AutoencodingEngine(nn.Module):
                  perceptual_loss: Optional[nn.Module] = None, perceptual_weight: float = 1.0, **kwargs):
         super().__init__()
         self.encoder, self.decoder = encoder, decoder
-        # adversarial part (GeneralLPIPSWithDiscriminator's arguments, discriminator_loss.py:23-40, with perceptual_weight = 0)
-        self.discriminator = discriminator
-        self.perceptual_loss = perceptual_loss            # neurosis_amd.modules.losses.LPIPS (frozen), or None
-        self.perceptual_weight = perceptual_weight if perceptual_loss is not None else 0.0
-        if discriminator is not None:
+        self.disc_store: Optional[FlatParamStore] = None
+        self.regularization = regularizer if regularizer is not None else DiagonalGaussianRegularizer()
+        if hasattr(loss, "engine_settings"):
+            # a loss CLASS of the reference's surface (neurosis_amd.modules.autoencoding.losses.GeneralLPIPSWithDiscriminator /
+            # AutoencoderLPIPSWithDiscr, as a config-5 YAML names it): registered as `self.loss` like the reference engine does
+            # (models/autoencoder.py:161), so its submodules checkpoint under `loss.*`; the fused arithmetic below reads its settings.
+            # The discriminator / LPIPS / logvar it owns are referenced WITHOUT registering them a second time.
+            self.loss = loss
+            cfg = loss.engine_settings()
+            self.__dict__["discriminator"] = cfg["discriminator"]
+            self.__dict__["perceptual_loss"] = cfg["perceptual_loss"]
+            self.perceptual_weight = cfg["perceptual_weight"] if cfg["perceptual_loss"] is not None else 0.0
+            disc_loss, disc_factor, disc_weight, rec_weight = cfg["disc_loss"], cfg["disc_factor"], cfg["disc_weight"], cfg["rec_weight"]
+            disc_start = disc_start if disc_start else cfg["disc_start"]
+            learn_logvar = cfg["learn_logvar"]
+            lv = cfg["logvar"]
+            if lv is None:
+                self.logvar = nn.Parameter(torch.zeros(size=()), requires_grad=False)
+            else:
+                self.__dict__["logvar"] = lv
+            if regularization_weights is None:
+                regularization_weights = cfg["regularization_weights"]
+            loss = cfg["rec_loss_type"]
+        else:
+            # adversarial part as keyword arguments (GeneralLPIPSWithDiscriminator's, discriminator_loss.py:23-40)
+            self.discriminator = discriminator
+            self.perceptual_loss = perceptual_loss            # neurosis_amd.modules.losses.LPIPS (frozen), or None
+            self.perceptual_weight = perceptual_weight if perceptual_loss is not None else 0.0
+            # the output log-variance of the nll (discriminator_loss.py:56-58): a scalar parameter, trained with the autoencoder when
+            # learn_logvar (get_trainable_autoencoder_parameters, :90-93)
+            self.logvar = nn.Parameter(torch.ones(size=()) * logvar_init, requires_grad=learn_logvar)
+        if self.discriminator is not None:
             from ..modules.losses import get_discr_loss_fn
 
             self.disc_loss = get_discr_loss_fn(disc_loss)
         self.disc_start, self.disc_factor, self.discriminator_weight = disc_start, disc_factor, disc_weight
         self.rec_weight = rec_weight
-        # the output log-variance of the nll (discriminator_loss.py:56-58): a scalar parameter, trained with the autoencoder when
-        # learn_logvar (get_trainable_autoencoder_parameters, :90-93)
-        self.logvar = nn.Parameter(torch.ones(size=()) * logvar_init, requires_grad=learn_logvar)
         self.learn_logvar = learn_logvar
-        self.disc_store: Optional[FlatParamStore] = None
-        self.regularization = regularizer if regularizer is not None else DiagonalGaussianRegularizer()
         if isinstance(loss, nn.MSELoss) or loss in ("l2", "mse"):
             self.rec_loss_type = "l2"
         elif isinstance(loss, nn.L1Loss) or loss in ("l1", "mae"):
             self.rec_loss_type = "l1"
         else:
-            raise NotImplementedError("only the simple reconstruction losses (l2 / l1) are built; GeneralLPIPSWithDiscriminator is not")
+            raise NotImplementedError("loss must be 'l2' / 'l1' (or nn.MSELoss / nn.L1Loss), or one of the loss classes of "
+                                      "neurosis_amd.modules.autoencoding.losses; got " + type(loss).__name__)
         self.input_key = input_key
         self.regularization_weights = dict(regularization_weights or {})     # e.g. {"kl_loss": 1e-6}; the reference's simple branch uses none
         self.global_step = 0

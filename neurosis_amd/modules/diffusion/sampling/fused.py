@@ -51,14 +51,17 @@ class CapturedEulerStep:
         self.uc = {k: uc[k].clone() for k in self.cond} if guider.rep == 2 else self.cond
         stream = torch.cuda.Stream(device=x.device)
         stream.wait_stream(torch.cuda.current_stream(x.device))
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream), ops.capture_scope():
             # eager run on the capture stream first: weight shadows, padded-conv parameters and the stream-K workspace of this
             # stream are created here (allocations that must not happen while capturing)
             fused._euler_eager(self.x, self.sigma_hat, self.sigma_next, self.cond, self.uc, guider, out=torch.empty_like(self.x))
         torch.cuda.current_stream(x.device).wait_stream(stream)
         torch.cuda.synchronize(x.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=stream):
+        # ops.capture_scope: weight-derived caches (the channel-padded stand-ins of the 4-channel convolutions and their bf16
+        # shadows) are refilled IN PLACE inside the graph, so a replay after an optimizer step or inside ema_scope() reads the
+        # current masters -- the key of this graph (frozen_stamp) does not change for store-managed parameters
+        with ops.capture_scope(), torch.cuda.graph(self.graph, stream=stream):
             fused._euler_eager(self.x, self.sigma_hat, self.sigma_next, self.cond, self.uc, guider, out=self.x)
 
     def load_conditioning(self, cond: dict, uc: dict) -> None:

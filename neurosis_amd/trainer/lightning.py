@@ -52,6 +52,10 @@ class DiffusionEngineMI355X(_Base):
         self._wire_dtype = {None: None, "fp32": None, "bf16": torch.bfloat16}[wire_dtype]
         self.dp = None
         self._micro = 0
+        # Lightning restores a checkpoint (load_state_dict, on_load_checkpoint) BEFORE on_fit_start, i.e. before the flat store, the
+        # fused optimizer and the EMA exist: what arrives early is parked here and applied at the end of on_fit_start
+        self._pending_optimizer: Optional[dict] = None
+        self._pending_ema: Optional[dict] = None
 
     # -- setup --------------------------------------------------------------------------------------------
     def _trainer_attr(self, name: str, default: Any) -> Any:
@@ -70,6 +74,34 @@ class DiffusionEngineMI355X(_Base):
         world = int(self._trainer_attr("world_size", 1) or 1)
         if world > 1:
             self.dp = FlatDataParallel(self.engine.model.diffusion_model, self.engine.store, wire_dtype=self._wire_dtype)
+        self._apply_pending()
+
+    def _apply_pending(self) -> None:
+        """checkpoint state that arrived before the store / optimizer / EMA existed (Trainer.fit(ckpt_path=...))"""
+        if self._pending_ema is not None:
+            ema = getattr(self.engine, "model_ema", None)
+            if ema is None:
+                raise RuntimeError("the checkpoint carries engine.model_ema.* but this engine was built with use_ema=False")
+            ema.load_state_dict(self._pending_ema)
+            self._pending_ema = None
+        if self._pending_optimizer is not None:
+            opt = self.engine._torch_optimizer
+            if opt is None:
+                raise RuntimeError("the checkpoint carries optimizer state (nk_optimizer) but the engine has no optimizer configured")
+            opt.load_state_dict(self._pending_optimizer)
+            self._pending_optimizer = None
+            self.engine.store.masters_changed()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        """`engine.model_ema.*` entries are held back while the EMA module does not exist yet (it is created with the flat store in
+        on_fit_start): a strict load would otherwise report them as unexpected keys."""
+        prefix = "engine.model_ema."
+        if getattr(self.engine, "model_ema", None) is None and self.engine.use_ema:
+            held = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+            if held:
+                self._pending_ema = held
+                state_dict = {k: v for k, v in state_dict.items() if not k.startswith(prefix)}
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
 
     # -- the step -----------------------------------------------------------------------------------------
     def training_step(self, batch: dict, batch_idx: int):
@@ -103,8 +135,11 @@ class DiffusionEngineMI355X(_Base):
 
     def on_load_checkpoint(self, checkpoint: dict) -> None:
         opt = self.engine._torch_optimizer
-        if opt is not None and "nk_optimizer" in checkpoint:
-            opt.load_state_dict(checkpoint["nk_optimizer"])
+        if "nk_optimizer" in checkpoint:
+            if opt is not None:
+                opt.load_state_dict(checkpoint["nk_optimizer"])
+            else:                       # the usual order under Trainer.fit(ckpt_path=...): applied by on_fit_start
+                self._pending_optimizer = checkpoint["nk_optimizer"]
         self.engine.global_step = int(checkpoint.get("nk_global_step", self.engine.global_step))
         if self.engine.store is not None:
             self.engine.store.masters_changed()

@@ -208,3 +208,54 @@ def test_lightning_adapter_step_logic_with_a_stand_in_trainer():
     ckpt = {}
     ad.on_save_checkpoint(ckpt)
     assert ckpt["nk_global_step"] == 1 and int(ckpt["nk_optimizer"]["state"][0]["step"]) == 1
+
+
+def test_lightning_adapter_applies_a_checkpoint_that_arrives_before_fit_start():
+    """Trainer.fit(ckpt_path=...) calls load_state_dict and on_load_checkpoint BEFORE on_fit_start, i.e. before the flat
+    store, the fused optimizer and the EMA module exist.  The adapter parks what arrives early and applies it at the end of
+    on_fit_start: the resumed adapter continues with the saved step count, second moments and EMA, and a strict load succeeds."""
+    from types import SimpleNamespace
+
+    import neurosis_amd.modules.diffusion as D
+    from neurosis_amd.models import AutoencoderKL
+    from neurosis_amd.optimizers import Adafactor
+    from neurosis_amd.trainer import DiffusionEngineMI355X
+
+    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    keys = json.loads((G / "engine_tiny_keys.json").read_text())
+
+    def mk():
+        net = D.UNetModel(**UNET_TINY)
+        net.load_state_dict(synth_state_dict(keys["unet"]))
+        vae = AutoencoderKL(embed_dim=4, ddconfig={k: v for k, v in VAE_TINY.items() if k != "embed_dim"})
+        vae.load_state_dict({k: v for k, v in synth_state_dict(keys["vae"]).items() if not k.startswith(("encoder.quant_conv", "decoder.post_quant_conv"))})
+        den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization())
+        ad = DiffusionEngineMI355X(require_lightning=False, model=net, denoiser=den, first_stage_model=vae, scale_factor=0.13025, input_key="image",
+                                   use_ema=True, ema_decay_rate=0.99, optimizer=partial(Adafactor, scale_parameter=True, relative_step=True, warmup_init=True),
+                                   loss_fn=D.StandardDiffusionLoss(sigma_generator=D.EDMSigmaGenerator(), loss_weighting=D.EpsWeighting()))
+        ad._trainer_stub = SimpleNamespace(device=torch.device("cuda", 0), world_size=1, accumulate_grad_batches=1)
+        return ad
+
+    batch = lambda: {"image": e["image"].cuda(), "crossattn": e["crossattn"].cuda(), "vector": e["vector"].cuda()}
+    a = mk()
+    a.on_fit_start()
+    torch.manual_seed(5)
+    a.training_step(batch(), 0)
+    a.training_step(batch(), 1)
+    a.engine.join_optimizer()
+    torch.cuda.synchronize()
+    ckpt = {"state_dict": {k: v.detach().clone() for k, v in a.state_dict().items()}}
+    a.on_save_checkpoint(ckpt)
+    assert any(k.startswith("engine.model_ema.") for k in ckpt["state_dict"])
+
+    b = mk()                                               # Lightning's order: restore first, on_fit_start afterwards
+    assert b.engine.store is None and b.engine._torch_optimizer is None
+    b.load_state_dict(ckpt["state_dict"], strict=True)
+    b.on_load_checkpoint(ckpt)
+    assert b._pending_optimizer is not None and b._pending_ema is not None
+    b.on_fit_start()
+    assert b._pending_optimizer is None and b._pending_ema is None
+    assert b.engine.global_step == 2 and b.engine.adafactor.step_count == 2
+    assert torch.equal(b.engine.store.master, a.engine.store.master)
+    assert torch.equal(b.engine.adafactor.state, a.engine.adafactor.state)
+    assert torch.equal(b.engine.model_ema.shadow, a.engine.model_ema.shadow) and int(b.engine.model_ema.num_updates) == 2

@@ -199,6 +199,33 @@ def test_captured_step_equals_eager_step_and_survives_weight_updates():
         assert rel_err(got3, want3) <= 1e-6 and rel_err(got3, want) > 1e-4
 
 
+def test_captured_step_sees_a_store_refresh_of_the_channel_padded_convs():
+    """with the parameters in a flat store the graph's key does not change when the masters do; the channel-padded stand-ins
+    of the 4-channel convolutions (conv_in, out) must therefore be refilled INSIDE the graph.  Replaying after store.refresh() with
+    changed weights equals the eager step on the new weights (it mixed old conv_in / out weights with new ones before)."""
+    import neurosis_amd.modules.diffusion as D
+    import neurosis_amd.modules.diffusion.sampling as S
+    from neurosis_amd.modules.guidance import VanillaCFG
+    from neurosis_amd.nn import FlatParamStore
+
+    fx = torch.load(G / "sampler_unet_tiny.pt", weights_only=False)
+    sampler = S.EulerEDMSampler(discretization=D.LegacyDDPMDiscretization(), guider=VanillaCFG(5.0), num_steps=3)
+    engine = _tiny_engine(sampler)
+    store = FlatParamStore(engine.model.parameters())
+    cond, uc = ({k: v.cuda() for k, v in d.items()} for d in (fx["cond"], fx["uc"]))
+    eager = S.FusedDenoiser(engine.model, engine.denoiser, use_graph=False)
+    graphed = S.FusedDenoiser(engine.model, engine.denoiser, use_graph=True)
+    with torch.no_grad():
+        first = sampler(graphed, fx["noise"].cuda().clone(), cond, uc=uc).clone()
+        graph = next(iter(graphed._captured.values()))
+        store.master.mul_(1.05)                      # what an optimizer step or ema_scope()'s copy_to does: masters move, then refresh
+        store.refresh()
+        want = sampler(eager, fx["noise"].cuda().clone(), cond, uc=uc).clone()
+        got = sampler(graphed, fx["noise"].cuda().clone(), cond, uc=uc).clone()
+    assert next(iter(graphed._captured.values())) is graph, "store-managed parameters keep the captured graph"
+    assert rel_err(got, want) <= 1e-6 and rel_err(got, first) > 1e-4
+
+
 def test_vae_decoder_against_reference_golden():
     import neurosis_amd.modules.diffusion as D
 
