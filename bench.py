@@ -115,9 +115,11 @@ class GemmTimer:
     stream the kernels are launched on; algorithmic FLOPs = 2*M*N*K per launch."""
 
     NAMES = ("nk_linear_fwd", "nk_linear_dgrad", "nk_linear_wgrad", "nk_conv2d_fwd", "nk_conv2d_dgrad", "nk_conv2d_wgrad",
-             "nk_linear_fwd_batched", "nk_linear_wgrad_batched")
-    # the batched entry points (several same-shape GEMMs per launch) are reported with the family they belong to
-    FAMILY = {"nk_linear_fwd_batched": "nk_linear_fwd", "nk_linear_wgrad_batched": "nk_linear_wgrad"}
+             "nk_linear_fwd_batched", "nk_linear_wgrad_batched", "nk_conv2d_fwd_fused", "nk_conv2d_dgrad_flipped")
+    # the batched entry points (several same-shape GEMMs per launch) are reported with the family they belong to; so are the
+    # convolutions with a fused GroupNorm statistics epilogue and the input gradients that run as forward convolutions of dy
+    FAMILY = {"nk_linear_fwd_batched": "nk_linear_fwd", "nk_linear_wgrad_batched": "nk_linear_wgrad", "nk_conv2d_fwd_fused": "nk_conv2d_fwd",
+              "nk_conv2d_dgrad_flipped": "nk_conv2d_dgrad"}
 
     def __init__(self):
         self.records = []
@@ -134,7 +136,7 @@ class GemmTimer:
             return 2.0 * args[3] * args[4] * args[5] * args[6]
         d = args[0]._obj
         up = 2 if d.upsample else 1
-        if name == "nk_conv2d_dgrad":  # rows = input pixels (virtual 2x grid when upsampling), algorithmic = same MACs as fwd
+        if name in ("nk_conv2d_dgrad", "nk_conv2d_dgrad_flipped"):  # rows = input pixels (virtual 2x grid when upsampling), algorithmic = same MACs as fwd
             return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin
         return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin
 

@@ -91,6 +91,27 @@ typedef struct NkConvDesc {
 /* y = conv(x, w) + bias[Cout] + rowvec[n][Cout] + residual[N][Ho][Wo][Cout]   (all three optional) */
 int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
                   const void* residual, void* y, void* stream);
+/* The same with GroupNorm fused on either side -- 3 x 3 / stride 1 / padding 1 convolutions the halo-tile kernel takes (conv_halo.h):
+ *   prologue  (gn_sums != NULL): the convolution reads silu?(GroupNorm(x)) without that tensor ever existing in HBM.  gn_sums
+ *             [N][gn_groups][2] = sum and sum of squares of x per (image, group) (nk_groupnorm_sums, or a producer's epilogue);
+ *             gn_gamma / gn_beta [Cin].  Forward-only users: the frozen VAE encoder's GroupNorm -> SiLU -> conv pairs
+ *             (modules/diffusion/model.py:116-124 ResnetBlock.forward: h = conv1(silu(norm1(x))), h = conv2(silu(norm2(h)))).
+ *   epilogue  (stats_part != NULL): per-tile partial sums of the OUTPUT, [N][tiles][2 * stats_groups] with tiles =
+ *             nk_conv2d_fused_tiles(...): what the GroupNorm that consumes y needs instead of its own statistics pass
+ *             (openaimodel.py:247-283: in_layers conv -> out_layers GroupNorm; model.py:116-124).
+ * nk_conv2d_fused_tiles returns 0 when this shape / option pair is not available: run the unfused kernels then. */
+long nk_conv2d_fused_tiles(const NkConvDesc* d, int gn_groups, int stats_groups);
+int nk_conv2d_fwd_fused(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
+                        const void* residual, void* y, const float* gn_sums, const float* gn_gamma, const float* gn_beta,
+                        float gn_eps, int gn_groups, int gn_silu, float* stats_part, int stats_groups, void* stream);
+/* wt[Cin][KH*KW][Cout], taps mirrored (tap t of w lands at tap KH*KW-1-t): the weights with which a stride-1 "same" convolution's
+ * INPUT GRADIENT is itself such a convolution, dx = nk_conv2d_fwd(dy, wt) with the channel roles swapped -- how the 3 x 3 input
+ * gradients of the ResBlocks (autograd of openaimodel.py:247-301) reach the halo-tile forward kernel. */
+int nk_conv_weight_flip(const void* w, void* wt, int Cout, int Cin, int taps, void* stream);
+/* nk_conv2d_dgrad with those weights, on the halo-tile forward kernel; _ok = 1 where it applies (3 x 3, stride 1, padding 1, whole
+ * 64-channel slabs, images the 32-pixel-wide tiles cover), else use nk_conv2d_dgrad */
+long nk_conv2d_dgrad_flipped_ok(const NkConvDesc* d);
+int nk_conv2d_dgrad_flipped(const NkConvDesc* d, const void* dy, const void* wt, void* dx, void* stream);
 /* dx over the conv input grid ([N][2H][2W][Cin] when upsample=1: follow with nk_upsample2x_bwd) */
 int nk_conv2d_dgrad(const NkConvDesc* d, const void* dy, const void* w, void* dx, void* stream);
 /* dw[Cout][KH][KW][Cin] (+)= ...  fp32 */
@@ -132,6 +153,13 @@ int nk_softmax_rows(void* s, long M, int L, void* stream);
 long nk_groupnorm_ws_floats(int N, int HW, int C, int G); /* fp32 elements of `ws` (per-block partial sums) */
 int nk_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      float* ws, int N, int HW, int C, int G, float eps, int silu, void* stream);
+/* The forward in separable passes (what nk_groupnorm_fwd runs back to back): sums [N][2G] (entry 2g = sum, 2g+1 = sum of squares over
+ * HW * C/G elements) from x, or from a convolution's per-tile partials; and the normalisation given the sums. */
+int nk_groupnorm_sums(const void* x, float* sums, float* ws, int N, int HW, int C, int G, void* stream);
+long nk_groupnorm_sums_ws_floats(int N, int nparts, int G);
+int nk_groupnorm_sums_from_parts(const float* part, float* sums, float* ws, int N, int nparts, int G, void* stream);
+int nk_groupnorm_apply(const void* x, const float* sums, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       int N, int HW, int C, int G, float eps, int silu, void* stream);
 int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                      const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
                      int N, int HW, int C, int G, int silu, int accumulate, void* stream);

@@ -2,40 +2,56 @@
 //
 // Why it exists.  The implicit-GEMM gather (OP_KCG) stages one [128 pixels][64 channels] A image PER TAP, so every activation
 // passes through the 64 B/clk/CU global -> LDS path nine times; at 128-wide CU tiles that path is the bound.  Here
-// a workgroup owns a 4 x 32 patch of output pixels of one image and keeps the (4+2) x (32+2) x 64-channel HALO of its inputs in
-// LDS: the nine taps of a 64-channel slab read their A fragments from that one image at per-lane addresses
-// (pixel + tap offset), and only the weights stream through the ring -- 26 KiB of activations per nine k-steps instead of 144.
+// a workgroup owns a TH x 32 patch of output pixels of one image (TH = 4 or 8) and keeps the (TH+2) x 34 x 64-channel HALO of its
+// inputs in LDS: the nine taps of a 64-channel slab read their A fragments from that one image at per-lane addresses
+// (pixel + tap offset), and only the weights stream through the ring.
 //
 // Structure: the two-group staggered loop of nk_gemm_g2_kernel (gemm_g2.h) with the A operand replaced.
-//   * tile = 128 output pixels (4 rows x 32 columns of one image) x BN output channels (160 or 128), 8 waves = 2 column groups x 4
-//     pixel rows; a wave's 32 pixels are one row segment, i.e. 32 CONSECUTIVE rows of the [N*H*W][Cout] output matrix;
-//   * k order is (64-channel slab, tap): the halo of slab s+1 is fetched while slab s is multiplied (two 26 KiB buffers);
+//   * tile = 32*TH output pixels x BN output channels (160 or 128); 8 waves = 2 column groups x 4 pixel-row groups; a wave owns
+//     TH/4 tile rows of 32 pixels = MI 16-pixel row blocks, each tile row being 32 CONSECUTIVE rows of the [N*H*W][Cout] output;
+//   * k order is (64-channel slab, tap): the halo of slab s+1 is fetched while slab s is multiplied (two buffers);
 //   * halo image: pixel hp = py * 34 + px at byte hp * 128, its eight 16-byte channel chunks XOR-swizzled by hp & 7 -- the sixteen
 //     consecutive pixels of a fragment read (one pixel row, any tap shift) then hit every bank once (ds_read_b128);
-//   * roles: waves 0-5 stage the weights (LDS-DMA, four-stage ring, counted exactly as in the g2 kernel), waves 6-7 stage the halo.
+//   * roles: waves 0-5 stage the weights (LDS-DMA into a THREE-stage ring: the weights of k-step t+2 are issued in the MFMA phase
+//     of k-step t, after the barrier behind which the last reads of stage (t-1) % 3 have retired), waves 6-7 stage the halo.
 //     vmcnt is per wave and in order, so a wave that staged both would have to land its HBM-latency halo pieces every k-step
-//     before its next weight slab; the halo waves instead keep up to seven k-steps of pieces in flight and drain once per slab;
-//   * optional GroupNorm(+SiLU) PROLOGUE (the VAE's frozen encoder): the raw input x lands in the halo buffer, and during the last
-//     taps of the previous slab all eight waves rewrite it in place as silu(x * a_c + b_c) (padding pixels stay zero) from the
-//     per-(image, group) sums of the producer -- the normalised tensor is never written to HBM;
+//     before its next weight slab; the halo waves instead keep several k-steps of pieces in flight and drain once per slab;
+//   * optional GroupNorm(+SiLU) PROLOGUE (the frozen VAE encoder): the raw input x lands in the halo buffer during taps 0-3 of the
+//     previous slab, and during taps 5-8 all eight waves rewrite it IN PLACE as silu(x * a_c + b_c) (padding pixels stay zero),
+//     a_c / b_c from the per-(image, group) sums of whoever produced x -- the normalised tensor never exists in HBM;
 //   * optional GroupNorm STATISTICS epilogue: per (tile, group) sum and sum of squares of the bf16-rounded outputs, combined in a
-//     fixed order (no atomics), for the GroupNorm that consumes this convolution's output;
-//   * swapped-operand MFMAs and the register-direct epilogue of the g2 kernel (bias / per-image row vector / residual fused).
+//     fixed order (no atomics), in the layout gn_reduce_partials_kernel (norm.hip) sums: the GroupNorm that consumes this
+//     convolution's output needs no statistics pass of its own;
+//   * swapped-operand MFMAs; register-direct epilogue (permlane16_swap pairs columns so a lane stores 16 B) with bias / per-image
+//     row vector / residual, all fetched in ONE batch of loads, so the
+//     epilogue exposes one memory latency instead of one per row block (measured on the first version of this kernel: ~18 us of
+//     fixed cost per 128-pixel tile, most of it five dependent load -> store round trips).
 // Reference call sites: ResBlock in_layers / out_layers convolutions (modules/diffusion/openaimodel.py:247-301), the VAE's
 // ResnetBlock conv1 / conv2 (modules/diffusion/model.py:85-134) and the GroupNorm + SiLU in front of them (:116-124).
 #pragma once
+#include <type_traits>
 
 #define CH_TW 32
-#define CH_TH 4
 #define CH_HW (CH_TW + 2)
-#define CH_HPX ((CH_TH + 2) * CH_HW)            // 204 halo pixels
-#define CH_HPIECES 26                           // 1 KiB pieces (8 pixels each) per halo buffer
-#define CH_HBUF (CH_HPIECES * 1024)             // 26624
 #define CH_BSTAGE 20480                         // weights of one k-step: up to 160 rows x 128 B
-#define CH_NS 4
-#define CH_SMEM_BYTES (2 * CH_HBUF + CH_NS * CH_BSTAGE)   // 135168
+#define CH_NS 3
 #define CH_NBW 6                                // weight-staging waves (0..5); waves 6, 7 stage the halo
-#define CH_HPW (CH_HPIECES / 2)                 // halo pieces per halo wave and slab: 13
+#define CH_TABLE_BYTES 1024                     // PRO: two [64 channels][a, b] fp32 tables
+
+template <int MI>
+struct HaloGeom {
+  static constexpr int TH = 2 * MI;                                   // tile rows: 4 or 8
+  static constexpr int RPW = MI / 2;                                  // tile rows per wave
+  static constexpr int HPX = (TH + 2) * CH_HW;                        // halo pixels: 204 / 340
+  static constexpr int HPIECES = ((HPX + 7) / 8 + 1) & ~1;            // 1 KiB pieces (8 pixels each), even: 26 / 44
+  static constexpr int HBUF = HPIECES * 1024;
+  static constexpr int HPW = HPIECES / 2;                             // pieces per halo wave and slab: 13 / 22
+  static constexpr int SMEM = 2 * HBUF + CH_NS * CH_BSTAGE + CH_TABLE_BYTES;   // 115712 / 152576
+  static constexpr int ITEMS = (HPIECES * 64 + 511) / 512;            // PRO: 16-byte halo items per thread and slab: 4 / 6
+};
+// halo pieces a halo wave issues at tap t when its NPH pieces are spread over taps 0..LAST
+constexpr int ch_count(int NPH, int LAST, int t) { return t > LAST ? 0 : (NPH + LAST - t) / (LAST + 1); }
+constexpr int ch_start(int NPH, int LAST, int t) { int s = 0; for (int u = 0; u < t; ++u) s += ch_count(NPH, LAST, u); return s; }
 
 // weights of one k-step: rows = output channels, 64 k of (tap, slab); the KC image of the g2 kernel, staged by waves 0-5
 template <int BN_>
@@ -55,37 +71,38 @@ struct HaloWeights {
       rp[i] = Wt + (long)(n0 + (ok[i] ? row : 0)) * ld + chunk * 8;
     }
   }
-  // sources of the next k-step; `adv` = element advance to the one after it (next tap: Cin; next slab: 64 - 8 * Cin)
-  __device__ __forceinline__ void next_sources(bool live, long adv, const bf16_t* (&src)[NPW]) {
+  // stage the current k-step's pieces into `img` (dead k-steps and rows past Cout: the zero page), then move on by `adv` elements
+  // (next tap: Cin; next slab: 64 - 8 * Cin)
+  __device__ __forceinline__ void fire_next(bool live, long adv, char* img, int wave) {
     const bf16_t* zp = (const bf16_t*)nk_zero_page;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-      src[i] = (live && ok[i]) ? rp[i] : zp;
+      if (wave + CH_NBW * i < NPC)      // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((nk_gptr)((live && ok[i]) ? rp[i] : zp), (nk_lptr)(img + (wave + CH_NBW * i) * 1024), 16, 0, 0);
       rp[i] += adv;
     }
   }
-  __device__ __forceinline__ void fire(const bf16_t* const (&src)[NPW], char* img, int wave) const {
-#pragma unroll
-    for (int i = 0; i < NPW; ++i)
-      if (wave + CH_NBW * i < NPC)      // (wave-uniform)
-        __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave + CH_NBW * i) * 1024), 16, 0, 0);
-  }
 };
 
+__device__ __forceinline__ float ch_silu(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f)); }
+
+// MI: 16-pixel row blocks per wave (2: 4 x 32 tiles, 4: 8 x 32 tiles)
 // PRO: 0 = the input is read as it is; 1 = GroupNorm(+SiLU) of the input applied in LDS (p.gn_*)
 // STATS: 1 = per-tile GroupNorm partial sums of the output written to p.stats_part
-template <int BN_, int PRO, int STATS>
+template <int BN_, int MI, int PRO, int STATS>
 __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  using G = HaloGeom<MI>;
   constexpr int HN = BN_ / 2, NJ = HN / 16;          // columns per group; 16-column blocks per wave: 5 or 4
-  constexpr int NPWB = HaloWeights<BN_>::NPW;
+  constexpr int RPW = G::RPW, HPW = G::HPW, HBUF = G::HBUF;
+  constexpr int HLAST = PRO ? 3 : 6;                 // last tap at which halo pieces of the next slab are issued
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wq = wave & 3;
   const bool hwave = wave >= CH_NBW;
 
   const int H = p.ga.H, W = p.ga.W, Cin = p.ga.C, Cout = p.N;
-  const int txn = (W + CH_TW - 1) / CH_TW, tyn = (H + CH_TH - 1) / CH_TH;
+  const int txn = (W + CH_TW - 1) / CH_TW, tyn = (H + G::TH - 1) / G::TH;
   const int per_img = txn * tyn;
   const int ntm = p.halo_nb * per_img, ntn = (Cout + BN_ - 1) / BN_;
   // XCD-aware bijective remap; groups of 16 pixel tiles x all column tiles, column-major inside a group: the 32 workgroups an XCD
@@ -103,79 +120,113 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   const int mt = first_m + (in_group - nt * gm);
   const int n0 = nt * BN_;
   const int img = mt / per_img;
-  const int rem = mt - img * per_img;
-  const int tyi = rem / txn;
-  const int y0 = tyi * CH_TH, x0 = (rem - tyi * txn) * CH_TW;
+  const int trem = mt - img * per_img;               // tile index inside the image
+  const int tyi = trem / txn;
+  const int y0 = tyi * G::TH, x0 = (trem - tyi * txn) * CH_TW;
   const int nslab = Cin >> 6, nk = nslab * 9;
 
   typedef __attribute__((address_space(3))) const char* lds_c;
   const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
-  char* const ring = smem + 2 * CH_HBUF;
+  char* const ring = smem + 2 * HBUF;
+  float* const tab = (float*)(smem + 2 * HBUF + CH_NS * CH_BSTAGE);     // PRO: [2][64][2]
+
+  // ---- halo staging (waves 6, 7): piece i of a halo wave covers halo pixels hp0 + 8 i (one per 8 lanes), slot lane & 7 of each;
+  // the source of a lane's 16 bytes is recomputed per piece (a dozen scalar-ish VALU instructions) instead of kept in 13 / 22 registers ----
+  const int hp0 = (wave - CH_NBW) * HPW * 8 + (lane >> 3);
+  auto fire_halo = [&](int i, int slab, char* hbuf) {     // piece i of this halo wave, channel slab `slab`
+    const int hp = hp0 + 8 * i;
+    const int py = hp / CH_HW, px = hp - py * CH_HW;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    const bool v = hp < G::HPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;      // else padding: the zero page
+    const int chunk = (lane & 7) ^ (hp & 7);
+    const bf16_t* src = v ? p.A + ((long)((img * H + y) * W + x) * Cin + chunk * 8 + slab * 64) : (const bf16_t*)nk_zero_page;
+    __builtin_amdgcn_global_load_lds((nk_gptr)src, (nk_lptr)(hbuf + ((wave - CH_NBW) * HPW + i) * 1024), 16, 0, 0);
+  };
 
   // ---- weights ----
   HaloWeights<BN_> wb;
   wb.init(p.B, p.ldb, Cout, n0, wave, lane);
   const long adv_tap = Cin, adv_slab = 64 - 8l * Cin;
-  FragG2<OP_KC, BN_, NJ> fb;
-  fb.init(lds0 + 2 * CH_HBUF, grp * HN, lane);
 
-  // ---- halo: this lane's A-fragment addresses, one per tap (block 1 = +16 pixels = +2048 B; k sub-step 1 = slot ^ 4 = ^64 B) ----
-  unsigned atap[9];
-  {
-    const int c = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int hp = (wq + t / 3) * CH_HW + (lane & 15) + (t % 3);
-      atap[t] = (unsigned)(hp * 128 + ((c ^ (hp & 7)) << 4));
-    }
-  }
-  // ---- halo staging (waves 6, 7): element offsets of this lane's 16-byte chunk of each piece, relative to channel slab 0; < 0 = padding ----
-  int hofs[CH_HPW];
-#pragma unroll
-  for (int i = 0; i < CH_HPW; ++i) hofs[i] = -1;
+  // ---- prologue loads go out first: halo of slab 0, weights of k-steps 0 and 1 ----
   if (hwave) {
 #pragma unroll
-    for (int i = 0; i < CH_HPW; ++i) {
-      const int pc = (wave - CH_NBW) * CH_HPW + i;
-      const int hp = pc * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ (hp & 7);
-      const int py = hp / CH_HW, px = hp - py * CH_HW;
-      const int y = y0 - 1 + py, x = x0 - 1 + px;
-      const bool v = hp < CH_HPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-      hofs[i] = v ? (((img * H + y) * W + x) * Cin + chunk * 8) : -1;
-    }
+    for (int i = 0; i < HPW; ++i) fire_halo(i, 0, smem);
+  } else {
+    wb.fire_next(true, adv_tap, ring, wave);
+    wb.fire_next(nk > 1, adv_tap, ring + CH_BSTAGE, wave);
   }
-  auto fire_halo = [&](int i, int slab, char* hbuf) {     // piece i of this halo wave, channel slab `slab`
-    const bf16_t* src = hofs[i] >= 0 ? p.A + (long)hofs[i] + slab * 64 : (const bf16_t*)nk_zero_page;
-    __builtin_amdgcn_global_load_lds((nk_gptr)src, (nk_lptr)(hbuf + ((wave - CH_NBW) * CH_HPW + i) * 1024), 16, 0, 0);
-  };
 
-  float4_t acc[2][NJ];
+  FragG2<OP_KC, BN_, NJ> fb;
+  fb.init(lds0 + 2 * HBUF, grp * HN, lane);
+  // A-fragment address of this lane in a halo buffer: row block (r, c) of tap (dy, dx) reads pixel hp = hpl + (r + dy) * 34 + dx at
+  // hp * 128 + ((lane >> 4) ^ (hp & 7)) * 16 (+ c * 2048; k sub-step 1 = slot ^ 4 = ^64 B) -- five VALU instructions per tile row and tap
+  const int hpl = wq * RPW * CH_HW + (lane & 15);
+  const int cl4 = lane >> 4;
+  const int g4 = lane >> 4;
+  const int nb = n0 + grp * HN;
+  float4_t acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-  bf16x8_t af[4], bfr[2 * NJ];
+  bf16x8_t af[2 * MI], bfr[2 * NJ];
 
 #define CH_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
   const int nbw = HaloWeights<BN_>::pieces(wave);         // weight pieces this wave stages per k-step (0 for the halo waves)
 
-  // ---- prologue: halo of slab 0, weights of k-steps 0 and 1 in flight; halo 0 and weights 0 landed for everyone ----
-  const bf16_t* sb[NPWB];
-  if (hwave) {
+  // PRO: the in-place GroupNorm(+SiLU) of a halo buffer.  Item it of thread tid = 16 bytes at byte (it * 512 + tid) * 16 of the buffer:
+  // pixel hp = idx >> 3, slot idx & 7 holds channel chunk slot ^ (hp & 7).  Padding pixels (outside the image) are left zero.
+  auto make_table = [&](int slab, float* tb) {             // 64 threads: a_c = rstd * gamma, b_c = beta - mean * a_c for the slab's channels
+    if (tid < 64) {
+      const int c = slab * 64 + tid;
+      const int cpg = Cin / p.gn_groups;
+      const int g = c / cpg;
+      const float inv_cnt = 1.0f / ((float)H * (float)W * (float)cpg);
+      const float m = p.gn_sums[((long)img * p.gn_groups + g) * 2] * inv_cnt;
+      const float var = fmaxf(p.gn_sums[((long)img * p.gn_groups + g) * 2 + 1] * inv_cnt - m * m, 0.f);
+      const float a = rsqrtf(var + p.gn_eps) * p.gn_gamma[c];
+      tb[2 * tid] = a;
+      tb[2 * tid + 1] = p.gn_beta[c] - m * a;
+    }
+  };
+  auto transform_item = [&](int it, char* hbuf, const float* tb) {
+    const int idx = it * 512 + tid;
+    if (idx >= G::HPIECES * 64) return;
+    const int hp = idx >> 3;
+    const int py = hp / CH_HW, px = hp - py * CH_HW;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    if (!(hp < G::HPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)) return;     // padding stays zero
+    const int chunk = (idx & 7) ^ (hp & 7);
+    uint4_t* slot = (uint4_t*)(hbuf + idx * 16);
+    float f[8];
+    unpack8(*slot, f);
+    const float4_t ab0 = *(const float4_t*)(tb + chunk * 16), ab1 = *(const float4_t*)(tb + chunk * 16 + 4);
+    const float4_t ab2 = *(const float4_t*)(tb + chunk * 16 + 8), ab3 = *(const float4_t*)(tb + chunk * 16 + 12);
+    f[0] = f[0] * ab0[0] + ab0[1]; f[1] = f[1] * ab0[2] + ab0[3]; f[2] = f[2] * ab1[0] + ab1[1]; f[3] = f[3] * ab1[2] + ab1[3];
+    f[4] = f[4] * ab2[0] + ab2[1]; f[5] = f[5] * ab2[2] + ab2[3]; f[6] = f[6] * ab3[0] + ab3[1]; f[7] = f[7] * ab3[2] + ab3[3];
+    if (p.gn_silu) {
 #pragma unroll
-    for (int i = 0; i < CH_HPW; ++i) fire_halo(i, 0, smem);
+      for (int e = 0; e < 8; ++e) f[e] = ch_silu(f[e]);
+    }
+    *slot = pack8(f);
+  };
+
+  // ---- prologue waits: halo 0 and weights 0 landed for everyone (weights 1 stay in flight) ----
+  if (hwave) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-    wb.next_sources(true, adv_tap, sb);
-    wb.fire(sb, ring, wave);
-    wb.next_sources(nk > 1, adv_tap, sb);
-    wb.fire(sb, ring + CH_BSTAGE, wave);
-    wb.next_sources(nk > 2, nk > 2 ? adv_tap : 0, sb);    // sources of k-step 2, fired in the first M phase
-    // leave k-step 1 in flight
     if (nbw == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (nbw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  }
+  if constexpr (PRO) {
+    make_table(0, tab);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CH_BAR();                                              // halo 0 (raw) and its table are visible
+#pragma unroll
+    for (int it = 0; it < G::ITEMS; ++it) transform_item(it, smem, tab);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   CH_BAR();
   if (grp == 1) { CH_BAR(); }                              // the second group runs one barrier behind
@@ -183,29 +234,54 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   unsigned so = 0, sn = 2 * CH_BSTAGE;                     // ring stage of k-step t / of k-step t + 2
   int t = 0;
   for (int s = 0; s < nslab; ++s) {
-    const unsigned hcur = lds0 + (unsigned)(s & 1) * CH_HBUF;
-    char* const hnext = smem + ((s + 1) & 1) * CH_HBUF;
+    const unsigned hcur = lds0 + (unsigned)(s & 1) * HBUF;
+    char* const hnext = smem + ((s + 1) & 1) * HBUF;
+    float* const tnext = tab + ((s + 1) & 1) * 128;
     const bool more = s + 1 < nslab;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap, ++t) {
+    auto step = [&](auto tapc) {
+      constexpr int tap = decltype(tapc)::value;
+      constexpr int dy = tap / 3, dx = tap % 3;
       // ---- R: fragment reads of k-step t; halo pieces of slab s + 1; wait for the weights of k-step t + 1 ----
       __builtin_amdgcn_sched_barrier(0);
       g2_read<OP_KC, BN_, NJ>(bfr, fb, so);
-      {
-        const unsigned a0 = hcur + atap[tap], a1 = hcur + (atap[tap] ^ 64u);
-        G2_RD128(af[0], a0, 0);
-        G2_RD128(af[1], a0, 2048);
-        G2_RD128(af[2], a1, 0);
-        G2_RD128(af[3], a1, 2048);
+      int hpv = hpl;
+      asm volatile("" : "+v"(hpv));          // (opaque: keeps the 9 x RPW tap addresses from being hoisted out of the slab loop into 18-36 registers)
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int hp = hpv + (r + dy) * CH_HW + dx;
+        const unsigned ar = (unsigned)(hp * 128 + ((cl4 ^ (hp & 7)) << 4));
+        const unsigned a0 = hcur + ar, a1 = hcur + (ar ^ 64u);
+        G2_RD128(af[2 * r], a0, 0);
+        G2_RD128(af[2 * r + 1], a0, 2048);
+        G2_RD128(af[MI + 2 * r], a1, 0);
+        G2_RD128(af[MI + 2 * r + 1], a1, 2048);
       }
       if (hwave) {
         if (more) {
-          if (tap < 6) { fire_halo(2 * tap, s + 1, hnext); fire_halo(2 * tap + 1, s + 1, hnext); }
-          else if (tap == 6) fire_halo(12, s + 1, hnext);
+          constexpr int cnt = ch_count(HPW, HLAST, tap), st = ch_start(HPW, HLAST, tap);
+#pragma unroll
+          for (int i = 0; i < cnt; ++i) fire_halo(st + i, s + 1, hnext);
         }
-        if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next slab's halo has landed (this wave's share)
+        // the next slab's halo has landed (this wave's share): before the barrier that precedes its first use
+        if (tap == (PRO ? 4 : 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the weights of k-step t + 1 have landed (this wave's share)
+      }
+      if constexpr (PRO) {
+        // taps 5-8, read phase: every wave normalises its share of the next slab's halo in place.  The raw halo landed before the
+        // barrier of tap 4; the last writes retire (lgkmcnt below) before this phase's barrier, hence before slab s + 1 is read.
+        if (more) {
+          if constexpr (tap == 4) make_table(s + 1, tnext);
+          if constexpr (tap >= 5) {
+            constexpr int per = (G::ITEMS + 3) / 4;                       // items per tap: 1 (4 x 32 tiles) or 2 (8 x 32: 2, 2, 1, 1)
+#pragma unroll
+            for (int u = 0; u < per; ++u) {
+              const int it = (tap - 5) * per + u;
+              if (it < G::ITEMS) transform_item(it, hnext, tnext);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+        }
       }
       CH_BAR();
       // ---- M: the wave's MFMAs; weights of k-step t + 2 staged and the sources after them computed in their shadow ----
@@ -213,75 +289,264 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       if (!hwave) {
-        wb.fire(sb, ring + sn, wave);
-        // k-step t + 3: the one after t + 2 is the next tap unless t + 2 is a slab's last tap
-        // sources of k-step t + 3 (fired in the next M phase); the pointer then moves on to k-step t + 4: the next tap, unless
-        // t + 3 is a slab's last tap
-        const int tap3 = (tap + 3) % 9;
-        wb.next_sources(t + 3 < nk, tap3 == 8 ? adv_slab : adv_tap, sb);
+        // weights of k-step t + 2; the pointer then moves on to k-step t + 3: the next tap, unless t + 2 is a slab's last tap
+        constexpr int tap2 = (tap + 2) % 9;
+        wb.fire_next(t + 2 < nk, tap2 == 8 ? adv_slab : adv_tap, ring + sn, wave);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)     // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks * NJ + j], af[ks * 2 + i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks * NJ + j], af[ks * MI + i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       CH_BAR();
       so += CH_BSTAGE; if (so == CH_NS * CH_BSTAGE) so = 0;
       sn += CH_BSTAGE; if (sn == CH_NS * CH_BSTAGE) sn = 0;
-    }
+      ++t;
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
   }
   if (grp == 0) { CH_BAR(); }                              // ... and the first group waits for it here
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the past-the-end zero-page pieces must land before the LDS is given up
-#undef CH_BAR
 
-  // ---- epilogue: the wave's 32 pixels are 32 consecutive rows of the output matrix ----
-  const int y = y0 + wq;
-  const int mb = (img * H + y) * W + x0;
-  const int mlimit = y < H ? mb + min(CH_TW, W - x0) : 0;
-  const int nb = n0 + grp * HN;
+  // ---- epilogue ----
+  // row block i = (tile row wq * RPW + (i >> 1), pixel columns (i & 1) * 16 + (lane & 15)); acc[i][j][r] = its column grp*HN + j*16 + g4*4 + r
+  int mrow[MI];
+  bool mok[MI];
 #pragma unroll
-  for (int half = 0; half < NJ / 2; ++half) {
-    float4_t pair[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { pair[i][0] = acc[i][2 * half]; pair[i][1] = acc[i][2 * half + 1]; }
-    reg_epilogue_64x32<0, 2>(p, p.C, pair, mb, nb + half * 32, lane, mlimit);
+  for (int i = 0; i < MI; ++i) {
+    const int y = y0 + wq * RPW + (i >> 1), x = x0 + (i & 1) * 16 + (lane & 15);
+    mok[i] = y < H && x < W;
+    mrow[i] = (img * H + y) * W + x;
   }
+  bf16_t* const C = (bf16_t*)p.C;
+  // the residual of every row block in one batch of loads
+  uint4_t res8[MI][NJ / 2 ? NJ / 2 : 1];
+  uint2_t res4[MI];
+  if (p.residual) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int h = 0; h < NJ / 2; ++h) {
+        const int n = nb + h * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;
+        res8[i][h] = (mok[i] && n < Cout) ? *(const uint4_t*)(p.residual + (long)mrow[i] * p.ldr + n) : (uint4_t){0u, 0u, 0u, 0u};
+      }
+      if constexpr (NJ & 1) {
+        const int n = nb + (NJ - 1) * 16 + g4 * 4;
+        res4[i] = (mok[i] && n < Cout) ? *(const uint2_t*)(p.residual + (long)mrow[i] * p.ldr + n) : (uint2_t){0u, 0u};
+      }
+    }
+  }
+  // addends: bias + the image's row vector for this lane's columns (8 per column pair, 4 for a lone block), in the same batch of loads
+  // after the permlane swap a lane holds columns n8(h) .. n8(h)+7 of column pair h, and g*4 .. +3 of the lone fifth block
+  float cadd[NJ / 2][8], cadd4[4];
+#pragma unroll
+  for (int h = 0; h < NJ / 2; ++h) {
+    const int n = nb + h * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cadd[h][e] = 0.f;
+    if (n < Cout) {
+      if (p.bias) {
+        const float4_t b0 = *(const float4_t*)(p.bias + n), b1 = *(const float4_t*)(p.bias + n + 4);
+        cadd[h][0] = b0[0]; cadd[h][1] = b0[1]; cadd[h][2] = b0[2]; cadd[h][3] = b0[3];
+        cadd[h][4] = b1[0]; cadd[h][5] = b1[1]; cadd[h][6] = b1[2]; cadd[h][7] = b1[3];
+      }
+      if (p.rowvec) {
+        float t[8];
+        unpack8(*(const uint4_t*)(p.rowvec + (long)img * p.ld_rowvec + n), t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cadd[h][e] += t[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) cadd4[e] = 0.f;
   if constexpr (NJ & 1) {
-    float4_t last[2] = {acc[0][NJ - 1], acc[1][NJ - 1]};
-    reg_epilogue_col16<0, 2>(p, p.C, last, mb, nb + (NJ - 1) * 16, lane, mlimit);
+    const int n = nb + (NJ - 1) * 16 + g4 * 4;
+    if (n < Cout) {
+      if (p.bias) { const float4_t b = *(const float4_t*)(p.bias + n); cadd4[0] = b[0]; cadd4[1] = b[1]; cadd4[2] = b[2]; cadd4[3] = b[3]; }
+      if (p.rowvec) {
+        float t[4];
+        unpack4(*(const uint2_t*)(p.rowvec + (long)img * p.ld_rowvec + n), t);
+        cadd4[0] += t[0]; cadd4[1] += t[1]; cadd4[2] += t[2]; cadd4[3] += t[3];
+      }
+    }
   }
+
+  // per-lane column sums for the statistics epilogue: [column slot][sum, sum of squares]
+  float st8[NJ / 2 ? NJ / 2 : 1][8][2], st4[4][2];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int h = 0; h < NJ / 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { st8[h][e][0] = 0.f; st8[h][e][1] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { st4[e][0] = 0.f; st4[e][1] = 0.f; }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int h = 0; h < NJ / 2; ++h) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // every lane takes part in the swap; the bounds predicates come after it
+        const float a_own = acc[i][2 * h][r], b_own = acc[i][2 * h + 1][r];
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a_own), __float_as_uint(b_own), false, false);
+        v[r] = __uint_as_float(sw[0]);
+        v[4 + r] = __uint_as_float(sw[1]);
+      }
+      const int n = nb + h * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += cadd[h][e];
+      if (p.residual) {
+        float tr[8];
+        unpack8(res8[i][h], tr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += tr[e];
+      }
+      const uint4_t packed = pack8(v);
+      const bool ok = mok[i] && n < Cout;
+      if (ok) *(uint4_t*)(C + (long)mrow[i] * p.ldc + n) = packed;
+      if constexpr (STATS) {
+        float q[8];
+        unpack8(packed, q);                   // statistics of what the consumer will read: the bf16-rounded values
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float x = ok ? q[e] : 0.f; st8[h][e][0] += x; st8[h][e][1] += x * x; }
+      }
+    }
+    if constexpr (NJ & 1) {
+      const int n = nb + (NJ - 1) * 16 + g4 * 4;
+      float v[4] = {acc[i][NJ - 1][0] + cadd4[0], acc[i][NJ - 1][1] + cadd4[1], acc[i][NJ - 1][2] + cadd4[2], acc[i][NJ - 1][3] + cadd4[3]};
+      if (p.residual) {
+        float tr[4];
+        unpack4(res4[i], tr);
+        v[0] += tr[0]; v[1] += tr[1]; v[2] += tr[2]; v[3] += tr[3];
+      }
+      uint2_t o;
+      o.x = pack2bf(v[0], v[1]);
+      o.y = pack2bf(v[2], v[3]);
+      const bool ok = mok[i] && n < Cout;
+      if (ok) *(uint2_t*)(C + (long)mrow[i] * p.ldc + n) = o;
+      if constexpr (STATS) {
+        float q[4];
+        unpack4(o, q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float x = ok ? q[e] : 0.f; st4[e][0] += x; st4[e][1] += x * x; }
+      }
+    }
+  }
+  if constexpr (STATS) {
+    // column sums over the tile, in a fixed order: 16 lanes of a column slot (xor butterfly) -> the 4 pixel-row waves of a column group
+    // (LDS) -> the columns of a GroupNorm group -> part[img][tile][2 * group + {0, 1}].  The ring is free: every wave is past the loop.
+    __syncthreads();
+    float* const cs = (float*)ring;            // [8 waves][HN columns][2]
+    auto lane16_sum = [](float x) {
+      x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+      return x;
+    };
+#pragma unroll
+    for (int h = 0; h < NJ / 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float tot = lane16_sum(st8[h][e][k]);
+          const int col = h * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8 + e;          // column inside the group's HN
+          if ((lane & 15) == 0) cs[(wave * HN + col) * 2 + k] = tot;
+        }
+    if constexpr (NJ & 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float tot = lane16_sum(st4[e][k]);
+          const int col = (NJ - 1) * 16 + g4 * 4 + e;
+          if ((lane & 15) == 0) cs[(wave * HN + col) * 2 + k] = tot;
+        }
+    }
+    __syncthreads();
+    const int cpg = Cout / p.stats_groups;      // channels per GroupNorm group; BN_ % cpg == 0 (use_halo)
+    const int ngt = BN_ / cpg;                  // groups this column tile covers
+    if (tid < 2 * ngt) {
+      const int gi = tid >> 1, k = tid & 1;
+      float a = 0.f;
+      for (int cc = 0; cc < cpg; ++cc) {
+        const int col = gi * cpg + cc;          // column of the tile: group half col / HN, its 4 pixel-row waves
+        const int gh = col / HN, cl = col - gh * HN;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) a += cs[((gh * 4 + w4) * HN + cl) * 2 + k];
+      }
+      p.stats_part[((long)img * per_img + trem) * 2 * p.stats_groups + 2 * (n0 / cpg + gi) + k] = a;
+    }
+  }
+#undef CH_BAR
 }
 
 // NK_CONV_HALO=0 keeps every convolution on the gather kernels (A/B runs)
-static bool use_halo(const NkGemmParams& p, int amode, int bmode, int out_f32) {
-  if (amode != OP_KCG || bmode != OP_KC || out_f32 || p.nbatch) return false;
-  if (const char* e = getenv("NK_CONV_HALO")) if (e[0] == '0') return false;
+static bool halo_shape_ok(const NkGemmParams& p) {
   const NkGather& g = p.ga;
   if (!p.halo_nb || g.KW != 3 || p.K != 9 * g.C || g.rs != 1 || g.ks != 1 || g.div != 1 || g.off_h != -1 || g.off_w != -1) return false;
-  if (g.Ho != g.H || g.Wo != g.W || (g.C & 63) || p.alpha != 1.0f) return false;
+  if (g.Ho != g.H || g.Wo != g.W || (g.C & 63) || p.alpha != 1.0f || p.nbatch) return false;
   if (p.N % 160 && p.N % 128) return false;
   if ((p.N & 7) || (p.ldc & 7) || (p.residual && (p.ldr & 7))) return false;
-  // whole tiles only where it pays: patches of 4 x 32 pixels must cover the image with little waste
-  const long cover = (long)((g.W + CH_TW - 1) / CH_TW) * CH_TW * ((g.H + CH_TH - 1) / CH_TH) * CH_TH;
-  return cover * 100 <= (long)g.H * g.W * 115;
+  return true;
+}
+// tile height for this problem: 8-row tiles where they still give about one workgroup per CU, else 4-row tiles; 0 = the patches
+// would cover the image with too much waste (ragged small images keep the gather kernels)
+static int halo_tile_rows(const NkGemmParams& p) {
+  const NkGather& g = p.ga;
+  const int bn = p.N % 160 == 0 ? 160 : 128;
+  const long txn = (g.W + CH_TW - 1) / CH_TW;
+  for (int th = 8; th >= 4; th -= 4) {
+    const long tyn = (g.H + th - 1) / th;
+    const long cover = txn * CH_TW * tyn * th;
+    if (cover * 100 > (long)g.H * g.W * 115) continue;
+    const long tiles = (long)p.halo_nb * txn * tyn * (p.N / bn);
+    if (th == 8 && tiles < 224) continue;
+    return th;
+  }
+  return 0;
+}
+static bool use_halo(const NkGemmParams& p, int amode, int bmode, int out_f32) {
+  if (amode != OP_KCG || bmode != OP_KC || out_f32) return false;
+  if (const char* e = getenv("NK_CONV_HALO")) if (e[0] == '0') return false;
+  return halo_shape_ok(p) && halo_tile_rows(p) != 0;
 }
 
-template <int BN_>
+template <int BN_, int MI, int PRO, int STATS>
 static int launch_halo_as(const NkGemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = nk_conv3x3_halo_kernel<BN_, 0, 0>;
+  auto kern = nk_conv3x3_halo_kernel<BN_, MI, PRO, STATS>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<MI>::SMEM);
     attr_set = true;
   }
   const NkGather& g = p.ga;
-  const long tiles = (long)p.halo_nb * ((g.W + CH_TW - 1) / CH_TW) * ((g.H + CH_TH - 1) / CH_TH) * (p.N / BN_);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), CH_SMEM_BYTES, stream, p);
+  const long tiles = (long)p.halo_nb * ((g.W + CH_TW - 1) / CH_TW) * ((g.H + HaloGeom<MI>::TH - 1) / HaloGeom<MI>::TH) * (p.N / BN_);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), HaloGeom<MI>::SMEM, stream, p);
   return nk_check_launch("nk_conv3x3_halo_kernel");
 }
+template <int PRO, int STATS>
+static int launch_halo_ps(const NkGemmParams& p, hipStream_t stream) {
+  int th = halo_tile_rows(p);
+  if (const char* e = getenv("NK_CONV_HALO_TH")) th = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : th);      // A/B runs
+  const bool wide = p.N % 160 == 0;
+  if (th == 8) return wide ? launch_halo_as<160, 4, PRO, STATS>(p, stream) : launch_halo_as<128, 4, PRO, STATS>(p, stream);
+  return wide ? launch_halo_as<160, 2, PRO, STATS>(p, stream) : launch_halo_as<128, 2, PRO, STATS>(p, stream);
+}
 static int launch_halo(const NkGemmParams& p, hipStream_t stream) {
-  return p.N % 160 == 0 ? launch_halo_as<160>(p, stream) : launch_halo_as<128>(p, stream);
+  const bool pro = p.gn_sums != nullptr, stats = p.stats_part != nullptr;
+  if (pro) return stats ? launch_halo_ps<1, 1>(p, stream) : launch_halo_ps<1, 0>(p, stream);
+  return stats ? launch_halo_ps<0, 1>(p, stream) : launch_halo_ps<0, 0>(p, stream);
+}
+// pixel tiles per image of the launch `launch_halo` would make (the statistics epilogue writes one partial row per tile)
+static int halo_tiles_per_image(const NkGemmParams& p) {
+  int th = halo_tile_rows(p);
+  if (const char* e = getenv("NK_CONV_HALO_TH")) th = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : th);
+  if (!th) return 0;
+  return ((p.ga.W + CH_TW - 1) / CH_TW) * ((p.ga.H + th - 1) / th);
 }

@@ -246,6 +246,44 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, DstT* __rest
     }
   }
 }
+// ------------------------------------------------------------------------------------------------
+// conv weight [Cout][KH*KW][Cin] -> [Cin][KH*KW flipped][Cout]: the weights of the convolution that IS the input gradient of a
+// stride-1 "same" convolution (dx = conv(dy, wt), taps mirrored, channel roles swapped).  With them the 3 x 3 input gradients run on
+// the forward halo-tile kernel (conv_halo.h) instead of the transposed-operand gather.  One 64 x 64 (co, ci) tile of one tap per
+// block, transposed through LDS; 16-byte loads along ci, 16-byte stores along co.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_weight_flip_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int Cout, int Cin, int taps) {
+  __shared__ bf16_t tile[64][64 + 8];          // [ci][co], rows padded by 16 B
+  const int tap = blockIdx.z, co0 = blockIdx.y * 64, ci0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + 256 * it;            // 64 rows (co) x 8 chunks (ci)
+    const int r = idx >> 3, ch = idx & 7;
+    uint4_t v = {0u, 0u, 0u, 0u};
+    if (co0 + r < Cout && ci0 + ch * 8 < Cin) v = *(const uint4_t*)(w + ((long)(co0 + r) * taps + tap) * Cin + ci0 + ch * 8);
+    const bf16_t* e = (const bf16_t*)&v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[ch * 8 + k][r] = e[k];
+  }
+  __syncthreads();
+  const int tflip = taps - 1 - tap;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + 256 * it;            // 64 rows (ci) x 8 chunks (co)
+    const int r = idx >> 3, ch = idx & 7;
+    if (ci0 + r < Cin && co0 + ch * 8 < Cout)
+      *(uint4_t*)(wt + ((long)(ci0 + r) * taps + tflip) * Cout + co0 + ch * 8) = *(const uint4_t*)&tile[r][ch * 8];
+  }
+}
+extern "C" int nk_conv_weight_flip(const void* w, void* wt, int Cout, int Cin, int taps, void* stream) {
+  NK_CHECK_ARG(w && wt && Cout > 0 && Cin > 0 && taps > 0 && taps <= 65535);
+  NK_CHECK_ARG((Cout & 7) == 0 && (Cin & 7) == 0);
+  hipLaunchKernelGGL(conv_weight_flip_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64, taps), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)wt,
+                     Cout, Cin, taps);
+  return nk_check_launch("conv_weight_flip_kernel");
+}
+
 extern "C" int nk_nchw_to_nhwc(const void* src, int src_is_f32, void* dst, int N, int C, int HW, int Cpad, float scale,
                                void* stream) {
   NK_CHECK_ARG(src && dst && N > 0 && C > 0 && HW > 0 && Cpad >= C);

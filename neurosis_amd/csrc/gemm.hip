@@ -2087,6 +2087,10 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
 
   // 3 x 3 / stride 1 / padding 1 convolutions over whole 64-channel slabs: the halo-tile kernel (conv_halo.h)
   if (!use_v1() && use_halo(p, amode, bmode, out_f32)) return launch_halo(p, stream);
+  if (p.gn_sums || p.stats_part) {      // the fused GroupNorm prologue / statistics epilogue exist in the halo-tile kernel only
+    nk_set_error(__FILE__, __LINE__, "fused GroupNorm options on a convolution the halo-tile kernel does not take (ask nk_conv2d_fused_tiles first)");
+    return NK_ERR_ARG;
+  }
 
   // two-group staggered ring at one workgroup per CU (gemm_g2.h): Linear forward / dgrad / wgrad shapes whose 128 x 160 (or
   // 128 x 128) tiles come out in whole rounds of 256
@@ -2156,3 +2160,11 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   nk_set_error(__FILE__, __LINE__, "unsupported operand mode combination");
   return NK_ERR_ARG;
 }
+
+// pixel tiles per image of the halo-tile launch this convolution would get (= rows per image of the statistics epilogue's partials);
+// 0 when it is not eligible (shape, NK_CONV_HALO=0)
+int nk_halo_tiles_per_image(const NkGemmParams& p) {
+  if (!use_halo(p, OP_KCG, OP_KC, 0)) return 0;
+  return halo_tiles_per_image(p);
+}
+

@@ -381,6 +381,70 @@ extern "C" int nk_groupnorm_fwd(const void* x, const float* gamma, const float* 
   return nk_check_launch("gn_apply_kernel");
 }
 
+// ---- GroupNorm in separable passes: the sums, and the normalisation given the sums.  A convolution's statistics epilogue
+// (conv_halo.h) produces the sums' per-tile partials itself, and its GroupNorm prologue consumes the sums: the passes below are
+// what remains for tensors that come from elsewhere.  sums[n][2g] = sum, sums[n][2g+1] = sum of squares over H*W*(C/G) elements. ----
+__global__ __launch_bounds__(256) void gn_reduce_partials_l1_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int G2, int nchunks) {
+  // level 1 of a two-level fixed-order sum for many partial rows: block (chunk, n) sums rows chunk, chunk + nchunks, ... of image n
+  __shared__ float sm[4][64];
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  float a = 0.f;
+  if (tx < G2)
+    for (int p = chunk + ty * nchunks; p < nparts; p += 4 * nchunks) a += part[((long)n * nparts + p) * G2 + tx];
+  sm[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && tx < G2) out[((long)n * nchunks + chunk) * G2 + tx] = (a + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
+}
+
+extern "C" long nk_groupnorm_sums_ws_floats(int N, int nparts, int G) {
+  (void)nparts;
+  return (long)N * 64 * 2 * G + 64;
+}
+extern "C" int nk_groupnorm_sums_from_parts(const float* part, float* sums, float* ws, int N, int nparts, int G, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(part && sums && N > 0 && nparts > 0 && G > 0 && G <= 32);
+  if (nparts > 128) {
+    NK_CHECK_ARG(ws != nullptr);
+    const int nchunks = 64;
+    hipLaunchKernelGGL(gn_reduce_partials_l1_kernel, dim3(nchunks, N), dim3(256), 0, stream, part, ws, nparts, 2 * G, nchunks);
+    if (int e = nk_check_launch("gn_reduce_partials_l1_kernel")) return e;
+    part = ws;
+    nparts = nchunks;
+  }
+  hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(1024), 0, stream, part, sums, nparts, 2 * G);
+  return nk_check_launch("gn_reduce_partials_kernel");
+}
+
+extern "C" int nk_groupnorm_sums(const void* x, float* sums, float* ws, int N, int HW, int C, int G, void* stream_) {
+  // the statistics pass of nk_groupnorm_fwd alone; ws: nk_groupnorm_ws_floats(N, HW, C, G) floats
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(N > 0 && HW > 0 && C > 0 && G > 0 && G <= 64);
+  NK_CHECK_ARG((C & 7) == 0 && C % G == 0 && C <= GN_MAXC);
+  NK_CHECK_ARG(x && sums && ws);
+  int nsplit;
+  int rows_per = gn_rows_per(N, HW, &nsplit);
+  const int nz = gn_nz(C);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, N, nz), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, ws, HW, C, G, rows_per);
+  if (int e = nk_check_launch("gn_stats_kernel")) return e;
+  hipLaunchKernelGGL(gn_reduce_partials_kernel, dim3(N), dim3(1024), 0, stream, ws, sums, nsplit * nz, 2 * G);
+  return nk_check_launch("gn_reduce_partials_kernel");
+}
+
+extern "C" int nk_groupnorm_apply(const void* x, const float* sums, const float* gamma, const float* beta, void* y, float* mean,
+                                  float* rstd, int N, int HW, int C, int G, float eps, int silu, void* stream_) {
+  // the normalisation pass of nk_groupnorm_fwd given the sums (from nk_groupnorm_sums or a convolution's statistics epilogue)
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(N > 0 && HW > 0 && C > 0 && G > 0 && G <= 64);
+  NK_CHECK_ARG((C & 7) == 0 && C % G == 0 && C <= GN_MAXC);
+  NK_CHECK_ARG(x && sums && gamma && beta && y && mean && rstd);
+  int nsplit;
+  int rows_per = gn_rows_per(N, HW, &nsplit);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nsplit, N), dim3(GN_THREADS), 2 * C * sizeof(float), stream, (const bf16_t*)x, sums, gamma, beta,
+                     (bf16_t*)y, mean, rstd, HW, C, G, eps, silu, rows_per);
+  return nk_check_launch("gn_apply_kernel");
+}
+
 extern "C" int nk_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                                 const float* mean, const float* rstd, const void* dx_add, void* dx, float* dgamma,
                                 float* dbeta, float* ws, int N, int HW, int C, int G, int silu, int accumulate, void* stream_) {

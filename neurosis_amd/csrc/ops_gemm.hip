@@ -122,9 +122,8 @@ static NkGather fwd_gather(const NkConvDesc* d) {
   return g;
 }
 
-extern "C" int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, const float* bias,
-                             const void* rowvec, const void* residual, void* y, void* stream) {
-  if (int e = check_conv(d)) return e;
+static NkGemmParams conv_fwd_params(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
+                                    const void* residual, void* y) {
   NkGemmParams p = zero_params();
   p.A = (const bf16_t*)x;
   p.ga = fwd_gather(d);
@@ -136,6 +135,45 @@ extern "C" int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, 
   p.fRowsPerBatch = make_fastdiv(d->Ho * d->Wo);
   p.residual = (const bf16_t*)residual; p.ldr = d->Cout;
   p.halo_nb = (d->KH == 3 && d->KW == 3) ? d->N : 0;       // 3 x 3 / stride 1 / padding 1 shapes may take the halo-tile kernel
+  return p;
+}
+
+extern "C" int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, const float* bias,
+                             const void* rowvec, const void* residual, void* y, void* stream) {
+  if (int e = check_conv(d)) return e;
+  NkGemmParams p = conv_fwd_params(d, x, w, bias, rowvec, residual, y);
+  return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_KC, 0, 0, (hipStream_t)stream);
+}
+
+// Can this convolution run with a fused GroupNorm prologue over `gn_groups` groups of its INPUT (0: none) and / or a GroupNorm
+// statistics epilogue over `stats_groups` groups of its OUTPUT (0: none)?  Returns the number of pixel tiles per image of that launch
+// (the statistics partials have that many rows per image), or 0: run the unfused kernels.
+extern "C" long nk_conv2d_fused_tiles(const NkConvDesc* d, int gn_groups, int stats_groups) {
+  if (check_conv(d)) return 0;
+  if (gn_groups < 0 || stats_groups < 0 || gn_groups > 32 || stats_groups > 32) return 0;
+  if (gn_groups && d->Cin % gn_groups) return 0;
+  if (stats_groups) {
+    if (d->Cout % stats_groups) return 0;
+    const int bn = d->Cout % 160 == 0 ? 160 : 128, cpg = d->Cout / stats_groups;
+    if (bn % cpg) return 0;               // a column tile must hold whole groups
+  }
+  NkGemmParams p = conv_fwd_params(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return nk_halo_tiles_per_image(p);
+}
+
+extern "C" int nk_conv2d_fwd_fused(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
+                                   const void* residual, void* y, const float* gn_sums, const float* gn_gamma, const float* gn_beta,
+                                   float gn_eps, int gn_groups, int gn_silu, float* stats_part, int stats_groups, void* stream) {
+  // nk_conv2d_fwd with (a) the GroupNorm(+SiLU) of the input applied on the way into LDS -- gn_sums [N][gn_groups][2] = per (image,
+  // group) sum and sum of squares of x over H*W*(Cin/groups) elements, gamma / beta [Cin] -- and / or (b) the same sums of the OUTPUT
+  // emitted as per-tile partials stats_part [N][tiles][2*stats_groups] (nk_groupnorm_sums_from_parts adds them up).
+  if (int e = check_conv(d)) return e;
+  NK_CHECK_ARG(gn_sums || stats_part);
+  NK_CHECK_ARG(nk_conv2d_fused_tiles(d, gn_sums ? gn_groups : 0, stats_part ? stats_groups : 0) > 0);
+  NK_CHECK_ARG(!gn_sums || (gn_gamma && gn_beta && gn_groups > 0));
+  NkGemmParams p = conv_fwd_params(d, x, w, bias, rowvec, residual, y);
+  p.gn_sums = gn_sums; p.gn_gamma = gn_gamma; p.gn_beta = gn_beta; p.gn_eps = gn_eps; p.gn_groups = gn_groups; p.gn_silu = gn_silu;
+  p.stats_part = stats_part; p.stats_groups = stats_groups;
   return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_KC, 0, 0, (hipStream_t)stream);
 }
 
@@ -163,6 +201,29 @@ extern "C" int nk_conv2d_dgrad(const NkConvDesc* d, const void* dy, const void* 
   p.M = d->N * Hin * Win; p.N = d->Cin; p.K = d->KH * d->KW * d->Cout;
   p.C = dx; p.ldc = d->Cin;
   return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_MCT, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" long nk_conv2d_dgrad_flipped_ok(const NkConvDesc* d) {
+  // 1 when nk_conv2d_dgrad_flipped takes this convolution: 3 x 3 / stride 1 / padding 1 (also behind a fused 2x upsample: the gradient
+  // is then taken over the virtual 2x grid) whose transposed problem the halo-tile forward kernel runs
+  if (check_conv(d) || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1) return 0;
+  const int Hin = d->upsample ? 2 * d->H : d->H, Win = d->upsample ? 2 * d->W : d->W;
+  if (d->Ho != Hin || d->Wo != Win) return 0;
+  NkConvDesc t = *d;
+  t.H = Hin; t.W = Win; t.Cin = d->Cout; t.Cout = d->Cin; t.upsample = 0;
+  NkGemmParams p = conv_fwd_params(&t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return nk_halo_tiles_per_image(p) > 0;
+}
+
+extern "C" int nk_conv2d_dgrad_flipped(const NkConvDesc* d, const void* dy, const void* wt, void* dx, void* stream) {
+  // nk_conv2d_dgrad for stride-1 3 x 3 "same" convolutions as a FORWARD convolution of dy with wt = nk_conv_weight_flip(w)
+  // ([Cin][9 taps mirrored][Cout]): dx[n,y,x,ci] = sum_{tap,co} dy[n, y+dy'-1, x+dx'-1, co] * wt[ci][tap'][co] -- the halo-tile kernel.
+  NK_CHECK_ARG(nk_conv2d_dgrad_flipped_ok(d) == 1);
+  const int Hin = d->upsample ? 2 * d->H : d->H, Win = d->upsample ? 2 * d->W : d->W;
+  NkConvDesc t = *d;
+  t.H = Hin; t.W = Win; t.Cin = d->Cout; t.Cout = d->Cin; t.upsample = 0;
+  NkGemmParams p = conv_fwd_params(&t, dy, wt, nullptr, nullptr, nullptr, dx);
+  return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_KC, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, int accumulate,

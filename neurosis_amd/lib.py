@@ -40,13 +40,19 @@ SIGNATURES: dict[str, list] = {
     "nk_linear_fwd_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, vp],
     "nk_linear_wgrad_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, i32, vp],
     "nk_conv2d_fwd": [cdp, vp, vp, vp, vp, vp, vp, vp],
+    "nk_conv2d_fwd_fused": [cdp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp],
+    "nk_conv_weight_flip": [vp, vp, i32, i32, i32, vp],
     "nk_conv2d_dgrad": [cdp, vp, vp, vp, vp],
+    "nk_conv2d_dgrad_flipped": [cdp, vp, vp, vp, vp],
     "nk_conv2d_wgrad": [cdp, vp, vp, vp, i32, vp],
     "nk_attention_fwd": [adp, vp, vp, vp, vp, vp, vp],
     "nk_attention_bwd": [adp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nk_softmax_rows": [vp, i64, i32, vp],
     "nk_softmax_rows_bwd": [vp, vp, i64, i32, f32, vp],
     "nk_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "nk_groupnorm_sums": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "nk_groupnorm_sums_from_parts": [vp, vp, vp, i32, i32, i32, vp],
+    "nk_groupnorm_apply": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "nk_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "nk_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "nk_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
@@ -94,6 +100,9 @@ SIGNATURES: dict[str, list] = {
 # entry points that return a size (long) instead of a status
 SIZE_QUERIES: dict[str, list] = {
     "nk_groupnorm_ws_floats": [i32, i32, i32, i32],
+    "nk_groupnorm_sums_ws_floats": [i32, i32, i32],
+    "nk_conv2d_fused_tiles": [cdp, i32, i32],
+    "nk_conv2d_dgrad_flipped_ok": [cdp],
     "nk_layernorm_ws_floats": [i32, i32],
     "nk_colsum_ws_floats": [i64, i32],
     "nk_batchnorm_ws_floats": [i64, i32],

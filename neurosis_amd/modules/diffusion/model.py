@@ -94,8 +94,13 @@ class ResnetBlock(nn.Module):
             else:
                 self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
-    def fwd(self, x: Img) -> Img:
-        h = self.conv1.fwd(_gn(x, self.norm1, True), need_dx=False)[0]
+    def fwd(self, x: Img, want_sums: bool = False) -> Img:
+        """forward only (the frozen first stage).  Each convolution's epilogue emits the GroupNorm sums of its output (conv1 for norm2;
+        with `want_sums` conv2 for whichever GroupNorm reads the block's output), so the GroupNorms run their normalisation pass only.
+        (Applying the GroupNorm inside the consuming convolution -- conv2d_fwd(gn=...) -- is built and tested, but measured slower here:
+        the in-place SiLU lengthens the kernel's read phases by more than the separate pass costs, tools/bench_conv_halo.py.)"""
+        groups = self.norm1.num_groups
+        h = self.conv1.fwd(_gn(x, self.norm1, True), need_dx=False, stats_groups=self.norm2.num_groups)[0]
         h = _gn(h, self.norm2, True)
         if self.in_channels != self.out_channels:
             if self.use_conv_shortcut:
@@ -104,7 +109,7 @@ class ResnetBlock(nn.Module):
                 s = ops.gemm_nt(x.t, ops.w2d(self.nin_shortcut.weight), self.nin_shortcut.bias)
         else:
             s = x.t
-        return self.conv2.fwd(h, residual=s, need_dx=False)[0]
+        return self.conv2.fwd(h, residual=s, need_dx=False, stats_groups=groups if want_sums else None)[0]
 
     def fwdb(self, x: Img):
         """(y, bwd); bwd(dy tokens) -> dx tokens"""
@@ -237,17 +242,22 @@ class Encoder(nn.Module):
     def fwd(self, x: Img) -> Img:
         """encode + quant_conv on an Img whose channels are already padded to a multiple of 8."""
         h = self.conv_in.fwd(x, need_dx=False)[0]
+        last_level = self.num_resolutions - 1
         for i_level in range(self.num_resolutions):
+            level = self.down[i_level]
             for i_block in range(self.num_res_blocks):
-                h = self.down[i_level].block[i_block].fwd(h)
-                if len(self.down[i_level].attn) > 0:
-                    h = self.down[i_level].attn[i_block].fwd(h)
-            if i_level != self.num_resolutions - 1:
-                h = self.down[i_level].downsample.fwd(h)
-        h = self.mid.block_1.fwd(h)
+                # the block's output feeds a GroupNorm (the next block's norm1, an attention block's norm, mid.block_1.norm1) unless a
+                # Downsample comes next: ask its last convolution for that GroupNorm's sums
+                to_norm = i_block + 1 < self.num_res_blocks or len(level.attn) > 0 or i_level == last_level
+                h = level.block[i_block].fwd(h, want_sums=to_norm)
+                if len(level.attn) > 0:
+                    h = level.attn[i_block].fwd(h)
+            if i_level != last_level:
+                h = level.downsample.fwd(h)
+        h = self.mid.block_1.fwd(h, want_sums=True)
         if not isinstance(self.mid.attn_1, nn.Identity):
             h = self.mid.attn_1.fwd(h)
-        h = self.mid.block_2.fwd(h)
+        h = self.mid.block_2.fwd(h, want_sums=True)
         h = self.conv_out.fwd(_gn(h, self.norm_out, True), need_dx=False)[0]
         if self.standalone:
             h = self.quant_conv.fwd(h, need_dx=False)[0]

@@ -187,7 +187,7 @@ class ResBlock(TimestepBlock):
         h1, b_gn1 = ops.groupnorm_fwd(x, gn1.weight, gn1.bias, 32, gn1.eps, silu=True)
         es, b_es = ops.silu_fwd(emb)
         eo, b_eo = linear_module_fwd(self.emb_layers[1], es)
-        h2, b_c1 = self.in_layers[2].fwd(h1, rowvec=eo)
+        h2, b_c1 = self.in_layers[2].fwd(h1, rowvec=eo, stats_groups=32)      # the epilogue sums h2 for gn2: no statistics pass there
         h3, b_gn2 = ops.groupnorm_fwd(h2, gn2.weight, gn2.bias, 32, gn2.eps, silu=True)
         skip = self.skip_connection
         b_skip = None
@@ -198,7 +198,7 @@ class ResBlock(TimestepBlock):
         else:
             si, b_skip3 = skip.fwd(x)
             s, b_skip = si.t, (lambda g: b_skip3(g)[0].t)
-        out, b_c2 = self.out_layers[3].fwd(h3, residual=s)
+        out, b_c2 = self.out_layers[3].fwd(h3, residual=s, stats_groups=32)   # ... and the block's output for the GroupNorm that reads it next
 
         def bwd(dy: Tensor):
             dh3, _ = b_c2(dy)

@@ -258,6 +258,8 @@ class Img:
     N: int
     H: int
     W: int
+    sums: Optional[Tensor] = None    # GroupNorm sums of THIS tensor, [N, 2G] fp32 (entry 2g = sum, 2g+1 = sum of squares per group), when the
+    #                                  kernel that produced it emitted them (conv2d_fwd(stats_groups=G)): groupnorm_fwd then skips its statistics pass
 
     @property
     def C(self) -> int:
@@ -505,12 +507,25 @@ def _conv_desc(N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, upsampl
     return NkConvDesc(N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, int(upsample))
 
 
+def groupnorm_sums(x: Img, groups: int) -> Tensor:
+    """[N, 2*groups] fp32 sums / sums of squares of x per (image, group): x.sums when its producer emitted them, else one pass over x."""
+    if x.sums is not None and x.sums.shape == (x.N, 2 * groups):
+        return x.sums
+    sums = torch.empty(x.N, 2 * groups, dtype=torch.float32, device=x.t.device)
+    ws = _ws(query("nk_groupnorm_ws_floats", x.N, x.H * x.W, x.C, groups), x.t.device)
+    call("nk_groupnorm_sums", x.t.data_ptr(), sums.data_ptr(), ws.data_ptr(), x.N, x.H * x.W, x.C, groups, _stream())
+    return sums
+
+
 def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, padding=1, upsample: bool = False,
                rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None, need_dx: bool = True,
-               asym_pad: bool = False):
+               asym_pad: bool = False, gn=None, stats_groups: Optional[int] = None):
     """nn.Conv2d forward on channels-last data as implicit GEMM.
     padding: int (symmetric) ; asym_pad=True reproduces ConstantPad2d((0,1,0,1)) + padding 0 (model.py:71-79).
     rowvec: bf16 [N, Cout] added to every pixel of image n (ResBlock emb_out); residual: bf16 [N*Ho*Wo, Cout].
+    gn = (GroupNorm module, silu): the convolution reads silu?(GroupNorm(x)) -- fused into the kernel where the halo-tile kernel takes
+    the shape (the normalised tensor is never written), otherwise a GroupNorm launch in front.  Forward-only: bwd raises.
+    stats_groups = G: the output Img carries `.sums` (its GroupNorm sums over G groups) when the kernel can emit them.
     bwd(dy) -> (dx Img | None, d_rowvec | None)."""
     Cout, Cin, KH, KW = weight.shape
     if x.C != Cin:
@@ -529,10 +544,35 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
     _check2d(x.t, "x")
     if not x.t.is_contiguous():
         raise ValueError("conv2d: x must be dense channels-last")
-    call("nk_conv2d_fwd", C.byref(d), x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(), _stream())
-    out = Img(y, x.N, Ho, Wo)
+    gn_groups = gn[0].num_groups if gn is not None else 0
+    tiles = query("nk_conv2d_fused_tiles", C.byref(d), gn_groups, stats_groups or 0) if (gn is not None or stats_groups) else 0
+    if gn is not None and not tiles:
+        # the fused prologue is not available for this shape: the GroupNorm as its own launches, then try the epilogue alone
+        x = groupnorm_fwd(x, gn[0].weight, gn[0].bias, gn[0].num_groups, gn[0].eps, gn[1])[0]
+        gn, gn_groups = None, 0
+        tiles = query("nk_conv2d_fused_tiles", C.byref(d), 0, stats_groups) if stats_groups else 0
+    if gn is not None and stats_groups and not query("nk_conv2d_fused_tiles", C.byref(d), gn_groups, stats_groups):
+        stats_groups = None
+    sums_out = None
+    if tiles:
+        dev = x.t.device
+        part = torch.empty(x.N, tiles, 2 * stats_groups, dtype=torch.float32, device=dev) if stats_groups else None
+        gsum = groupnorm_sums(x, gn_groups) if gn is not None else None
+        call("nk_conv2d_fwd_fused", C.byref(d), x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
+             _p(gsum), _p(gn[0].weight if gn is not None else None), _p(gn[0].bias if gn is not None else None),
+             float(gn[0].eps) if gn is not None else 0.0, gn_groups, int(bool(gn[1])) if gn is not None else 0, _p(part), stats_groups or 0, _stream())
+        if stats_groups:
+            sums_out = torch.empty(x.N, 2 * stats_groups, dtype=torch.float32, device=dev)
+            ws = _ws(query("nk_groupnorm_sums_ws_floats", x.N, tiles, stats_groups), dev)
+            call("nk_groupnorm_sums_from_parts", part.data_ptr(), sums_out.data_ptr(), ws.data_ptr(), x.N, tiles, stats_groups, _stream())
+    else:
+        call("nk_conv2d_fwd", C.byref(d), x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(), _stream())
+    out = Img(y, x.N, Ho, Wo, sums_out)
+    fused_gn = gn is not None
 
     def bwd(dy: Tensor):
+        if fused_gn:
+            raise RuntimeError("conv2d_fwd(gn=...) fused the GroupNorm into the forward kernel and kept no normalised tensor: forward-only")
         _check2d(dy, "dy")
         if not dy.is_contiguous():
             raise ValueError("conv2d bwd: dy must be dense")
@@ -552,7 +592,15 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
         dx = None
         if need_dx:
             dxt = torch.empty(x.N * Hin * Win, Cin, dtype=BF16, device=dy.device)
-            call("nk_conv2d_dgrad", C.byref(d), dy.data_ptr(), w2d(weight).data_ptr(), dxt.data_ptr(), _stream())
+            # the input gradient of a stride-1 3 x 3 "same" convolution is such a convolution of dy with the mirrored, channel-swapped
+            # weights: where the halo-tile forward kernel takes that shape it runs there (one small transposing pass over the weights,
+            # re-done per step because they change), otherwise on the transposed-operand gather kernel
+            if query("nk_conv2d_dgrad_flipped_ok", C.byref(d)):
+                wt = torch.empty(Cin * 9 * Cout, dtype=BF16, device=dy.device)
+                call("nk_conv_weight_flip", w2d(weight).data_ptr(), wt.data_ptr(), Cout, Cin, 9, _stream())
+                call("nk_conv2d_dgrad_flipped", C.byref(d), dy.data_ptr(), wt.data_ptr(), dxt.data_ptr(), _stream())
+            else:
+                call("nk_conv2d_dgrad", C.byref(d), dy.data_ptr(), w2d(weight).data_ptr(), dxt.data_ptr(), _stream())
             if upsample:
                 dsm = torch.empty(x.N * x.H * x.W, Cin, dtype=BF16, device=dy.device)
                 call("nk_upsample2x_bwd", dxt.data_ptr(), dsm.data_ptr(), x.N, x.H, x.W, Cin, _stream())
@@ -575,9 +623,14 @@ def groupnorm_fwd(x: Img, weight: Tensor, bias: Tensor, groups: int, eps: float,
     mean = torch.empty(N, groups, dtype=torch.float32, device=x.t.device)
     rstd = torch.empty_like(mean)
     nws = query("nk_groupnorm_ws_floats", N, HW, Cc, groups)
-    ws = _ws(nws, x.t.device)
-    call("nk_groupnorm_fwd", x.t.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-         ws.data_ptr(), N, HW, Cc, groups, float(eps), int(silu), _stream())
+    if x.sums is not None and x.sums.shape == (N, 2 * groups):
+        # the producer's statistics epilogue already summed x: the normalisation pass alone
+        call("nk_groupnorm_apply", x.t.data_ptr(), x.sums.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+             rstd.data_ptr(), N, HW, Cc, groups, float(eps), int(silu), _stream())
+    else:
+        ws = _ws(nws, x.t.device)
+        call("nk_groupnorm_fwd", x.t.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+             ws.data_ptr(), N, HW, Cc, groups, float(eps), int(silu), _stream())
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
         dx = torch.empty_like(x.t)
