@@ -115,11 +115,13 @@ class GemmTimer:
     stream the kernels are launched on; algorithmic FLOPs = 2*M*N*K per launch."""
 
     NAMES = ("nk_linear_fwd", "nk_linear_dgrad", "nk_linear_wgrad", "nk_conv2d_fwd", "nk_conv2d_dgrad", "nk_conv2d_wgrad",
-             "nk_linear_fwd_batched", "nk_linear_wgrad_batched", "nk_conv2d_fwd_fused", "nk_conv2d_dgrad_flipped")
+             "nk_linear_fwd_batched", "nk_linear_wgrad_batched", "nk_conv2d_fwd_stats", "nk_conv2d_dgrad_flipped", "nk_linear_wgrad_bias",
+             "nk_conv2d_wgrad_bias", "nk_linear_dgrad_geglu")
     # the batched entry points (several same-shape GEMMs per launch) are reported with the family they belong to; so are the
     # convolutions with a fused GroupNorm statistics epilogue and the input gradients that run as forward convolutions of dy
-    FAMILY = {"nk_linear_fwd_batched": "nk_linear_fwd", "nk_linear_wgrad_batched": "nk_linear_wgrad", "nk_conv2d_fwd_fused": "nk_conv2d_fwd",
-              "nk_conv2d_dgrad_flipped": "nk_conv2d_dgrad"}
+    FAMILY = {"nk_linear_fwd_batched": "nk_linear_fwd", "nk_linear_wgrad_batched": "nk_linear_wgrad", "nk_conv2d_fwd_stats": "nk_conv2d_fwd",
+              "nk_conv2d_dgrad_flipped": "nk_conv2d_dgrad", "nk_linear_wgrad_bias": "nk_linear_wgrad", "nk_conv2d_wgrad_bias": "nk_conv2d_wgrad",
+              "nk_linear_dgrad_geglu": "nk_linear_dgrad"}
 
     def __init__(self):
         self.records = []
@@ -132,8 +134,12 @@ class GemmTimer:
             return 2.0 * args[4] * args[5] * args[6]
         if name == "nk_linear_wgrad":
             return 2.0 * args[3] * args[4] * args[5]
-        if name in ("nk_linear_fwd_batched", "nk_linear_wgrad_batched"):     # (ptrs, ptrs, ptrs, count, M, N, K, ...)
+        if name in ("nk_linear_wgrad_bias", "nk_linear_dgrad_geglu"):        # (dy, x | w, dw | u, dbias | du, M, N, K | I, ...)
+            return 2.0 * args[4] * args[5] * args[6]
+        if name == "nk_linear_fwd_batched":     # (ptrs, ptrs, ptrs, count, M, N, K, ...)
             return 2.0 * args[3] * args[4] * args[5] * args[6]
+        if name == "nk_linear_wgrad_batched":   # (ptrs, ptrs, ptrs, bias ptrs, count, M, N, K, ...)
+            return 2.0 * args[4] * args[5] * args[6] * args[7]
         d = args[0]._obj
         up = 2 if d.upsample else 1
         if name in ("nk_conv2d_dgrad", "nk_conv2d_dgrad_flipped"):  # rows = input pixels (virtual 2x grid when upsampling), algorithmic = same MACs as fwd

@@ -38,8 +38,16 @@ int nk_linear_fwd(const void* x, const void* w, const float* bias, const void* r
 int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add, void* dx, int M, int N, int K,
                     long lddy, long ldw, long ldadd, long lddx, void* stream);
 /* dw[N,K] (+)= dy[M,N]^T @ x[M,K]   fp32.  accumulate: 0 overwrite, 1 add, 2 destination is known to be all zero */
+/* nk_linear_dgrad of FeedForward.net[2] with the GEGLU backward in its epilogue (modules/attention.py:50-74): du[M][2I] =
+ * [d * gelu(g) | d * a * gelu'(g)], d = dy[M][N] @ w[N][I], u = [a | g] [M][2I] saved by the forward */
+int nk_linear_dgrad_geglu(const void* dy, const void* w, const void* u, void* du, int M, int N, int I, long lddy, long ldw, long ldu,
+                          long lddu, void* stream);
 int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy, long ldx,
                     long lddw, int accumulate, void* stream);
+/* ... with the bias gradient dbias[N] (+)= column sums of dy from the same launch: the weight-gradient kernel already stages the dy panel;
+ * the first column tile of each row block sums it with one extra MFMA per k sub-step against ones (no separate reduction launches) */
+int nk_linear_wgrad_bias(const void* dy, const void* x, float* dw, float* dbias, int M, int N, int K, long lddy, long ldx, long lddw,
+                         int accumulate, void* stream);
 
 /* Health of the persistent stream-K tile kernel (gemm.hip): a workgroup that finishes a K-split tile waits -- bounded --
  * for the partial tiles of lower-indexed workgroups.  Returns 0 if no launch ever gave up that wait, 1 otherwise
@@ -72,8 +80,9 @@ int nk_colsum_batched(const void* dy, float* out, float* ws, long M, int N, long
 int nk_linear_fwd_batched(const void* const* x, const void* const* w, void* const* y, int count, int M, int N, int K,
                           long ldx, long ldw, long ldy, void* stream);
 
-int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, int count, int M, int N, int K,
-                            long lddy, long ldx, long lddw, int accumulate, void* stream);
+/* dbias: NULL, or `count` pointers (NULL entries allowed) to the layers' bias gradients [N], summed in the same launch */
+int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, float* const* dbias, int count, int M, int N,
+                            int K, long lddy, long ldx, long lddw, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * nn.Conv2d as implicit GEMM  (openaimodel.py:124 Upsample.conv, :183-190 Downsample.op, :247-301 ResBlock convs,
@@ -91,19 +100,19 @@ typedef struct NkConvDesc {
 /* y = conv(x, w) + bias[Cout] + rowvec[n][Cout] + residual[N][Ho][Wo][Cout]   (all three optional) */
 int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
                   const void* residual, void* y, void* stream);
-/* The same with GroupNorm fused on either side -- 3 x 3 / stride 1 / padding 1 convolutions the halo-tile kernel takes (conv_halo.h):
- *   prologue  (gn_sums != NULL): the convolution reads silu?(GroupNorm(x)) without that tensor ever existing in HBM.  gn_sums
- *             [N][gn_groups][2] = sum and sum of squares of x per (image, group) (nk_groupnorm_sums, or a producer's epilogue);
- *             gn_gamma / gn_beta [Cin].  Forward-only users: the frozen VAE encoder's GroupNorm -> SiLU -> conv pairs
- *             (modules/diffusion/model.py:116-124 ResnetBlock.forward: h = conv1(silu(norm1(x))), h = conv2(silu(norm2(h)))).
- *   epilogue  (stats_part != NULL): per-tile partial sums of the OUTPUT, [N][tiles][2 * stats_groups] with tiles =
- *             nk_conv2d_fused_tiles(...): what the GroupNorm that consumes y needs instead of its own statistics pass
- *             (openaimodel.py:247-283: in_layers conv -> out_layers GroupNorm; model.py:116-124).
- * nk_conv2d_fused_tiles returns 0 when this shape / option pair is not available: run the unfused kernels then. */
-long nk_conv2d_fused_tiles(const NkConvDesc* d, int gn_groups, int stats_groups);
-int nk_conv2d_fwd_fused(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
-                        const void* residual, void* y, const float* gn_sums, const float* gn_gamma, const float* gn_beta,
-                        float gn_eps, int gn_groups, int gn_silu, float* stats_part, int stats_groups, void* stream);
+/* nk_conv2d_fwd that also emits, from its epilogue, the GroupNorm sums of its OUTPUT as per-tile partials [N][tiles][2 * stats_groups]
+ * (entry 2g = sum, 2g+1 = sum of squares of the bf16-rounded values; tiles = nk_conv2d_stats_tiles): the GroupNorm that reads y then needs no
+ * statistics pass (openaimodel.py:247-283 in_layers conv -> out_layers GroupNorm; model.py:116-124 conv1 -> norm2).  3 x 3 / stride 1 /
+ * padding 1 convolutions the halo-tile kernel takes (conv_halo.h); nk_conv2d_stats_tiles returns 0 where it is not available (run
+ * nk_conv2d_fwd and nk_groupnorm_fwd then); with stats_groups = 0 it tells whether the halo-tile kernel takes the shape at all. */
+long nk_conv2d_stats_tiles(const NkConvDesc* d, int stats_groups);
+int nk_conv2d_fwd_stats(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec, const void* residual,
+                        void* y, float* stats_part, int stats_groups, void* stream);
+/* 3 x 3 / stride 1 / padding 1 forward for images with 3 or 4 real channels stored padded to 8 (x [N][H][W][8], w [Cout][3][3][8]): the
+ * first convolutions of the VAE encoder (model.py:519) and of the UNet (openaimodel.py:622-624) as a register-resident FMA kernel --
+ * K = 27 / 36 gives the MFMA engine nothing to do, and its gather spent milliseconds on a 1 GB output. */
+int nk_conv3x3_few_channels_fwd(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cout, int cin_real,
+                                void* stream);
 /* wt[Cin][KH*KW][Cout], taps mirrored (tap t of w lands at tap KH*KW-1-t): the weights with which a stride-1 "same" convolution's
  * INPUT GRADIENT is itself such a convolution, dx = nk_conv2d_fwd(dy, wt) with the channel roles swapped -- how the 3 x 3 input
  * gradients of the ResBlocks (autograd of openaimodel.py:247-301) reach the halo-tile forward kernel. */
@@ -116,6 +125,8 @@ int nk_conv2d_dgrad_flipped(const NkConvDesc* d, const void* dy, const void* wt,
 int nk_conv2d_dgrad(const NkConvDesc* d, const void* dy, const void* w, void* dx, void* stream);
 /* dw[Cout][KH][KW][Cin] (+)= ...  fp32 */
 int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, int accumulate, void* stream);
+/* ... with the bias gradient dbias[Cout] (+)= sum over pixels of dy from the same launch */
+int nk_conv2d_wgrad_bias(const NkConvDesc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention  softmax(q k^T * scale) v, no dropout; no mask

@@ -16,9 +16,6 @@
 //     of k-step t, after the barrier behind which the last reads of stage (t-1) % 3 have retired), waves 6-7 stage the halo.
 //     vmcnt is per wave and in order, so a wave that staged both would have to land its HBM-latency halo pieces every k-step
 //     before its next weight slab; the halo waves instead keep several k-steps of pieces in flight and drain once per slab;
-//   * optional GroupNorm(+SiLU) PROLOGUE (the frozen VAE encoder): the raw input x lands in the halo buffer during taps 0-3 of the
-//     previous slab, and during taps 5-8 all eight waves rewrite it IN PLACE as silu(x * a_c + b_c) (padding pixels stay zero),
-//     a_c / b_c from the per-(image, group) sums of whoever produced x -- the normalised tensor never exists in HBM;
 //   * optional GroupNorm STATISTICS epilogue: per (tile, group) sum and sum of squares of the bf16-rounded outputs, combined in a
 //     fixed order (no atomics), in the layout gn_reduce_partials_kernel (norm.hip) sums: the GroupNorm that consumes this
 //     convolution's output needs no statistics pass of its own;
@@ -36,7 +33,6 @@
 #define CH_BSTAGE 20480                         // weights of one k-step: up to 160 rows x 128 B
 #define CH_NS 3
 #define CH_NBW 6                                // weight-staging waves (0..5); waves 6, 7 stage the halo
-#define CH_TABLE_BYTES 1024                     // PRO: two [64 channels][a, b] fp32 tables
 
 template <int MI>
 struct HaloGeom {
@@ -46,8 +42,7 @@ struct HaloGeom {
   static constexpr int HPIECES = ((HPX + 7) / 8 + 1) & ~1;            // 1 KiB pieces (8 pixels each), even: 26 / 44
   static constexpr int HBUF = HPIECES * 1024;
   static constexpr int HPW = HPIECES / 2;                             // pieces per halo wave and slab: 13 / 22
-  static constexpr int SMEM = 2 * HBUF + CH_NS * CH_BSTAGE + CH_TABLE_BYTES;   // 115712 / 152576
-  static constexpr int ITEMS = (HPIECES * 64 + 511) / 512;            // PRO: 16-byte halo items per thread and slab: 4 / 6
+  static constexpr int SMEM = 2 * HBUF + CH_NS * CH_BSTAGE;           // 114688 / 151552
 };
 // halo pieces a halo wave issues at tap t when its NPH pieces are spread over taps 0..LAST
 constexpr int ch_count(int NPH, int LAST, int t) { return t > LAST ? 0 : (NPH + LAST - t) / (LAST + 1); }
@@ -84,18 +79,15 @@ struct HaloWeights {
   }
 };
 
-__device__ __forceinline__ float ch_silu(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f)); }
-
 // MI: 16-pixel row blocks per wave (2: 4 x 32 tiles, 4: 8 x 32 tiles)
-// PRO: 0 = the input is read as it is; 1 = GroupNorm(+SiLU) of the input applied in LDS (p.gn_*)
 // STATS: 1 = per-tile GroupNorm partial sums of the output written to p.stats_part
-template <int BN_, int MI, int PRO, int STATS>
+template <int BN_, int MI, int STATS>
 __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G = HaloGeom<MI>;
   constexpr int HN = BN_ / 2, NJ = HN / 16;          // columns per group; 16-column blocks per wave: 5 or 4
   constexpr int RPW = G::RPW, HPW = G::HPW, HBUF = G::HBUF;
-  constexpr int HLAST = PRO ? 3 : 6;                 // last tap at which halo pieces of the next slab are issued
+  constexpr int HLAST = 6;                           // last tap at which halo pieces of the next slab are issued
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wq = wave & 3;
@@ -128,7 +120,6 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   typedef __attribute__((address_space(3))) const char* lds_c;
   const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
   char* const ring = smem + 2 * HBUF;
-  float* const tab = (float*)(smem + 2 * HBUF + CH_NS * CH_BSTAGE);     // PRO: [2][64][2]
 
   // ---- halo staging (waves 6, 7): piece i of a halo wave covers halo pixels hp0 + 8 i (one per 8 lanes), slot lane & 7 of each;
   // the source of a lane's 16 bytes is recomputed per piece (a dozen scalar-ish VALU instructions) instead of kept in 13 / 22 registers ----
@@ -175,43 +166,6 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
 #define CH_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
   const int nbw = HaloWeights<BN_>::pieces(wave);         // weight pieces this wave stages per k-step (0 for the halo waves)
 
-  // PRO: the in-place GroupNorm(+SiLU) of a halo buffer.  Item it of thread tid = 16 bytes at byte (it * 512 + tid) * 16 of the buffer:
-  // pixel hp = idx >> 3, slot idx & 7 holds channel chunk slot ^ (hp & 7).  Padding pixels (outside the image) are left zero.
-  auto make_table = [&](int slab, float* tb) {             // 64 threads: a_c = rstd * gamma, b_c = beta - mean * a_c for the slab's channels
-    if (tid < 64) {
-      const int c = slab * 64 + tid;
-      const int cpg = Cin / p.gn_groups;
-      const int g = c / cpg;
-      const float inv_cnt = 1.0f / ((float)H * (float)W * (float)cpg);
-      const float m = p.gn_sums[((long)img * p.gn_groups + g) * 2] * inv_cnt;
-      const float var = fmaxf(p.gn_sums[((long)img * p.gn_groups + g) * 2 + 1] * inv_cnt - m * m, 0.f);
-      const float a = rsqrtf(var + p.gn_eps) * p.gn_gamma[c];
-      tb[2 * tid] = a;
-      tb[2 * tid + 1] = p.gn_beta[c] - m * a;
-    }
-  };
-  auto transform_item = [&](int it, char* hbuf, const float* tb) {
-    const int idx = it * 512 + tid;
-    if (idx >= G::HPIECES * 64) return;
-    const int hp = idx >> 3;
-    const int py = hp / CH_HW, px = hp - py * CH_HW;
-    const int y = y0 - 1 + py, x = x0 - 1 + px;
-    if (!(hp < G::HPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)) return;     // padding stays zero
-    const int chunk = (idx & 7) ^ (hp & 7);
-    uint4_t* slot = (uint4_t*)(hbuf + idx * 16);
-    float f[8];
-    unpack8(*slot, f);
-    const float4_t ab0 = *(const float4_t*)(tb + chunk * 16), ab1 = *(const float4_t*)(tb + chunk * 16 + 4);
-    const float4_t ab2 = *(const float4_t*)(tb + chunk * 16 + 8), ab3 = *(const float4_t*)(tb + chunk * 16 + 12);
-    f[0] = f[0] * ab0[0] + ab0[1]; f[1] = f[1] * ab0[2] + ab0[3]; f[2] = f[2] * ab1[0] + ab1[1]; f[3] = f[3] * ab1[2] + ab1[3];
-    f[4] = f[4] * ab2[0] + ab2[1]; f[5] = f[5] * ab2[2] + ab2[3]; f[6] = f[6] * ab3[0] + ab3[1]; f[7] = f[7] * ab3[2] + ab3[3];
-    if (p.gn_silu) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = ch_silu(f[e]);
-    }
-    *slot = pack8(f);
-  };
-
   // ---- prologue waits: halo 0 and weights 0 landed for everyone (weights 1 stay in flight) ----
   if (hwave) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -219,14 +173,6 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
     if (nbw == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (nbw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  }
-  if constexpr (PRO) {
-    make_table(0, tab);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    CH_BAR();                                              // halo 0 (raw) and its table are visible
-#pragma unroll
-    for (int it = 0; it < G::ITEMS; ++it) transform_item(it, smem, tab);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   CH_BAR();
   if (grp == 1) { CH_BAR(); }                              // the second group runs one barrier behind
@@ -236,7 +182,6 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   for (int s = 0; s < nslab; ++s) {
     const unsigned hcur = lds0 + (unsigned)(s & 1) * HBUF;
     char* const hnext = smem + ((s + 1) & 1) * HBUF;
-    float* const tnext = tab + ((s + 1) & 1) * 128;
     const bool more = s + 1 < nslab;
     auto step = [&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
@@ -263,25 +208,9 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
           for (int i = 0; i < cnt; ++i) fire_halo(st + i, s + 1, hnext);
         }
         // the next slab's halo has landed (this wave's share): before the barrier that precedes its first use
-        if (tap == (PRO ? 4 : 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the weights of k-step t + 1 have landed (this wave's share)
-      }
-      if constexpr (PRO) {
-        // taps 5-8, read phase: every wave normalises its share of the next slab's halo in place.  The raw halo landed before the
-        // barrier of tap 4; the last writes retire (lgkmcnt below) before this phase's barrier, hence before slab s + 1 is read.
-        if (more) {
-          if constexpr (tap == 4) make_table(s + 1, tnext);
-          if constexpr (tap >= 5) {
-            constexpr int per = (G::ITEMS + 3) / 4;                       // items per tap: 1 (4 x 32 tiles) or 2 (8 x 32: 2, 2, 1, 1)
-#pragma unroll
-            for (int u = 0; u < per; ++u) {
-              const int it = (tap - 5) * per + u;
-              if (it < G::ITEMS) transform_item(it, hnext, tnext);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          }
-        }
       }
       CH_BAR();
       // ---- M: the wave's MFMAs; weights of k-step t + 2 staged and the sources after them computed in their shadow ----
@@ -517,10 +446,10 @@ static bool use_halo(const NkGemmParams& p, int amode, int bmode, int out_f32) {
   return halo_shape_ok(p) && halo_tile_rows(p) != 0;
 }
 
-template <int BN_, int MI, int PRO, int STATS>
+template <int BN_, int MI, int STATS>
 static int launch_halo_as(const NkGemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = nk_conv3x3_halo_kernel<BN_, MI, PRO, STATS>;
+  auto kern = nk_conv3x3_halo_kernel<BN_, MI, STATS>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<MI>::SMEM);
     attr_set = true;
@@ -530,18 +459,16 @@ static int launch_halo_as(const NkGemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), HaloGeom<MI>::SMEM, stream, p);
   return nk_check_launch("nk_conv3x3_halo_kernel");
 }
-template <int PRO, int STATS>
-static int launch_halo_ps(const NkGemmParams& p, hipStream_t stream) {
+template <int STATS>
+static int launch_halo_s(const NkGemmParams& p, hipStream_t stream) {
   int th = halo_tile_rows(p);
   if (const char* e = getenv("NK_CONV_HALO_TH")) th = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : th);      // A/B runs
   const bool wide = p.N % 160 == 0;
-  if (th == 8) return wide ? launch_halo_as<160, 4, PRO, STATS>(p, stream) : launch_halo_as<128, 4, PRO, STATS>(p, stream);
-  return wide ? launch_halo_as<160, 2, PRO, STATS>(p, stream) : launch_halo_as<128, 2, PRO, STATS>(p, stream);
+  if (th == 8) return wide ? launch_halo_as<160, 4, STATS>(p, stream) : launch_halo_as<128, 4, STATS>(p, stream);
+  return wide ? launch_halo_as<160, 2, STATS>(p, stream) : launch_halo_as<128, 2, STATS>(p, stream);
 }
 static int launch_halo(const NkGemmParams& p, hipStream_t stream) {
-  const bool pro = p.gn_sums != nullptr, stats = p.stats_part != nullptr;
-  if (pro) return stats ? launch_halo_ps<1, 1>(p, stream) : launch_halo_ps<1, 0>(p, stream);
-  return stats ? launch_halo_ps<0, 1>(p, stream) : launch_halo_ps<0, 0>(p, stream);
+  return p.stats_part ? launch_halo_s<1>(p, stream) : launch_halo_s<0>(p, stream);
 }
 // pixel tiles per image of the launch `launch_halo` would make (the statistics epilogue writes one partial row per tile)
 static int halo_tiles_per_image(const NkGemmParams& p) {

@@ -11,13 +11,6 @@ static inline int ew_blocks(long work_items) {
   return (int)b;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float dgelu_erf(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
-}
-
 // ---- GEGLU (modules/attention.py:55-57): y = u[:, :I] * gelu(u[:, I:]) ------------------------
 __global__ void geglu_fwd_kernel(const bf16_t* __restrict__ u, bf16_t* __restrict__ y, long M, int I) {
   const int cpr = I >> 3;
@@ -282,6 +275,80 @@ extern "C" int nk_conv_weight_flip(const void* w, void* wt, int Cout, int Cin, i
   hipLaunchKernelGGL(conv_weight_flip_kernel, dim3((Cin + 63) / 64, (Cout + 63) / 64, taps), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)wt,
                      Cout, Cin, taps);
   return nk_check_launch("conv_weight_flip_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3 x 3 / stride 1 / padding 1 convolution of an image with 3 or 4 REAL channels (stored padded to 8): the VAE's conv_in
+// (modules/diffusion/model.py:519, 3 -> 128 at 1024^2) and the UNet's (openaimodel.py:622-624, 4 -> 320).  27 or 36 MACs per output
+// are nothing for the MFMA engine to chew on -- as an implicit GEMM with K = 72 the gather kernel spent several ms per step decoding
+// taps for a 1 GB output; here it is a plain FMA kernel: a thread owns 4 output channels (their 27 / 36 weights live in registers as
+// fp32) and walks pixels; the 32 threads of a pixel write its 128 channels as one 256-byte row.  HBM-bound (the output).
+// ------------------------------------------------------------------------------------------------
+template <int CR>
+__global__ __launch_bounds__(256) void conv3x3_few_channels_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                                   bf16_t* __restrict__ y, int N, int H, int W, int Cout, int pix_per_block) {
+  const int cg = threadIdx.x & 31, pl = threadIdx.x >> 5;       // 4-channel group inside this block's 128 channels; pixel lane (8 pixels per pass)
+  const int co = blockIdx.y * 128 + cg * 4;
+  const bool live = co < Cout;
+  float wr[4][9 * CR], b4[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    b4[o] = (live && bias) ? bias[co + o] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      uint4_t v = {0u, 0u, 0u, 0u};
+      if (live) v = *(const uint4_t*)(w + ((long)(co + o) * 9 + t) * 8);
+      float f[8];
+      unpack8(v, f);
+#pragma unroll
+      for (int c = 0; c < CR; ++c) wr[o][t * CR + c] = f[c];
+    }
+  }
+  const long total = (long)N * H * W;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  for (int it = pl; it < pix_per_block; it += 8) {
+    const long pix = p0 + it;
+    if (pix >= total) break;
+    const int n = (int)(pix / ((long)H * W));
+    const int rem = (int)(pix - (long)n * H * W);
+    const int py = rem / W, px = rem - py * W;
+    float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      uint4_t v = {0u, 0u, 0u, 0u};
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = *(const uint4_t*)(x + (((long)n * H + yy) * W + xx) * 8);
+      float f[8];
+      unpack8(v, f);
+#pragma unroll
+      for (int c = 0; c < CR; ++c)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] += f[c] * wr[o][t * CR + c];
+    }
+    if (live) {
+      uint2_t out;
+      out.x = pack2bf(acc[0], acc[1]);
+      out.y = pack2bf(acc[2], acc[3]);
+      *(uint2_t*)(y + pix * Cout + co) = out;
+    }
+  }
+}
+extern "C" int nk_conv3x3_few_channels_fwd(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cout, int cin_real,
+                                           void* stream) {
+  // x [N][H][W][8] bf16 (channels >= cin_real are padding), w [Cout][3][3][8] bf16, y [N][H][W][Cout] bf16, bias [Cout] fp32 or NULL
+  NK_CHECK_ARG(x && w && y && N > 0 && H > 0 && W > 0 && Cout > 0 && (Cout & 3) == 0);
+  NK_CHECK_ARG(cin_real == 3 || cin_real == 4);
+  const long total = (long)N * H * W;
+  // ~8 blocks per CU and column slab; at least 64 pixels per block so that the weight preload (a few hundred loads) is amortised
+  long per = (total + 2047) / 2048;
+  if (per < 64) per = 64;
+  per = (per + 7) / 8 * 8;
+  dim3 grid((unsigned)((total + per - 1) / per), (unsigned)((Cout + 127) / 128));
+  if (cin_real == 3)
+    hipLaunchKernelGGL(conv3x3_few_channels_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, N, H, W, Cout, (int)per);
+  else
+    hipLaunchKernelGGL(conv3x3_few_channels_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, N, H, W, Cout, (int)per);
+  return nk_check_launch("conv3x3_few_channels_kernel");
 }
 
 extern "C" int nk_nchw_to_nhwc(const void* src, int src_is_f32, void* dst, int N, int C, int HW, int Cpad, float scale,

@@ -298,6 +298,20 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
       }
+      if (vec && p.geglu_u) {
+        // GEGLU backward (modules/attention.py:55-57, y = a * gelu(g)): this tile holds d = dL/dy; u = [a | g] was saved by the forward
+        float a[8], g[8], da[8], dg[8];
+        unpack8(*(const uint4_t*)(p.geglu_u + (long)m * p.ld_u + n), a);
+        unpack8(*(const uint4_t*)(p.geglu_u + (long)m * p.ld_u + p.N + n), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          da[e] = v[e] * gelu_erf(g[e]);
+          dg[e] = v[e] * a[e] * dgelu_erf(g[e]);
+        }
+        *(uint4_t*)(C + (long)m * p.ldc + n) = pack8(da);
+        *(uint4_t*)(C + (long)m * p.ldc + p.N + n) = pack8(dg);
+        continue;
+      }
       if (vec) {
         if (p.bias) {
           const float4_t b0 = *(const float4_t*)(p.bias + n);
@@ -746,6 +760,29 @@ struct OperandDMA {
   }
 };
 
+// ---- bias gradient inside a weight-gradient kernel ----
+// The A operand of a weight-gradient GEMM is dy (rows = output features, k = tokens / pixels): its row sums ARE the bias gradient.  The
+// first column tile of every row block accumulates them with an MFMA against ones -- acc[row][any column] += sum_k A(row, k) -- one per
+// 16-row block and k sub-step, shared out over the waves that hold the same rows.  Deterministic unless K is split (then fp32 atomics,
+// as for the weight gradient itself).
+__device__ __forceinline__ bf16x8_t nk_ones_frag() {
+  const short8_t o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};     // bf16 1.0
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+// standard operand order (acc row = (lane >> 4) * 4 + r, column = lane & 15): lanes of column 0 hold the 16 row sums of the block
+__device__ __forceinline__ void nk_store_bias_rows(float* db, const float4_t& a, int row0, int M, float alpha, int mode, int lane) {
+  if (lane & 15) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = row0 + (lane >> 4) * 4 + r;
+    if (m < M) {
+      const float v = a[r] * alpha;
+      if (mode == 2) unsafeAtomicAdd(db + m, v);        // K split over workgroups (destination zeroed or accumulating)
+      else db[m] = mode == 1 ? db[m] + v : v;
+    }
+  }
+}
+
 // NW = 4: waves 2x2, 64x64 per wave, 2 waves per SIMD at two workgroups per CU.
 // NW = 8: waves 2x4, 64x32 per wave, 4 waves per SIMD: same tile, same LDS, twice the waves to cover each other's
 //         DMA waits and fragment-read latency (under-filled grids run one workgroup per CU, i.e. 1 vs 2 waves per SIMD).
@@ -789,6 +826,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  // bias gradient (weight-gradient instantiations, first column tile): this wave's share of the row blocks it holds fragments of
+  constexpr bool CAN_BIAS = AMODE == OP_MC && OUT_F32 == 1;
+  constexpr int NWN = NW == 4 ? 2 : 4, BPW = 4 / NWN;         // waves sharing the same rows; row blocks per wave
+  float* const dbias = CAN_BIAS ? (p.nbatch ? p.dbias_b[blockIdx.z] : p.dbias) : nullptr;
+  const bool do_bias = CAN_BIAS && dbias != nullptr && nt == 0;
+  float4_t accb[BPW];
+#pragma unroll
+  for (int u = 0; u < BPW; ++u) accb[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   opa.start(kbeg, p.ga);      // running source pointers, as in the ring and stream-K kernels
   opb.start(kbeg, p.gb);
@@ -832,6 +877,22 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    if constexpr (CAN_BIAS) {
+      if (do_bias) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int u = 0; u < BPW; ++u)
+            accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][wn * BPW + u], nk_ones_frag(), accb[u], 0, 0, 0);
+      }
+    }
+  }
+  if constexpr (CAN_BIAS) {
+    if (do_bias) {
+      const int mode = gridDim.y > 1 ? 2 : (p.accumulate ? 1 : 0);
+#pragma unroll
+      for (int u = 0; u < BPW; ++u) nk_store_bias_rows(dbias, accb[u], m0 + wm * 64 + (wn * BPW + u) * 16, p.M, p.alpha, mode, lane);
+    }
   }
   __syncthreads();
 #ifdef NK_CLOCK_STAMPS
@@ -917,6 +978,10 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+  constexpr bool CAN_BIAS = AMODE == OP_MC && OUT_F32 == 1;      // bias gradient: see nk_gemm_dma_kernel
+  const bool do_bias = CAN_BIAS && p.dbias != nullptr && nt == 0;
+  float4_t accb = (float4_t){0.f, 0.f, 0.f, 0.f};
+
   // running source pointers (slabs are issued in k order): a k-step costs one 64-bit add and one select per piece instead of
   // the k * ld products -- this loop had 65 vector instructions per 16 MFMAs, 12 of them integer multiplies
   opa.start(kbeg, p.ga);
@@ -963,7 +1028,16 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    if constexpr (CAN_BIAS) {
+      if (do_bias) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][wn], nk_ones_frag(), accb, 0, 0, 0);
+      }
+    }
     if (++cur_stage == RING_NS) cur_stage = 0;
+  }
+  if constexpr (CAN_BIAS) {
+    if (do_bias) nk_store_bias_rows(p.dbias, accb, m0 + wm * 64 + wn * 16, p.M, p.alpha, gridDim.y > 1 ? 2 : (p.accumulate ? 1 : 0), lane);
   }
   __syncthreads();
   nk_gemm_epilogue<OUT_F32, BM, 512, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
@@ -2085,10 +2159,16 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   if (!out_f32) NK_CHECK_ARG((p.ldc & 7) == 0 || (p.N & 7) != 0);
   if (p.fRowsPerBatch.d == 0) p.fRowsPerBatch = make_fastdiv(1);
 
+  if (p.dbias || (p.nbatch && p.dbias_b[0])) NK_CHECK_ARG(amode == OP_MC && out_f32 && !use_v1());      // weight-gradient launches only
+  if (p.geglu_u) {   // the fused GEGLU backward lives in the LDS-staged epilogue of the 128 x 128 data-parallel / ring kernels only
+    NK_CHECK_ARG(amode == OP_KC && bmode == OP_MC && !out_f32 && !p.nbatch && (p.N & 7) == 0 && (p.ld_u & 7) == 0 && !p.bias && !p.rowvec && !p.residual);
+    set_split(p, 1);
+    return launch<OP_KC, OP_MC, 0>(p, 1, stream);
+  }
   // 3 x 3 / stride 1 / padding 1 convolutions over whole 64-channel slabs: the halo-tile kernel (conv_halo.h)
   if (!use_v1() && use_halo(p, amode, bmode, out_f32)) return launch_halo(p, stream);
-  if (p.gn_sums || p.stats_part) {      // the fused GroupNorm prologue / statistics epilogue exist in the halo-tile kernel only
-    nk_set_error(__FILE__, __LINE__, "fused GroupNorm options on a convolution the halo-tile kernel does not take (ask nk_conv2d_fused_tiles first)");
+  if (p.stats_part) {      // the GroupNorm statistics epilogue exists in the halo-tile kernel only
+    nk_set_error(__FILE__, __LINE__, "statistics epilogue on a convolution the halo-tile kernel does not take (ask nk_conv2d_stats_tiles first)");
     return NK_ERR_ARG;
   }
 
@@ -2134,6 +2214,8 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
       float* dst = (float*)(p.nbatch ? p.Cb[z] : p.C);
       const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
       hipLaunchKernelGGL(nk_zero_f32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, n);
+      float* db = p.nbatch ? p.dbias_b[z] : p.dbias;        // the fused bias gradient is summed by the same atomics
+      if (db) hipLaunchKernelGGL(nk_zero_f32_kernel, dim3(1), dim3(256), 0, stream, db, (size_t)p.M);
     }
     if (hipGetLastError() != hipSuccess) return NK_ERR_LAUNCH;
     p.accumulate = 1;

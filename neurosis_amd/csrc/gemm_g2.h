@@ -327,6 +327,12 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
   bf16x8_t af[4], bfr[2 * NJ];
+  // bias gradient of a weight-gradient launch (see nk_gemm_dma_kernel): the two column groups hold the same 32 rows per row quarter;
+  // group g sums the 16-row block g.  Swapped operands: the row is on lane & 15, every register of the result holds its sum.
+  constexpr bool CAN_BIAS = AMODE == OP_MC && OUT_F32 == 1;
+  float* const dbias = CAN_BIAS ? (p.nbatch ? p.dbias_b[blockIdx.z] : p.dbias) : nullptr;
+  const bool do_bias = CAN_BIAS && dbias != nullptr && nt == 0;
+  float4_t accb = (float4_t){0.f, 0.f, 0.f, 0.f};
 
 #define G2_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
   // this wave's pieces per slab: 4 (BN 128) or 5 / 4 (BN 160, waves 0-3 / 4-7) -- the counted wait leaves exactly one slab in flight
@@ -404,6 +410,12 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
 #pragma unroll
         for (int j = 0; j < NJ; ++j)     // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks * NJ + j], af[ks * 2 + i], acc[i][j], 0, 0, 0);
+    if constexpr (CAN_BIAS) {
+      if (do_bias) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nk_ones_frag(), af[ks * 2 + grp], accb, 0, 0, 0);
+      }
+    }
 #else
     { asm volatile("" :: "v"(bfr[0]), "v"(bfr[NJ]), "v"(af[0]), "v"(af[2])); }
 #endif
@@ -418,6 +430,12 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
 #undef G2_WAIT_ONE_SLAB
 
   const int mb = m0 + wq * 32, nb = n0 + grp * HN;
+  if constexpr (CAN_BIAS) {
+    if (do_bias && lane < 16) {
+      const int m = mb + grp * 16 + lane;
+      if (m < p.M) dbias[m] = p.accumulate ? dbias[m] + accb[0] * p.alpha : accb[0] * p.alpha;       // (no K split in this kernel)
+    }
+  }
 #pragma unroll
   for (int half = 0; half < NJ / 2; ++half) {
     float4_t pair[2][2];

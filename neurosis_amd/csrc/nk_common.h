@@ -98,3 +98,11 @@ __device__ __forceinline__ float dsilu_f(float x) {
   float s = 1.0f / (1.0f + __expf(-x));
   return s * (1.0f + x * (1.0f - s));
 }
+
+// exact (erf) GELU and its derivative: GEGLU (modules/attention.py:50-57) in elementwise.hip and in the GEMM epilogue that fuses its backward
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

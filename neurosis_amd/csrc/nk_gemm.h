@@ -55,14 +55,17 @@ struct NkGemmParams {
   int sk_chunked;           // 1: each XCD owns a contiguous eighth of the tile list
   int sk_debug;             // NK_SK_DEBUG: 1 = no epilogue stores (ablation), 2 = every fix-up wait gives up at once (tests the fail-closed path)
   unsigned* sk_health;      // backward-health word (errors.hip): raised when a fix-up wait gives up
+  // weight-gradient launches (A = dy, r-contiguous): the bias gradient dbias[m] (+)= sum_k A(m, k), accumulated by the first column tile of
+  // every row block with one extra MFMA per row block and k sub-step against a fragment of ones (the dy panel is already in registers)
+  float* dbias;
+  float* dbias_b[8];        // batched launch: one per problem
+  // GEGLU backward fused into the epilogue of the feed-forward-out input gradient (the LDS-staged epilogue of the 128 x 128 kernels):
+  // the GEMM's result is d = dL/d(a * gelu(g)) [M][N]; written instead: C[m][n] = d * gelu(g), C[m][N + n] = d * a * gelu'(g), with
+  // a = geglu_u[m][n], g = geglu_u[m][N + n] (ld_u elements per row) -- i.e. C is dL/du [M][2N]
+  const bf16_t* geglu_u;
+  long ld_u;
   // halo-tile 3 x 3 convolution (conv_halo.h)
   int halo_nb;              // images in the batch (0: not a convolution the halo kernel may take)
-  const float* gn_sums;     // prologue GroupNorm of the INPUT: [halo_nb][groups][2] sum, sum of squares over (H*W, channels of the group)
-  const float* gn_gamma;    // [Cin]
-  const float* gn_beta;     // [Cin]
-  float gn_eps;
-  int gn_groups;
-  int gn_silu;
   float* stats_part;        // statistics epilogue: [halo_nb][pixel tiles per image][2 * stats_groups] partial sums of the OUTPUT
   int stats_groups;
 };

@@ -60,22 +60,48 @@ extern "C" int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add
   return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_MC, 0, 0, (hipStream_t)stream);
 }
 
-extern "C" int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy,
-                               long ldx, long lddw, int accumulate, void* stream) {
-  // dw[N,K] (+)= dy[M,N]^T @ x[M,K] : reduction over M; both operands r-contiguous
+extern "C" int nk_linear_dgrad_geglu(const void* dy, const void* w, const void* u, void* du, int M, int N, int I, long lddy, long ldw,
+                                     long ldu, long lddu, void* stream) {
+  // FeedForward backward through net[2] and the GEGLU in one launch (modules/attention.py:60-74): d = dy[M,N] @ w[N,I] is the gradient of
+  // a * gelu(g); the epilogue turns it into du[M, 2I] = [d * gelu(g) | d * a * gelu'(g)] with u = [a | g] [M, 2I] from the forward --
+  // the stand-alone GEGLU backward kernel and its read of d are gone
+  NK_CHECK_ARG(dy && w && u && du && I > 0 && (I & 7) == 0);
+  NkGemmParams p = zero_params();
+  p.A = (const bf16_t*)dy; p.lda = lddy;
+  p.B = (const bf16_t*)w; p.ldb = ldw;
+  p.M = M; p.N = I; p.K = N;
+  p.C = du; p.ldc = lddu;
+  p.geglu_u = (const bf16_t*)u; p.ld_u = ldu;
+  return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_MC, 0, 0, (hipStream_t)stream);
+}
+
+static int linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, int M, int N, int K, long lddy, long ldx, long lddw,
+                        int accumulate, void* stream) {
+  // dw[N,K] (+)= dy[M,N]^T @ x[M,K] : reduction over M; both operands r-contiguous.  dbias[N] (+)= column sums of dy, in the same launch
   NkGemmParams p = zero_params();
   p.A = (const bf16_t*)dy; p.lda = lddy;
   p.B = (const bf16_t*)x; p.ldb = ldx;
   p.M = N; p.N = K; p.K = M;
   p.C = dw; p.ldc = lddw;
   p.accumulate = accumulate;
+  p.dbias = dbias;
   return nk_gemm_dispatch(p, NK_OP_MC, NK_OP_MC, 1, lddw == K, (hipStream_t)stream);
 }
+extern "C" int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy,
+                               long ldx, long lddw, int accumulate, void* stream) {
+  return linear_wgrad(dy, x, dw, nullptr, M, N, K, lddy, ldx, lddw, accumulate, stream);
+}
+extern "C" int nk_linear_wgrad_bias(const void* dy, const void* x, float* dw, float* dbias, int M, int N, int K, long lddy,
+                                    long ldx, long lddw, int accumulate, void* stream) {
+  NK_CHECK_ARG(dbias != nullptr);
+  return linear_wgrad(dy, x, dw, dbias, M, N, K, lddy, ldx, lddw, accumulate, stream);
+}
 
-extern "C" int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, int count, int M,
+extern "C" int nk_linear_wgrad_batched(const void* const* dy, const void* const* x, float* const* dw, float* const* dbias, int count, int M,
                                        int N, int K, long lddy, long ldx, long lddw, int accumulate, void* stream) {
   // `count` weight gradients of IDENTICAL shape in one launch (blockIdx.z): dw[i][N,K] (+)= dy[i][M,N]^T @ x[i][M,K].
-  // Host pointer arrays; the device pointers are copied into the kernel arguments.
+  // Host pointer arrays; the device pointers are copied into the kernel arguments.  dbias: NULL, or one pointer per problem (NULL entries
+  // allowed: layers without a bias) for the bias gradients dbias[i][N] (+)= column sums of dy[i].
   NK_CHECK_ARG(dy && x && dw && count >= 1 && count <= NK_MAX_BATCH);
   NkGemmParams p = zero_params();
   p.lda = lddy; p.ldb = ldx;
@@ -87,6 +113,7 @@ extern "C" int nk_linear_wgrad_batched(const void* const* dy, const void* const*
     p.Ab[i] = (const bf16_t*)dy[i];
     p.Bb[i] = (const bf16_t*)x[i];
     p.Cb[i] = dw[i];
+    p.dbias_b[i] = dbias ? dbias[i] : nullptr;
   }
   p.A = p.Ab[0]; p.B = p.Bb[0]; p.C = p.Cb[0];
   return nk_gemm_dispatch(p, NK_OP_MC, NK_OP_MC, 1, lddw == K, (hipStream_t)stream);
@@ -145,13 +172,12 @@ extern "C" int nk_conv2d_fwd(const NkConvDesc* d, const void* x, const void* w, 
   return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_KC, 0, 0, (hipStream_t)stream);
 }
 
-// Can this convolution run with a fused GroupNorm prologue over `gn_groups` groups of its INPUT (0: none) and / or a GroupNorm
-// statistics epilogue over `stats_groups` groups of its OUTPUT (0: none)?  Returns the number of pixel tiles per image of that launch
-// (the statistics partials have that many rows per image), or 0: run the unfused kernels.
-extern "C" long nk_conv2d_fused_tiles(const NkConvDesc* d, int gn_groups, int stats_groups) {
+// Can this convolution emit the GroupNorm sums of its OUTPUT over `stats_groups` groups from its epilogue (the halo-tile kernel takes the
+// shape, and a column tile holds whole groups)?  Returns the number of pixel tiles per image of that launch -- the partials have that many
+// rows per image -- or 0: run nk_conv2d_fwd and a statistics pass.  stats_groups = 0 asks whether the halo-tile kernel takes the shape.
+extern "C" long nk_conv2d_stats_tiles(const NkConvDesc* d, int stats_groups) {
   if (check_conv(d)) return 0;
-  if (gn_groups < 0 || stats_groups < 0 || gn_groups > 32 || stats_groups > 32) return 0;
-  if (gn_groups && d->Cin % gn_groups) return 0;
+  if (stats_groups < 0 || stats_groups > 32) return 0;
   if (stats_groups) {
     if (d->Cout % stats_groups) return 0;
     const int bn = d->Cout % 160 == 0 ? 160 : 128, cpg = d->Cout / stats_groups;
@@ -161,18 +187,14 @@ extern "C" long nk_conv2d_fused_tiles(const NkConvDesc* d, int gn_groups, int st
   return nk_halo_tiles_per_image(p);
 }
 
-extern "C" int nk_conv2d_fwd_fused(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
-                                   const void* residual, void* y, const float* gn_sums, const float* gn_gamma, const float* gn_beta,
-                                   float gn_eps, int gn_groups, int gn_silu, float* stats_part, int stats_groups, void* stream) {
-  // nk_conv2d_fwd with (a) the GroupNorm(+SiLU) of the input applied on the way into LDS -- gn_sums [N][gn_groups][2] = per (image,
-  // group) sum and sum of squares of x over H*W*(Cin/groups) elements, gamma / beta [Cin] -- and / or (b) the same sums of the OUTPUT
-  // emitted as per-tile partials stats_part [N][tiles][2*stats_groups] (nk_groupnorm_sums_from_parts adds them up).
+extern "C" int nk_conv2d_fwd_stats(const NkConvDesc* d, const void* x, const void* w, const float* bias, const void* rowvec,
+                                   const void* residual, void* y, float* stats_part, int stats_groups, void* stream) {
+  // nk_conv2d_fwd that also writes, per pixel tile, the sums and sums of squares of its (bf16-rounded) output per GroupNorm group:
+  // stats_part [N][tiles][2 * stats_groups], tiles = nk_conv2d_stats_tiles(d, stats_groups); nk_groupnorm_sums_from_parts adds them up
   if (int e = check_conv(d)) return e;
-  NK_CHECK_ARG(gn_sums || stats_part);
-  NK_CHECK_ARG(nk_conv2d_fused_tiles(d, gn_sums ? gn_groups : 0, stats_part ? stats_groups : 0) > 0);
-  NK_CHECK_ARG(!gn_sums || (gn_gamma && gn_beta && gn_groups > 0));
+  NK_CHECK_ARG(stats_part && stats_groups > 0);
+  NK_CHECK_ARG(nk_conv2d_stats_tiles(d, stats_groups) > 0);
   NkGemmParams p = conv_fwd_params(d, x, w, bias, rowvec, residual, y);
-  p.gn_sums = gn_sums; p.gn_gamma = gn_gamma; p.gn_beta = gn_beta; p.gn_eps = gn_eps; p.gn_groups = gn_groups; p.gn_silu = gn_silu;
   p.stats_part = stats_part; p.stats_groups = stats_groups;
   return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_KC, 0, 0, (hipStream_t)stream);
 }
@@ -226,9 +248,8 @@ extern "C" int nk_conv2d_dgrad_flipped(const NkConvDesc* d, const void* dy, cons
   return nk_gemm_dispatch(p, NK_OP_KCG, NK_OP_KC, 0, 0, (hipStream_t)stream);
 }
 
-extern "C" int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, int accumulate,
-                               void* stream) {
-  // dw[co, (tap,ci)] (+)= sum_pix dy[pix, co] * x[gather(pix, tap), ci]
+static int conv_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate, void* stream) {
+  // dw[co, (tap,ci)] (+)= sum_pix dy[pix, co] * x[gather(pix, tap), ci];  dbias[co] (+)= sum_pix dy[pix, co] in the same launch
   if (int e = check_conv(d)) return e;
   NkGemmParams p = zero_params();
   p.A = (const bf16_t*)dy; p.lda = d->Cout;
@@ -236,5 +257,15 @@ extern "C" int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* 
   p.M = d->Cout; p.N = d->KH * d->KW * d->Cin; p.K = d->N * d->Ho * d->Wo;
   p.C = dw; p.ldc = p.N;
   p.accumulate = accumulate;
+  p.dbias = dbias;
   return nk_gemm_dispatch(p, NK_OP_MC, NK_OP_MCG, 1, 1, (hipStream_t)stream);
+}
+extern "C" int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, int accumulate,
+                               void* stream) {
+  return conv_wgrad(d, dy, x, dw, nullptr, accumulate, stream);
+}
+extern "C" int nk_conv2d_wgrad_bias(const NkConvDesc* d, const void* dy, const void* x, float* dw, float* dbias, int accumulate,
+                                    void* stream) {
+  NK_CHECK_ARG(dbias != nullptr);
+  return conv_wgrad(d, dy, x, dw, dbias, accumulate, stream);
 }

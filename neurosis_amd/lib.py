@@ -36,12 +36,16 @@ cdp, adp = C.POINTER(NkConvDesc), C.POINTER(NkAttnDesc)
 SIGNATURES: dict[str, list] = {
     "nk_linear_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, f32, vp],
     "nk_linear_dgrad": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
+    "nk_linear_dgrad_geglu": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "nk_linear_wgrad": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp],
     "nk_linear_fwd_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, vp],
-    "nk_linear_wgrad_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, i32, vp],
+    "nk_linear_wgrad_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, i32, vp],
+    "nk_linear_wgrad_bias": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp],
+    "nk_conv2d_wgrad_bias": [cdp, vp, vp, vp, vp, i32, vp],
     "nk_conv2d_fwd": [cdp, vp, vp, vp, vp, vp, vp, vp],
-    "nk_conv2d_fwd_fused": [cdp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, i32, vp],
+    "nk_conv2d_fwd_stats": [cdp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "nk_conv_weight_flip": [vp, vp, i32, i32, i32, vp],
+    "nk_conv3x3_few_channels_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "nk_conv2d_dgrad": [cdp, vp, vp, vp, vp],
     "nk_conv2d_dgrad_flipped": [cdp, vp, vp, vp, vp],
     "nk_conv2d_wgrad": [cdp, vp, vp, vp, i32, vp],
@@ -101,7 +105,7 @@ SIGNATURES: dict[str, list] = {
 SIZE_QUERIES: dict[str, list] = {
     "nk_groupnorm_ws_floats": [i32, i32, i32, i32],
     "nk_groupnorm_sums_ws_floats": [i32, i32, i32],
-    "nk_conv2d_fused_tiles": [cdp, i32, i32],
+    "nk_conv2d_stats_tiles": [cdp, i32],
     "nk_conv2d_dgrad_flipped_ok": [cdp],
     "nk_layernorm_ws_floats": [i32, i32],
     "nk_colsum_ws_floats": [i64, i32],

@@ -59,11 +59,13 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
 
     def fwd(self, x: Tensor, residual: Optional[Tensor] = None):
-        g, b_glu = self.net[0].fwd(x)
+        u, b_proj = linear_module_fwd(self.net[0].proj, x)
+        g = ops.geglu_fwd(u)[0]
         y, b_out = linear_module_fwd(self.net[2], g, residual)
 
         def bwd(dy: Tensor):
-            return b_glu(b_out(dy))
+            # net[2]'s input gradient with the GEGLU backward in its epilogue: one launch, d(a * gelu(g)) never goes to HBM
+            return b_proj(b_out(dy, geglu_u=u))
 
         return y, bwd
 

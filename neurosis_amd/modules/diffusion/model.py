@@ -97,8 +97,8 @@ class ResnetBlock(nn.Module):
     def fwd(self, x: Img, want_sums: bool = False) -> Img:
         """forward only (the frozen first stage).  Each convolution's epilogue emits the GroupNorm sums of its output (conv1 for norm2;
         with `want_sums` conv2 for whichever GroupNorm reads the block's output), so the GroupNorms run their normalisation pass only.
-        (Applying the GroupNorm inside the consuming convolution -- conv2d_fwd(gn=...) -- is built and tested, but measured slower here:
-        the in-place SiLU lengthens the kernel's read phases by more than the separate pass costs, tools/bench_conv_halo.py.)"""
+        (Applying the GroupNorm inside the consuming convolution, as an in-LDS rewrite of its halo, was built and measured slower than
+        the separate normalisation pass -- DESIGN.md -- and removed.)"""
         groups = self.norm1.num_groups
         h = self.conv1.fwd(_gn(x, self.norm1, True), need_dx=False, stats_groups=self.norm2.num_groups)[0]
         h = _gn(h, self.norm2, True)

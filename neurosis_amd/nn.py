@@ -151,19 +151,17 @@ class Conv2d(nn.Module):
         return wp, bp
 
     def fwd(self, x: Img, rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None, upsample: bool = False, need_dx: bool = True,
-            gn=None, stats_groups: Optional[int] = None):
-        """gn = (GroupNorm module, silu): this convolution reads silu?(GroupNorm(x)) (forward-only, fused where the kernel allows);
-        stats_groups = G: ask for the output's GroupNorm sums (out.sums) -- see ops.conv2d_fwd."""
+            stats_groups: Optional[int] = None):
+        """stats_groups = G: ask for the output's GroupNorm sums (out.sums) -- see ops.conv2d_fwd."""
         if not self.padded:
             return ops.conv2d_fwd(x, self.weight, self.bias, self.stride, self.padding, upsample, rowvec, residual, need_dx, self.asym_pad,
-                                  gn=gn, stats_groups=stats_groups)
-        if gn is not None:
-            x = ops.groupnorm_fwd(x, gn[0].weight, gn[0].bias, gn[0].num_groups, gn[0].eps, gn[1])[0]
+                                  stats_groups=stats_groups)
         wp, bp = self._padded_params()
         wp.grad = None
         if bp is not None:
             bp.grad = None
-        out, b = ops.conv2d_fwd(x, wp, bp, self.stride, self.padding, upsample, rowvec, residual, need_dx, self.asym_pad)
+        out, b = ops.conv2d_fwd(x, wp, bp, self.stride, self.padding, upsample, rowvec, residual, need_dx, self.asym_pad,
+                                cin_real=self.in_channels if self.in_channels in (3, 4) else None)
 
         def bwd(dy: Tensor):
             acc = ops.state_of(self.weight).grad_accumulate

@@ -161,8 +161,9 @@ class WgradQueue:
     def takes(cls, weight: Tensor) -> bool:
         return weight.numel() <= cls.MAX_ELEMS
 
-    def add(self, dy: Tensor, x: Tensor, dw: Tensor) -> None:
-        self.items.append((dy, x, dw))
+    def add(self, dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor] = None) -> None:
+        """db: the layer's bias gradient [N] (fp32), summed from dy by the same launch"""
+        self.items.append((dy, x, dw, db))
 
     def flush(self) -> None:
         items, self.items = self.items, []
@@ -170,7 +171,7 @@ class WgradQueue:
             return
         groups = {}
         for it in items:
-            dy, x, dw = it
+            dy, x, dw, _db = it
             key = (dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), dw.stride(0))
             groups.setdefault(key, []).append(it)
         mode = wgrad_mode(self.owner)
@@ -180,12 +181,13 @@ class WgradQueue:
                 for i in range(0, len(its), 8):
                     chunk = its[i:i + 8]
                     if len(chunk) == 1:
-                        gemm_tn_f32(chunk[0][0], chunk[0][1], chunk[0][2], mode)
+                        gemm_tn_f32(chunk[0][0], chunk[0][1], chunk[0][2], mode, dbias=chunk[0][3])
                         continue
                     n = len(chunk)
                     arr = C.c_void_p * n
                     call("nk_linear_wgrad_batched", arr(*[c[0].data_ptr() for c in chunk]), arr(*[c[1].data_ptr() for c in chunk]),
-                         arr(*[c[2].data_ptr() for c in chunk]), n, M, N, K, lddy, ldx, lddw, mode, _stream())
+                         arr(*[c[2].data_ptr() for c in chunk]), arr(*[None if c[3] is None else c[3].data_ptr() for c in chunk]), n, M, N, K,
+                         lddy, ldx, lddw, mode, _stream())
 
         on_wgrad_stream(run, *[t for it in items for t in it[:2]], owner=self.owner)
 
@@ -459,15 +461,21 @@ def gemm_nn(dy: Tensor, w: Tensor, dx_add: Optional[Tensor] = None, out: Optiona
     return out
 
 
-def gemm_tn_f32(dy: Tensor, x: Tensor, dw: Tensor, accumulate) -> None:
-    """dw (+)= dy^T @ x ; dy [M,N], x [M,K], dw fp32 [N,K]."""
+def gemm_tn_f32(dy: Tensor, x: Tensor, dw: Tensor, accumulate, dbias: Optional[Tensor] = None) -> None:
+    """dw (+)= dy^T @ x ; dy [M,N], x [M,K], dw fp32 [N,K].  dbias fp32 [N] (+)= column sums of dy, from the same launch."""
     _check2d(dy, "dy")
     _check2d(x, "x")
     M, N = dy.shape
     K = x.shape[1]
     if x.shape[0] != M or dw.shape != (N, K) or dw.dtype != torch.float32 or dw.stride(1) != 1:
         raise ValueError(f"gemm_tn_f32: bad shapes {dy.shape} {x.shape} {dw.shape}")
-    call("nk_linear_wgrad", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), _stream())
+    if dbias is None:
+        call("nk_linear_wgrad", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), _stream())
+        return
+    if dbias.shape != (N,) or dbias.dtype != torch.float32 or not dbias.is_contiguous():
+        raise ValueError(f"gemm_tn_f32: dbias must be a dense fp32 [{N}] tensor")
+    call("nk_linear_wgrad_bias", dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbias.data_ptr(), M, N, K, dy.stride(0), x.stride(0), dw.stride(0),
+         int(accumulate), _stream())
 
 
 def colsum(dy: Tensor, out: Tensor, accumulate: bool) -> None:
@@ -482,19 +490,32 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
     bwd(dy, dx_add=None) -> dx (None if need_dx is False); writes weight.grad / bias.grad."""
     y = gemm_nt(x, w2d(weight), bias, residual)
 
-    def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
+    def bwd(dy: Tensor, dx_add: Optional[Tensor] = None, geglu_u: Optional[Tensor] = None):
+        """geglu_u = the [a | g] matrix whose GEGLU produced x (FeedForward): the returned gradient is then d/du [M, 2K], the GEGLU
+        backward applied in the input-gradient GEMM's epilogue (nk_linear_dgrad_geglu)"""
         queued = _wgrad_queue is not None and _wgrad_queue.takes(weight) and dy.is_contiguous() and x.is_contiguous()
+        # the bias gradient (column sums of dy) comes out of the weight-gradient launch: every parameter gradient is OVERWRITTEN by its
+        # (single) producer unless accumulating -- the same mode for both
+        db = grad_flat(bias) if bias is not None else None
         if queued:
-            _wgrad_queue.add(dy, x, g2d(weight))
-
-        acc = state_of(weight).grad_accumulate   # every parameter gradient is OVERWRITTEN by its (single) producer unless accumulating
-
-        if not queued:
-            on_wgrad_stream(lambda: gemm_tn_f32(dy, x, g2d(weight), wgrad_mode(weight)), dy, x, owner=weight)
-        if bias is not None:
-            on_wgrad_stream(lambda: colsum(dy, grad_flat(bias), acc), dy, owner=weight, small=True)
+            _wgrad_queue.add(dy, x, g2d(weight), db)
+        else:
+            on_wgrad_stream(lambda: gemm_tn_f32(dy, x, g2d(weight), wgrad_mode(weight), dbias=db), dy, x, owner=weight)
         if not need_dx:
             return None
+        if geglu_u is not None:
+            if dx_add is not None:
+                raise ValueError("linear bwd: geglu_u and dx_add are exclusive")
+            M, N = dy.shape
+            K = weight.shape[1]
+            _check2d(geglu_u, "geglu_u")
+            if geglu_u.shape != (M, 2 * K):
+                raise ValueError(f"linear bwd: geglu_u must be [{M}, {2 * K}], got {tuple(geglu_u.shape)}")
+            du = torch.empty(M, 2 * K, dtype=BF16, device=dy.device)
+            wq = w2d(weight)
+            call("nk_linear_dgrad_geglu", dy.data_ptr(), wq.data_ptr(), geglu_u.data_ptr(), du.data_ptr(), M, N, K, dy.stride(0), wq.stride(0),
+                 geglu_u.stride(0), du.stride(0), _stream())
+            return du
         return gemm_nn(dy, w2d(weight), dx_add)
 
     return y, bwd
@@ -519,13 +540,13 @@ def groupnorm_sums(x: Img, groups: int) -> Tensor:
 
 def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, padding=1, upsample: bool = False,
                rowvec: Optional[Tensor] = None, residual: Optional[Tensor] = None, need_dx: bool = True,
-               asym_pad: bool = False, gn=None, stats_groups: Optional[int] = None):
+               asym_pad: bool = False, stats_groups: Optional[int] = None, cin_real: Optional[int] = None):
     """nn.Conv2d forward on channels-last data as implicit GEMM.
     padding: int (symmetric) ; asym_pad=True reproduces ConstantPad2d((0,1,0,1)) + padding 0 (model.py:71-79).
     rowvec: bf16 [N, Cout] added to every pixel of image n (ResBlock emb_out); residual: bf16 [N*Ho*Wo, Cout].
-    gn = (GroupNorm module, silu): the convolution reads silu?(GroupNorm(x)) -- fused into the kernel where the halo-tile kernel takes
-    the shape (the normalised tensor is never written), otherwise a GroupNorm launch in front.  Forward-only: bwd raises.
     stats_groups = G: the output Img carries `.sums` (its GroupNorm sums over G groups) when the kernel can emit them.
+    cin_real = 3 | 4: x's 8 channels are 3 or 4 real ones plus zero padding (image / latent inputs): the forward of a plain 3 x 3
+    stride-1 convolution then runs as the register-resident FMA kernel instead of a K = 72 implicit GEMM.
     bwd(dy) -> (dx Img | None, d_rowvec | None)."""
     Cout, Cin, KH, KW = weight.shape
     if x.C != Cin:
@@ -544,45 +565,36 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
     _check2d(x.t, "x")
     if not x.t.is_contiguous():
         raise ValueError("conv2d: x must be dense channels-last")
-    gn_groups = gn[0].num_groups if gn is not None else 0
-    tiles = query("nk_conv2d_fused_tiles", C.byref(d), gn_groups, stats_groups or 0) if (gn is not None or stats_groups) else 0
-    if gn is not None and not tiles:
-        # the fused prologue is not available for this shape: the GroupNorm as its own launches, then try the epilogue alone
-        x = groupnorm_fwd(x, gn[0].weight, gn[0].bias, gn[0].num_groups, gn[0].eps, gn[1])[0]
-        gn, gn_groups = None, 0
-        tiles = query("nk_conv2d_fused_tiles", C.byref(d), 0, stats_groups) if stats_groups else 0
-    if gn is not None and stats_groups and not query("nk_conv2d_fused_tiles", C.byref(d), gn_groups, stats_groups):
-        stats_groups = None
+    tiles = query("nk_conv2d_stats_tiles", C.byref(d), stats_groups) if stats_groups else 0
     sums_out = None
     if tiles:
         dev = x.t.device
-        part = torch.empty(x.N, tiles, 2 * stats_groups, dtype=torch.float32, device=dev) if stats_groups else None
-        gsum = groupnorm_sums(x, gn_groups) if gn is not None else None
-        call("nk_conv2d_fwd_fused", C.byref(d), x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
-             _p(gsum), _p(gn[0].weight if gn is not None else None), _p(gn[0].bias if gn is not None else None),
-             float(gn[0].eps) if gn is not None else 0.0, gn_groups, int(bool(gn[1])) if gn is not None else 0, _p(part), stats_groups or 0, _stream())
-        if stats_groups:
-            sums_out = torch.empty(x.N, 2 * stats_groups, dtype=torch.float32, device=dev)
-            ws = _ws(query("nk_groupnorm_sums_ws_floats", x.N, tiles, stats_groups), dev)
-            call("nk_groupnorm_sums_from_parts", part.data_ptr(), sums_out.data_ptr(), ws.data_ptr(), x.N, tiles, stats_groups, _stream())
+        part = torch.empty(x.N, tiles, 2 * stats_groups, dtype=torch.float32, device=dev)
+        call("nk_conv2d_fwd_stats", C.byref(d), x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
+             part.data_ptr(), stats_groups, _stream())
+        sums_out = torch.empty(x.N, 2 * stats_groups, dtype=torch.float32, device=dev)
+        ws = _ws(query("nk_groupnorm_sums_ws_floats", x.N, tiles, stats_groups), dev)
+        call("nk_groupnorm_sums_from_parts", part.data_ptr(), sums_out.data_ptr(), ws.data_ptr(), x.N, tiles, stats_groups, _stream())
+    elif (cin_real in (3, 4) and Cin == 8 and KH == 3 and KW == 3 and stride == 1 and pad_t == 1 and not asym_pad and not upsample and rowvec is None
+          and residual is None and Cout % 4 == 0):
+        call("nk_conv3x3_few_channels_fwd", x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), y.data_ptr(), x.N, x.H, x.W, Cout, cin_real, _stream())
     else:
         call("nk_conv2d_fwd", C.byref(d), x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(), _stream())
     out = Img(y, x.N, Ho, Wo, sums_out)
-    fused_gn = gn is not None
 
     def bwd(dy: Tensor):
-        if fused_gn:
-            raise RuntimeError("conv2d_fwd(gn=...) fused the GroupNorm into the forward kernel and kept no normalised tensor: forward-only")
         _check2d(dy, "dy")
         if not dy.is_contiguous():
             raise ValueError("conv2d bwd: dy must be dense")
         acc = state_of(weight).grad_accumulate
 
         if weight.requires_grad:          # frozen convolutions (the LPIPS trunk) only pass the gradient through
-            on_wgrad_stream(lambda: call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(weight), _stream()),
-                            dy, x.t, owner=weight)
-            if bias is not None:
-                on_wgrad_stream(lambda: colsum(dy, grad_flat(bias), acc), dy, owner=weight, small=True)
+            if bias is not None:       # the bias gradient rides in the weight-gradient launch
+                on_wgrad_stream(lambda: call("nk_conv2d_wgrad_bias", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), grad_flat(bias).data_ptr(),
+                                             wgrad_mode(weight), _stream()), dy, x.t, owner=weight)
+            else:
+                on_wgrad_stream(lambda: call("nk_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.t.data_ptr(), g2d(weight).data_ptr(), wgrad_mode(weight), _stream()),
+                                dy, x.t, owner=weight)
         drow = None
         if rowvec is not None:
             drow32 = torch.empty(x.N, Cout, dtype=torch.float32, device=dy.device)

@@ -61,51 +61,34 @@ def test_halo_matches_gather_and_repeats_bitwise():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("case", [(2, 32, 64, 128, 128, True), (1, 64, 64, 256, 512, False), (2, 16, 32, 320, 320, True), (1, 30, 62, 128, 256, True)])
-def test_halo_fused_groupnorm_prologue_and_statistics_epilogue(case):
-    """conv(silu?(GroupNorm(x))) + residual with the GroupNorm applied inside the kernel, and the output's GroupNorm sums from the
-    epilogue, against the same three steps as separate launches (GroupNorm kernel -> gather convolution -> statistics kernel)."""
+@pytest.mark.parametrize("case", [(2, 32, 64, 128, 128), (1, 64, 64, 256, 512), (2, 16, 32, 320, 320), (1, 30, 62, 128, 256), (4, 32, 32, 1280, 1280)])
+def test_halo_statistics_epilogue(case):
+    """The GroupNorm statistics epilogue: the convolution's output is bit-identical with and without it, the sums it emits are those of
+    the tensor it wrote (against the stand-alone statistics pass), and GroupNorm consumes them instead of its own first pass."""
     from neurosis_amd import ops
     from neurosis_amd.ops import Img
 
-    N, H, W, Cin, Cout, silu = case
+    N, H, W, Cin, Cout = case
     x = Img(dev(rnd(N * H * W, Cin, scale=1.5) + 0.3), N, H, W)
-    norm = torch.nn.GroupNorm(32, Cin, eps=1e-6).cuda()
-    with torch.no_grad():
-        norm.weight.normal_(1.0, 0.2)
-        norm.bias.normal_(0.0, 0.2)
     w = torch.nn.Parameter(ops.conv_weight_param(Cout, Cin, 3, 3).data.normal_(0, (9 * Cin) ** -0.5).cuda(), requires_grad=False)
     bias = torch.randn(Cout, device="cuda")
     res = dev(rnd(N * H * W, Cout))
-
-    os.environ["NK_CONV_HALO"] = "0"
-    try:
-        xn = ops.groupnorm_fwd(x, norm.weight, norm.bias, 32, norm.eps, silu)[0]
-        want = ops.conv2d_fwd(xn, w, bias, residual=res, need_dx=False)[0]
-        assert want.sums is None
-        want_sums = ops.groupnorm_sums(want, 32)
-    finally:
-        os.environ.pop("NK_CONV_HALO", None)
-    got = ops.conv2d_fwd(x, w, bias, residual=res, need_dx=False, gn=(norm, silu), stats_groups=32)[0]
-    assert got.sums is not None, "this shape must take the fused kernel"
-    scale = float(want.t.float().abs().max())
-    assert float((got.t.float() - want.t.float()).abs().max()) <= 2e-2 * scale
-    own = ops.groupnorm_sums(Img(got.t, N, H, W), 32)           # the epilogue's sums are those of the tensor it wrote
-    assert float((got.sums - own).abs().max()) <= 1e-4 * float(own.abs().max())
-    assert float((got.sums - want_sums).abs().max()) <= 2e-2 * float(want_sums.abs().max())
-    # statistics epilogue alone (the UNet's in_layers convolution): same tensor as the plain kernel, bit for bit
-    plain = ops.conv2d_fwd(xn, w, bias, residual=res, need_dx=False)[0]
-    with_stats = ops.conv2d_fwd(xn, w, bias, residual=res, need_dx=False, stats_groups=32)[0]
-    assert torch.equal(plain.t, with_stats.t) and with_stats.sums is not None
-    # and GroupNorm consumes the sums instead of its own statistics pass
-    a = ops.groupnorm_fwd(with_stats, norm.weight[:Cout] if Cout <= Cin else torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda"), 32, 1e-5, True)[0]
-    b = ops.groupnorm_fwd(Img(plain.t, N, H, W), norm.weight[:Cout] if Cout <= Cin else torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda"), 32, 1e-5, True)[0]
+    rowvec = dev(rnd(N, Cout))
+    plain = ops.conv2d_fwd(x, w, bias, rowvec=rowvec, residual=res, need_dx=False)[0]
+    with_stats = ops.conv2d_fwd(x, w, bias, rowvec=rowvec, residual=res, need_dx=False, stats_groups=32)[0]
+    assert plain.sums is None and with_stats.sums is not None, "this shape must take the halo-tile kernel"
+    assert torch.equal(plain.t, with_stats.t)
+    own = ops.groupnorm_sums(Img(plain.t, N, H, W), 32)
+    assert float((with_stats.sums - own).abs().max()) <= 1e-4 * float(own.abs().max())
+    gamma, beta = torch.randn(Cout, device="cuda") * 0.2 + 1.0, torch.randn(Cout, device="cuda") * 0.2
+    a = ops.groupnorm_fwd(with_stats, gamma, beta, 32, 1e-5, True)[0]           # normalisation pass only
+    b = ops.groupnorm_fwd(Img(plain.t, N, H, W), gamma, beta, 32, 1e-5, True)[0]  # statistics pass + normalisation pass
     assert float((a.t.float() - b.t.float()).abs().max()) <= 2e-2 * float(b.t.float().abs().max())
 
 
 def test_vae_encoder_fused_path_equals_unfused_at_real_channel_counts():
-    """The frozen SD/SDXL VAE encoder (128..512 channels) on a 128 x 128 image: GroupNorm prologues / statistics epilogues in the
-    halo-tile convolutions against the separate-launch path (NK_CONV_HALO=0).  Same tolerances as the encoder's golden test."""
+    """The frozen SD/SDXL VAE encoder (128..512 channels) on a 128 x 128 image: halo-tile convolutions with statistics epilogues and
+    apply-only GroupNorms against the gather kernels with full GroupNorms (NK_CONV_HALO=0).  Tolerances of the encoder's golden test."""
     from neurosis_amd.modules.diffusion.model import Encoder
     from tests.util import cosine, rel_err
 
@@ -121,3 +104,35 @@ def test_vae_encoder_fused_path_equals_unfused_at_real_channel_counts():
         os.environ.pop("NK_CONV_HALO", None)
     assert got.shape == want.shape == (2, 4, 16, 16)
     assert rel_err(got, want) <= 3e-2 and cosine(got, want) >= 0.999
+
+
+@pytest.mark.parametrize("case", [(2, 3, 128, 40, 56), (1, 4, 320, 33, 17), (2, 3, 8, 16, 16)])
+def test_few_channel_conv_in(case):
+    """the first convolutions (3 -> 128 of the VAE, 4 -> 320 of the UNet) through nn.Conv2d's channel-padded route: forward on the
+    register-resident FMA kernel, weight / bias gradients on the tile engine as before; against torch's fp32 conv2d"""
+    import torch.nn.functional as F
+
+    from neurosis_amd import nn as nkn, ops
+    from neurosis_amd.ops import Img
+    from tests.util import assert_close
+
+    N, Cin, Cout, H, W = case
+    torch.manual_seed(7)
+    conv = nkn.Conv2d(Cin, Cout, 3, padding=1).cuda()
+    x = rnd(N, Cin, H, W)
+    xt = ops.nchw_to_tokens(dev(x, torch.float32), 8)
+    out, bwd = conv.fwd(Img(xt, N, H, W), need_dx=False)
+    wq = conv.weight.detach().float().cpu().to(torch.bfloat16).float().requires_grad_(True)
+    bq = conv.bias.detach().float().cpu().requires_grad_(True)
+    ref = F.conv2d(x, wq, bq, padding=1)
+    pad = (Cout + 7) // 8 * 8
+    got = out.t.view(N, H, W, pad).permute(0, 3, 1, 2)[:, :Cout]
+    assert_close(got, ref, 2e-2, "few-channel conv fwd")
+    dy = rnd(N, Cout, H, W)
+    ref.backward(dy)
+    dyt = torch.zeros(N, H, W, pad)
+    dyt[..., :Cout] = dy.permute(0, 2, 3, 1)
+    bwd(dev(dyt.reshape(-1, pad)))
+    ops.join_wgrad_stream()
+    assert_close(conv.weight.grad, wq.grad, 1e-2, "few-channel conv wgrad")
+    assert_close(conv.bias.grad, bq.grad, 1e-2, "few-channel conv bias grad")

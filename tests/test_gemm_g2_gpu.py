@@ -85,7 +85,7 @@ def test_g2_batched_wgrad_three_projections_fill_the_chip():
     d_dy, d_x = [dev(t) for t in dys], [dev(t) for t in xs]
     dws = [torch.full((N, K), 3.0, device="cuda") for _ in range(n)]
     arr = C.c_void_p * n
-    ops.call("nk_linear_wgrad_batched", arr(*[t.data_ptr() for t in d_dy]), arr(*[t.data_ptr() for t in d_x]), arr(*[t.data_ptr() for t in dws]), n, M, N, K,
+    ops.call("nk_linear_wgrad_batched", arr(*[t.data_ptr() for t in d_dy]), arr(*[t.data_ptr() for t in d_x]), arr(*[t.data_ptr() for t in dws]), None, n, M, N, K,
              N, K, K, 0, ops._stream())
     for dy, x, dw in zip(dys, xs, dws):
         assert_close(dw, dy.t() @ x, TOL_F32, "g2 batched wgrad")

@@ -73,6 +73,26 @@ def test_linear_wgrad(ops, M, N, K):
     assert_close(dw, 2 * ref, TOL_F32, "linear_wgrad accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 200, 320), (4096, 1280, 1280), (4096, 10240, 1280), (308, 1280, 2048), (16384, 640, 640), (4, 1280, 320)])
+def test_linear_wgrad_with_fused_bias_gradient(ops, M, N, K):
+    """nk_linear_wgrad_bias: the bias gradient (column sums of dy) from the weight-gradient launch itself -- the ring kernel (<= 256 tiles),
+    the data-parallel kernel (800 tiles), split-K grids (tiny outputs: fp32 atomics) -- overwrite and accumulate; the weight gradient is
+    unchanged bit for bit."""
+    dy, x = rnd(M, N), rnd(M, K)
+    dyd, xd = dev(dy), dev(x)
+    dw_plain = torch.full((N, K), 7.0, device="cuda")
+    ops.gemm_tn_f32(dyd, xd, dw_plain, False)
+    dw, db = torch.full((N, K), 7.0, device="cuda"), torch.full((N,), -3.0, device="cuda")
+    ops.gemm_tn_f32(dyd, xd, dw, False, dbias=db)
+    assert_close(dw, dy.t() @ x, TOL_F32, "wgrad")
+    if M * 0 + N * K >= 96 * 128 * 128:     # no K split: deterministic, identical to the launch without the bias sum
+        assert torch.equal(dw, dw_plain)
+    assert_close(db, dy.sum(0), TOL_F32, "fused bias gradient (store)")
+    ops.gemm_tn_f32(dyd, xd, dw, True, dbias=db)
+    assert_close(db, 2 * dy.sum(0), TOL_F32, "fused bias gradient (accumulate)")
+    assert_close(dw, 2 * (dy.t() @ x), TOL_F32, "wgrad accumulate")
+
+
 @pytest.mark.parametrize("M,N,K,count", [(1024, 256, 384, 3), (64, 128, 128, 8), (4096, 1280, 1280, 3)])
 def test_linear_wgrad_batched(ops, M, N, K, count, monkeypatch):
     """`count` same-shape weight gradients in one launch (blockIdx.z) == the launches one by one; also through the queue."""
@@ -80,13 +100,16 @@ def test_linear_wgrad_batched(ops, M, N, K, count, monkeypatch):
     dys, xs = [rnd(M, N) for _ in range(count)], [rnd(M, K) for _ in range(count)]
     q = ops.WgradQueue()
     dws = [torch.full((N, K), 3.0, device="cuda") for _ in range(count)]
-    for dy, x, dw in zip(dys, xs, dws):
-        q.add(dev(dy), dev(x), dw)
+    dbs = [torch.full((N,), 5.0, device="cuda") if i != 1 else None for i in range(count)]      # (the second layer has no bias)
+    for dy, x, dw, db in zip(dys, xs, dws, dbs):
+        q.add(dev(dy), dev(x), dw, db)
     q.add(dev(rnd(M, 2 * N)), dev(rnd(M, K)), torch.zeros(2 * N, K, device="cuda"))  # an odd shape rides along unbatched
     q.flush()
     ops.join_wgrad_stream()
-    for dy, x, dw in zip(dys, xs, dws):
+    for dy, x, dw, db in zip(dys, xs, dws, dbs):
         assert_close(dw, dy.t() @ x, TOL_F32, "linear_wgrad_batched")
+        if db is not None:
+            assert_close(db, dy.sum(0), TOL_F32, "linear_wgrad_batched bias gradient")
 
 
 def test_colsum(ops):
@@ -232,6 +255,27 @@ def test_layernorm(ops, M, C):
     assert_close(dx, x.grad + extra, TOL_BF16, "ln dx")
     assert_close(w.grad, gr.grad, TOL_F32, "ln dgamma")
     assert_close(b.grad, br.grad, TOL_F32, "ln dbeta")
+
+
+@pytest.mark.parametrize("M,N,I", [(300, 320, 1280), (4096, 1280, 5120), (1000, 136, 264)])
+def test_feedforward_out_dgrad_with_fused_geglu_backward(ops, M, N, I):
+    """nk_linear_dgrad_geglu: the input gradient of FeedForward.net[2] with the GEGLU backward in the GEMM's epilogue, against autograd
+    of (a * gelu(g)) @ W^T on the CPU (ragged M / N / I, the real 1280-wide shape) and against the two separate launches."""
+    u = rnd(M, 2 * I).requires_grad_(True)
+    w = rnd(N, I, scale=I ** -0.5)
+    dy = rnd(M, N)
+    a, g = u.chunk(2, dim=-1)
+    ((a * F.gelu(g)) @ w.t()).backward(dy)
+    ud, wd, dyd = dev(u.detach()), dev(w), dev(dy)
+    x = ops.geglu_fwd(ud)[0]
+    weight = torch.nn.Parameter(wd.float())
+    y, bwd = ops.linear_fwd(x, weight, None)
+    fused = bwd(dyd, geglu_u=ud)
+    ops.join_wgrad_stream()
+    assert fused.shape == (M, 2 * I)
+    assert_close(fused, u.grad, TOL_BF16, "fused geglu bwd")
+    separate = ops.geglu_fwd(ud)[1](ops.gemm_nn(dyd, ops.w2d(weight)))
+    assert_close(fused, separate.float().cpu(), TOL_BF16, "fused vs separate")
 
 
 def test_geglu_silu_add_cat(ops):

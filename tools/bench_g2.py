@@ -36,7 +36,7 @@ M, N, K, n = 4096, 1280, 1280, 3
 dys, xs, dws = [rb(M, N) for _ in range(n)], [rb(M, K) for _ in range(n)], [torch.zeros(N, K, device="cuda") for _ in range(n)]
 arr = C.c_void_p * n
 def batched():
-    ops.call("nk_linear_wgrad_batched", arr(*[t.data_ptr() for t in dys]), arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in dws]), n, M, N, K, N, K, K, 0, ops._stream())
+    ops.call("nk_linear_wgrad_batched", arr(*[t.data_ptr() for t in dys]), arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in dws]), None, n, M, N, K, N, K, K, 0, ops._stream())
 t0, t2 = time_modes(batched)
 fl = 2.0 * M * N * K * n
 print(f"{'wgradx3':6s} {M:6d} {N:6d} {K:6d}   {t0:8.1f} {t2:8.1f}   {fl/t0/1e6:7.0f} {fl/t2/1e6:7.0f}  {t0/t2:5.2f}")
