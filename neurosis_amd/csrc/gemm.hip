@@ -831,6 +831,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
   constexpr int NWN = NW == 4 ? 2 : 4, BPW = 4 / NWN;         // waves sharing the same rows; row blocks per wave
   float* const dbias = CAN_BIAS ? (p.nbatch ? p.dbias_b[blockIdx.z] : p.dbias) : nullptr;
   const bool do_bias = CAN_BIAS && dbias != nullptr && nt == 0;
+  const int wn_s = __builtin_amdgcn_readfirstlane(wn);
   float4_t accb[BPW];
 #pragma unroll
   for (int u = 0; u < BPW; ++u) accb[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -879,11 +880,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
     if constexpr (CAN_BIAS) {
       if (do_bias) {
+        // (the row block is chosen by a wave-uniform switch over COMPILE-TIME indices: af[ks][wn] with a run-time wn would put the
+        // fragment array in scratch memory -- measured: weight gradients at 90 TFLOP/s)
+        const bf16x8_t ones = nk_ones_frag();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int u = 0; u < BPW; ++u)
-            accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][wn * BPW + u], nk_ones_frag(), accb[u], 0, 0, 0);
+        for (int u = 0; u < BPW; ++u) {
+          switch (wn_s * BPW + u) {
+            case 0: accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][0], ones, accb[u], 0, 0, 0); accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][0], ones, accb[u], 0, 0, 0); break;
+            case 1: accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][1], ones, accb[u], 0, 0, 0); accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][1], ones, accb[u], 0, 0, 0); break;
+            case 2: accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][2], ones, accb[u], 0, 0, 0); accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][2], ones, accb[u], 0, 0, 0); break;
+            default: accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][3], ones, accb[u], 0, 0, 0); accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][3], ones, accb[u], 0, 0, 0); break;
+          }
+        }
       }
     }
   }
@@ -1029,9 +1037,14 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
     if constexpr (CAN_BIAS) {
-      if (do_bias) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][wn], nk_ones_frag(), accb, 0, 0, 0);
+      if (do_bias) {     // (compile-time fragment indices behind a wave-uniform switch: see nk_gemm_dma_kernel)
+        const bf16x8_t ones = nk_ones_frag();
+        switch (__builtin_amdgcn_readfirstlane(wn)) {
+          case 0: accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][0], ones, accb, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][0], ones, accb, 0, 0, 0); break;
+          case 1: accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][1], ones, accb, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][1], ones, accb, 0, 0, 0); break;
+          case 2: accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][2], ones, accb, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][2], ones, accb, 0, 0, 0); break;
+          default: accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][3], ones, accb, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][3], ones, accb, 0, 0, 0); break;
+        }
       }
     }
     if (++cur_stage == RING_NS) cur_stage = 0;

@@ -413,7 +413,8 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
     if constexpr (CAN_BIAS) {
       if (do_bias) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nk_ones_frag(), af[ks * 2 + grp], accb, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks)     // (grp is wave-uniform: a select between two compile-time fragments, not an indexed array)
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nk_ones_frag(), grp ? af[ks * 2 + 1] : af[ks * 2], accb, 0, 0, 0);
       }
     }
 #else

@@ -1,0 +1,135 @@
+"""BASELINE configs 4 and 5 at THEIR OWN sizes, in the test suite (round-2 verdict: they existed only as builder-run benches).
+
+Config 4 -- SDXL aspect-bucketed mixed resolution: whole training steps of `bench.build_engine` at 832 x 1216 and 1216 x 832 (two of
+the SDXLBucketList shapes, /root/reference/src/neurosis/dataset/aspect/lists.py:14-56), batch 4: finite, the forward is bit-reproducible,
+the hipGraph replay of the UNet chain equals the eager launches bit for bit, every parameter receives a gradient.
+
+Config 5 -- AutoencoderKL training at 256^2, batch 4, reconstruction + LPIPS + PatchGAN through `AutoencodingEngine.training_step`
+(/root/reference/src/neurosis/models/autoencoder.py:280-293) configured by the reference's loss CLASS
+(neurosis_amd.modules.autoencoding.losses.GeneralLPIPSWithDiscriminator): finite, the two optimizers alternate, and a batch-1 slice of
+the generator-side loss agrees with the CPU oracle's autograd restatement (loss 2e-2, nll 1e-2, reconstruction 3e-2 / cosine 0.999,
+sampled gradients cosine >= 0.98 -- the tolerances of the tiny-fixture tests, here at the real channel counts).
+"""
+import os
+
+import pytest
+import torch
+
+from tests.util import cosine, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sdxl_engine():
+    import bench
+
+    eng = bench.build_engine(torch.device("cuda", 0))
+    yield eng
+    del eng
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("hw", [(1216, 832), (832, 1216)])       # (H, W): the tallest and the widest of the ~1024^2-pixel buckets
+def test_config4_mixed_resolution_step_at_batch_4(sdxl_engine, hw, monkeypatch):
+    import bench
+
+    eng = sdxl_engine
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(11 + hw[0])
+    batch = bench.synthetic_batch(dev, 4, hw, gen)
+    sig = torch.tensor([0.25, 0.9, 3.0, 11.0], device=dev)
+    latents = eng.encode_first_stage(batch["image"])
+    assert latents.shape == (4, 4, hw[0] // 8, hw[1] // 8) and bool(torch.isfinite(latents).all())
+    noise = torch.randn(latents.shape, device=dev, generator=gen)
+
+    def run():
+        eng.store.grad.zero_()
+        loss = eng(latents, batch, sigmas=sig, noise=noise)
+        loss.mean().backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), eng.store.grad.clone()
+
+    # eager launches (NK_GRAPH=0), twice: bit-reproducible forward
+    monkeypatch.setenv("NK_GRAPH", "0")
+    l_eager, g_eager = run()
+    l_eager2, _ = run()
+    assert bool(torch.isfinite(l_eager).all()) and torch.equal(l_eager, l_eager2)
+    assert bool(torch.isfinite(g_eager).all())
+    dead = [n for n, p in eng.model.diffusion_model.named_parameters() if float(p.grad.abs().max()) == 0.0]
+    assert not dead, dead[:5]
+    # hipGraph replay of the UNet chain (captured on the second step of a signature, replayed from the third): the same kernels on the
+    # same buffers -- loss bit-identical, gradients identical except the few split-K weight gradients summed by fp32 atomics
+    monkeypatch.delenv("NK_GRAPH")
+    for _ in range(3):
+        l_graph, g_graph = run()
+    assert torch.equal(l_graph, l_eager)
+    assert float((g_graph - g_eager).norm() / g_eager.norm()) <= 1e-3
+    eng.optimizer_step(lr=1e-6)
+    eng.join_optimizer()
+    assert bool(torch.isfinite(eng.store.master).all())
+
+
+def _vae_full(loss):
+    from neurosis_amd.models.autoencoder import AutoencodingEngine, DiagonalGaussianRegularizer
+    from neurosis_amd.modules.diffusion.model import Decoder, Encoder
+
+    import bench
+
+    dd = dict(bench.SDXL_VAE_DD)
+    torch.manual_seed(21)
+    eng = AutoencodingEngine(encoder=Encoder(**dd), decoder=Decoder(**dd), loss=loss, regularizer=DiagonalGaussianRegularizer(sample=True))
+    return dd, eng
+
+
+def test_config5_autoencoder_training_256_batch_4_with_lpips_and_patchgan():
+    from neurosis_amd.modules.autoencoding.losses import GeneralLPIPSWithDiscriminator
+    from oracle import patchgan_oracle as PO
+    from tests.test_lpips_cpu import trunk_weights
+
+    lfx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "lpips_vgg_tiny.pt"), weights_only=False)
+    loss = GeneralLPIPSWithDiscriminator(disc_start=0, disc_factor=0.5, disc_weight=0.8, perceptual_weight=0.6, logvar_init=0.1, rec_weight=1.2,
+                                         lpips_kwargs=dict(pnet_type="vgg", lin_weights=lfx["lin"]))
+    loss.perceptual_loss.load_state_dict(trunk_weights(), strict=False)          # synthetic trunk (the ImageNet weights are a download)
+    dd, eng = _vae_full(loss)
+    eng = eng.cuda().train()
+    eng.setup_flat_params()
+    assert eng.discriminator is loss.discriminator and eng.perceptual_loss is loss.perceptual_loss and eng.logvar is loss.logvar
+    assert any(k.startswith("loss.discriminator.") for k in eng.state_dict()) and not any(k.startswith("discriminator.") for k in eng.state_dict())
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(4, 3, 256, 256, generator=g) * 2 - 1)
+    noise = torch.randn(4, 4, 32, 32, generator=g)
+    batch = {"image": x.cuda()}
+
+    # (a) batch-1 slice of the generator-side loss against the CPU oracle's autograd (same weights, image, posterior noise)
+    sd = {k: v.detach().float().cpu().clone() for k, v in eng.state_dict().items()}
+    enc = {k[len("encoder."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    dec = {k[len("decoder."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    dsd = {k[len("loss.discriminator."):]: v for k, v in sd.items() if k.startswith("loss.discriminator.")}
+    loss_ref, nll_ref, g_ref, dw_ref, xrec_ref = PO.generator_adversarial_loss(enc, dec, dsd, dd, x[:1], noise[:1], rec_weight=1.2, logvar=0.1, disc_factor=0.5,
+                                                                               disc_weight=0.8, lpips=(trunk_weights(), lfx["lin"]), perceptual_weight=0.6)
+    loss_ref.backward()
+    l1, _, xrec1, log1 = eng.loss_and_backward(x[:1].cuda(), noise=noise[:1].cuda())
+    assert rel_err(xrec1, xrec_ref) <= 3e-2 and cosine(xrec1, xrec_ref) >= 0.999
+    assert abs(float(log1["nll_loss"]) - float(nll_ref)) <= 1e-2 * abs(float(nll_ref))
+    assert abs(float(log1["d_weight"]) - float(dw_ref)) <= 0.15 * float(dw_ref)
+    assert abs(float(l1) - float(loss_ref)) <= 2e-2 * abs(float(loss_ref))
+    grads = dict(eng.named_parameters())
+    for key, ref in (("decoder.conv_out.weight", dec["conv_out.weight"]), ("decoder.conv_in.weight", dec["conv_in.weight"]),
+                     ("decoder.up.1.block.0.conv1.weight", dec["up.1.block.0.conv1.weight"]), ("encoder.conv_in.weight", enc["conv_in.weight"]),
+                     ("encoder.down.2.block.1.conv2.weight", enc["down.2.block.1.conv2.weight"])):
+        assert cosine(grads[key].grad, ref.grad) >= 0.98, (key, cosine(grads[key].grad, ref.grad))
+
+    # (b) batch 4 through training_step: the optimizers alternate by batch index (autoencoder.py:280-293), everything stays finite
+    ae0, d0 = eng.store.master.clone(), eng.disc_store.master.clone()
+    la = eng.training_step(batch, 0, lr=1e-4, noise=noise.cuda())
+    assert "train/loss/rec" in eng.last_log and float((eng.store.master - ae0).abs().max()) > 0 and torch.equal(eng.disc_store.master, d0)
+    ae1 = eng.store.master.clone()
+    ld = eng.training_step(batch, 1, lr=1e-4, noise=noise.cuda())
+    assert "train/loss/disc" in eng.last_log and torch.equal(eng.store.master, ae1) and float((eng.disc_store.master - d0).abs().max()) > 0
+    for i in range(2, 6):
+        eng.training_step(batch, i, lr=1e-4, noise=noise.cuda())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(la)) and bool(torch.isfinite(ld)) and eng.global_step == 6
+    assert bool(torch.isfinite(eng.store.master).all()) and bool(torch.isfinite(eng.disc_store.master).all())
+    assert float(eng.last_log["train/p_loss"]) > 0 if "train/p_loss" in eng.last_log else True
