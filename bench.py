@@ -325,6 +325,9 @@ def main():
     ap.add_argument("--wire-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: dtype of the gradient all-reduce (fp32 = what Lightning DDP exchanges for the reference's fp32 parameters; "
                          "bf16 halves the bytes on xGMI and sums in bf16)")
+    ap.add_argument("--dp-mode", choices=["allreduce", "rs_ag"], default=os.environ.get("NK_DP_MODE", "allreduce"),
+                    help="N > 1: allreduce = flat all-reduce of every gradient slice, the whole optimizer on every rank (default, what Lightning DDP does); "
+                         "rs_ag = slices reduced to tensor-aligned owner shards, optimizer on the owned shard, bf16 shadows gathered (neurosis_amd/dp.py)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
@@ -354,7 +357,11 @@ def main():
     unet = eng.model.diffusion_model
     if args.optimizer == "adafactor":
         eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)   # configs/sdxl/sdxl.example.yaml:158-164
-    dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if args.wire_dtype == "bf16" else None) if world > 1 else None
+    dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if args.wire_dtype == "bf16" else None, mode=args.dp_mode) if world > 1 else None
+    if dp is not None and dp.sharded:
+        if args.optimizer != "adafactor":
+            raise SystemExit("--dp-mode rs_ag needs --optimizer adafactor (the chunked fused optimizer)")
+        dp.attach_optimizer(eng.adafactor)
     if args.serialize:
         eng.store.state.wgrad_stream = None
         eng.overlap_optimizer = False
@@ -390,7 +397,7 @@ def main():
                 e2 = torch.cuda.Event(enable_timing=True)
                 e2.record()
                 comm_marks.append((e1, e2) + dp.reducer.take_timing())
-        eng.optimizer_step(lr=1e-6, weight_decay=1e-2, grad_scale=gs)
+        eng.optimizer_step(lr=1e-6, weight_decay=1e-2, grad_scale=gs, dp=dp)
         return loss
 
     def barrier():
@@ -418,6 +425,7 @@ def main():
     gc.freeze()
     if dp is not None:
         dp.reducer.record_timing = True
+        dp.reducer.take_counts()       # count the timed steps' collectives only
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -438,7 +446,18 @@ def main():
         exposed = [a.elapsed_time(b) for a, b, _, _ in comm_marks]
         span = [f.elapsed_time(l) for _, _, f, l in comm_marks if f is not None and l is not None]
         nbytes = eng.store.grad.numel() * (2 if args.wire_dtype == "bf16" else eng.store.grad.element_size())
-        comm = {"allreduce_bytes_per_step": nbytes, "exposed_ms_mean": round(sum(exposed) / len(exposed), 2),
+        ncoll, wire = dp.reducer.take_counts()
+        nsteps_counted = max(len(comm_marks), 1)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        except Exception:  # noqa: BLE001 - version query only
+            rccl = None
+        devices = [None] * world
+        dist.all_gather_object(devices, f"{torch.cuda.get_device_name(device)} #{torch.cuda.current_device()} pid {os.getpid()}")
+        comm = {"world_size": world, "backend": dist.get_backend(), "rccl_version": rccl, "devices": devices, "mode": dp.mode,
+                "wire_dtype": args.wire_dtype, "collectives_per_step": round(ncoll / nsteps_counted, 1),
+                "bytes_sent_per_rank_per_step": int(wire / nsteps_counted),
+                "allreduce_bytes_per_step": nbytes, "exposed_ms_mean": round(sum(exposed) / len(exposed), 2),
                 "first_to_last_collective_ms_mean": round(sum(span) / max(len(span), 1), 2) if span else None,
                 "busbw_GBps_over_span": round(nbytes * 2 * (world - 1) / world / (sum(span) / len(span) * 1e-3) / 1e9, 1) if span else None,
                 "note": "exposed = compute stream stalled between end of backward and end of the flat all-reduce; span includes the backward the exchange overlaps"}

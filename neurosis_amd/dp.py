@@ -6,6 +6,18 @@ registration order, and the UNet's explicit backward finalises them from the bac
 top-level block by block.  After each block the wrapper reduces that block's slice on a side stream, so the
 exchange overlaps the rest of the backward; only the last slices (input blocks, time/label embeddings -- the
 "backward tail") are exposed.  The mean over ranks is applied as grad_scale = 1/world in the fused optimizer.
+
+Two exchange modes (NK_DP_MODE, or FlatDataParallel(mode=...)):
+
+  allreduce (default)  every slice is all-reduced; every rank runs the whole optimizer.  What Lightning DDP does for the reference.
+  rs_ag                the sharded form SURVEY 5 / 8(e) describes: the flat buffers are cut into `world` contiguous, TENSOR-ALIGNED shards
+                       (factored Adafactor statistics never cross a shard); a slice's elements are REDUCED TO THEIR OWNER only
+                       (reduce-scatter at tensor granularity), the owner runs the fused optimizer on its shard (1/world of the update:
+                       11.4 -> ~1.4 ms per rank at 8 ranks for SDXL), and the new bf16 shadows -- all the next forward needs -- are
+                       gathered (each rank broadcasts its shard).  fp32 bytes in + bf16 bytes out: 25 % fewer bytes per link than the
+                       all-reduce.  The fp32 MASTERS of foreign shards go stale; `sync_masters()` gathers them where they are needed
+                       (checkpoints, EMA swaps).  Built and tested with gloo (world 2, CPU and two ranks on one GPU); not yet measured
+                       on RCCL, so not the default.
 """
 from __future__ import annotations
 
@@ -20,12 +32,19 @@ class FlatGradReducer:
     """Sums slices [lo, hi) of a flat gradient tensor across ranks, asynchronously when the tensor is on a GPU.
     Device-agnostic so the exchange logic is testable with gloo on CPU."""
 
-    def __init__(self, flat_grad: Tensor, group=None, wire_dtype: Optional[torch.dtype] = None, max_chunk: int = 1 << 28):
+    def __init__(self, flat_grad: Tensor, group=None, wire_dtype: Optional[torch.dtype] = None, max_chunk: int = 1 << 28,
+                 owner_bounds: Optional[list] = None):
+        """owner_bounds: None = all-reduce every slice; else element offsets [0 = e_0 <= e_1 <= ... <= e_world = numel]: rank r owns
+        [e_r, e_r+1) and a slice is reduced TO ITS OWNERS only (the other ranks' copies of it are left unspecified)."""
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.wire_dtype = wire_dtype
         self.max_chunk = max_chunk
+        self.owner_bounds = owner_bounds
+        self.collectives = 0           # collective calls issued since take_counts()
+        self.wire_bytes = 0            # bytes each rank sends for them: all-reduce 2 (N-1)/N x payload, reduce / broadcast (N-1)/N x payload
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.pending = []
@@ -51,23 +70,42 @@ class FlatGradReducer:
             if self.record_timing and self.ev_first is None:
                 self.ev_first = torch.cuda.Event(enable_timing=True)
                 self.ev_first.record(self.stream)
-        for a in range(lo, hi, self.max_chunk):
-            b = min(hi, a + self.max_chunk)
-            sl = self.flat[a:b]
-            if self.cuda:
-                with torch.cuda.stream(self.stream):
-                    self._reduce(sl)
-            else:
-                self._reduce(sl)
-            self.reduced_elems += b - a
+        pieces = [(lo, hi, None)]
+        if self.owner_bounds is not None:      # cut the slice at the shard boundaries: each piece goes to one owner
+            pieces = []
+            for r in range(self.world):
+                a, b = max(lo, self.owner_bounds[r]), min(hi, self.owner_bounds[r + 1])
+                if b > a:
+                    pieces.append((a, b, r))
+        for plo, phi, owner in pieces:
+            for a in range(plo, phi, self.max_chunk):
+                b = min(phi, a + self.max_chunk)
+                sl = self.flat[a:b]
+                if self.cuda:
+                    with torch.cuda.stream(self.stream):
+                        self._reduce(sl, owner)
+                else:
+                    self._reduce(sl, owner)
+                self.reduced_elems += b - a
 
-    def _reduce(self, sl: Tensor) -> None:
-        if self.wire_dtype is not None and self.wire_dtype != sl.dtype:
-            tmp = sl.to(self.wire_dtype)
-            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
-            sl.copy_(tmp)
+    def _reduce(self, sl: Tensor, owner: Optional[int] = None) -> None:
+        wire = sl if self.wire_dtype is None or self.wire_dtype == sl.dtype else sl.to(self.wire_dtype)
+        self.collectives += 1
+        self.wire_bytes += int(wire.numel() * wire.element_size() * (2 if owner is None else 1) * (self.world - 1) / self.world)
+        if owner is None or (wire.is_cuda and dist.get_backend(self.group) == "gloo"):
+            # (gloo has no reduce for device tensors: the on-GPU rehearsal of the sharded mode all-reduces, which gives the owner the same sum)
+            dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
         else:
-            dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group)
+            dst = dist.get_global_rank(self.group, owner) if self.group is not None else owner
+            dist.reduce(wire, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+        if wire is not sl and (owner is None or owner == self.rank):
+            sl.copy_(wire)
+
+    def take_counts(self):
+        """(collective calls, bytes sent per rank) since the last call"""
+        c = (self.collectives, self.wire_bytes)
+        self.collectives = self.wire_bytes = 0
+        return c
 
     def finish(self) -> None:
         """Make the compute stream wait for every outstanding reduction."""
@@ -89,11 +127,23 @@ class FlatGradReducer:
 class FlatDataParallel:
     """Wires a FlatGradReducer to a UNetModel's backward through `grad_ready_hook`."""
 
-    def __init__(self, unet: nn.Module, store, group=None, wire_dtype: Optional[torch.dtype] = None, broadcast_params: bool = True):
-        self.unet, self.store = unet, store
-        self.reducer = FlatGradReducer(store.grad, group, wire_dtype)
+    def __init__(self, unet: nn.Module, store, group=None, wire_dtype: Optional[torch.dtype] = None, broadcast_params: bool = True,
+                 mode: Optional[str] = None):
+        import os
+
+        self.unet, self.store, self.group = unet, store, group
+        self.mode = mode or os.environ.get("NK_DP_MODE", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError(f"FlatDataParallel: mode must be 'allreduce' or 'rs_ag', got {self.mode!r}")
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.owner_bounds = self.tensor_bounds = None
+        if self.mode == "rs_ag" and world > 1:
+            self.tensor_bounds, self.owner_bounds = shard_bounds(store, world)
+        self.reducer = FlatGradReducer(store.grad, group, wire_dtype, owner_bounds=self.owner_bounds)
         self.world = self.reducer.world
+        self.rank = self.reducer.rank
         self.sync = True
+        self._optimizers = []
         if broadcast_params and self.world > 1:
             dist.broadcast(store.master, src=0, group=group)
             store.refresh()
@@ -124,3 +174,62 @@ class FlatDataParallel:
         """Wait for the exchange; returns the grad_scale (1/world) the optimizer must apply for the mean."""
         self.reducer.finish()
         return 1.0 / self.world
+
+    # -- rs_ag: the optimizer runs on the owned shard only; shadows are gathered afterwards ------------------------------------------
+    @property
+    def sharded(self) -> bool:
+        return self.owner_bounds is not None
+
+    def owned_tensors(self) -> tuple[int, int]:
+        """[lo, hi) indices into store.params of this rank's shard (all of them when not sharded)"""
+        if not self.sharded:
+            return (0, len(self.store.params))
+        return (self.tensor_bounds[self.rank], self.tensor_bounds[self.rank + 1])
+
+    def attach_optimizer(self, flat_optimizer) -> None:
+        """Restrict a chunked flat optimizer (optim.FlatAdafactor) to this rank's shard.  No-op in all-reduce mode."""
+        if self.sharded:
+            flat_optimizer.restrict(*self.owned_tensors())
+            self._optimizers.append(flat_optimizer)
+
+    def after_optimizer_step(self) -> None:
+        """rs_ag: every rank broadcasts the bf16 shadows of its shard (what the next forward reads), on the CURRENT stream -- call it
+        where the optimizer kernels were issued (DiffusionEngine.optimizer_step does, on its optimizer stream)."""
+        if not self.sharded:
+            return
+        for r in range(self.world):
+            a, b = self.owner_bounds[r], self.owner_bounds[r + 1]
+            if b > a:
+                src = dist.get_global_rank(self.group, r) if self.group is not None else r
+                dist.broadcast(self.store.shadow[a:b], src=src, group=self.group)
+                self.reducer.collectives += 1
+                self.reducer.wire_bytes += int((b - a) * self.store.shadow.element_size() * (self.world - 1) / self.world)
+        self.store._mark_fresh()
+
+    def sync_masters(self) -> None:
+        """rs_ag: gather the fp32 masters of every shard (checkpoints, EMA swaps, anything that reads parameters other than through the
+        bf16 shadows).  The shadows are already current."""
+        if not self.sharded:
+            return
+        for r in range(self.world):
+            a, b = self.owner_bounds[r], self.owner_bounds[r + 1]
+            if b > a:
+                src = dist.get_global_rank(self.group, r) if self.group is not None else r
+                dist.broadcast(self.store.master[a:b], src=src, group=self.group)
+        for o in self.store.listeners:
+            o.masters_changed()
+
+
+def shard_bounds(store, world: int):
+    """Cut store.params into `world` contiguous groups of about equal element count.  Returns (tensor index bounds, element offset
+    bounds), each of length world + 1.  Shards begin at tensor boundaries: factored second moments and per-tensor RMS stay local."""
+    offs = list(store.offsets) + [store.numel]
+    total = store.numel
+    tb = [0]
+    for r in range(1, world):
+        target = total * r // world
+        # the tensor boundary nearest to the target, not before the previous bound
+        best = min(range(tb[-1], len(store.params) + 1), key=lambda t: abs(offs[t] - target))
+        tb.append(best)
+    tb.append(len(store.params))
+    return tb, [offs[t] for t in tb]

@@ -305,16 +305,24 @@ class DiffusionEngine(nn.Module):
         self.model_ema = FlatEma(self.store, decay, use_num_updates, names=[by_id[id(p)] for p in self.store.params])
         return self.model_ema
 
-    def optimizer_step(self, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
+    def optimizer_step(self, lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0,
+                       dp=None) -> None:
         """One parameter update on the flat buffers (gradients are not cleared: the next backward overwrites them): the configured Adafactor if
         configure_adafactor() was called (its own hyper-parameters; only grad_scale is used), else fused flat AdamW.
 
         The update is HBM-bound (2.6 G parameters: ~13 ms) and the next step begins with ~30 ms that never touch the UNet's weights
         (frozen VAE encoder: MFMA-bound convolutions; frozen conditioner: launch latency).  So the update is issued on a second stream
         behind the backward, and the main stream only waits for it where the UNet forward starts (`join_optimizer`, called by
-        `forward`, `sample`, `ema_scope` and `state_dict`): the two overlap instead of queueing.  NK_OPT_OVERLAP=0 keeps it in line."""
+        `forward`, `sample`, `ema_scope` and `state_dict`): the two overlap instead of queueing.  NK_OPT_OVERLAP=0 keeps it in line.
+
+        dp: the FlatDataParallel wrapper when its exchange is SHARDED (mode rs_ag): this rank's optimizer then updates its own shard only
+        (dp.attach_optimizer) and the ranks' new bf16 shadows are gathered right behind the update, on the same stream."""
         if self.store is None:
             raise RuntimeError("call setup_flat_params() first")
+        sharded = dp is not None and getattr(dp, "sharded", False)
+        if sharded and (getattr(self, "model_ema", None) is not None or getattr(self, "adafactor", None) is None or self._streaming_step):
+            raise NotImplementedError("the sharded exchange (NK_DP_MODE=rs_ag) needs the fused Adafactor and supports neither EMA (its update reads "
+                                      "every fp32 master) nor the streamed update")
         overlap = self.overlap_optimizer and self.store.master.is_cuda
         scope = nullcontext()
         if overlap:
@@ -342,6 +350,8 @@ class DiffusionEngine(nn.Module):
                 self._torch_scheduler.step()
             if getattr(self, "model_ema", None) is not None:
                 self.model_ema.update()
+            if sharded:
+                dp.after_optimizer_step()      # every rank's shard of the new shadows, gathered behind the update
         self._optimizer_in_flight = overlap
         self.store.state.grad_accumulate = False
         self.global_step += 1

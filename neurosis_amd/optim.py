@@ -83,9 +83,11 @@ class FlatAdafactor:
         ws_max = 0
         mr_slots = 0
         c_t0, c_i0, c_f0, c_bytes, c_ws = 0, 0, 0, 0, 0
+        self._fin_start = []     # index into `fin` at which each tensor's entries begin (restrict() cuts chunks at tensor boundaries)
         for ti, (p, off) in enumerate(zip(store.params, store.offsets)):
             t = tens[ti]
             t["off"] = off
+            self._fin_start.append(len(fin))
             if p.dim() >= 2 and p.dim() not in (2, 4):
                 raise NotImplementedError(f"FlatAdafactor: {p.dim()}-d parameters are not supported")
             nbytes = p.numel() * 4
@@ -142,7 +144,27 @@ class FlatAdafactor:
         self.scale = torch.zeros(self.ntensors, dtype=torch.float32, device=dev)
         self.lr_t = torch.zeros(self.ntensors, dtype=torch.float32, device=dev)
         self._p2_valid = False
+        self.owned = None          # restrict(): (tensor_lo, tensor_hi) this process updates; None = everything
         store.add_listener(self)
+
+    def restrict(self, tensor_lo: int, tensor_hi: int) -> None:
+        """Update only tensors [tensor_lo, tensor_hi) from now on (data-parallel rs_ag mode: a rank owns a contiguous, tensor-aligned shard
+        of the flat buffers; the others' updated shadows arrive by broadcast).  Chunks are cut at the two boundaries; per-tensor state
+        never crosses a tensor, so cutting changes no arithmetic."""
+        cut = []
+        for (t0, t1, i0, i1, f0, f1) in self.chunks:
+            marks = sorted({t0, t1} | {b for b in (tensor_lo, tensor_hi) if t0 < b < t1})
+            for a, b in zip(marks[:-1], marks[1:]):
+                ia = i0 if a == t0 else int(self._tens_np[a]["item0"])
+                ib = i1 if b == t1 else int(self._tens_np[b]["item0"])
+                fa = f0 if a == t0 else self._fin_start[a]
+                fb = f1 if b == t1 else self._fin_start[b]
+                cut.append((a, b, ia, ib, fa, fb))
+        self.chunks = cut
+        self.owned = (tensor_lo, tensor_hi)
+
+    def _mine(self, ci: int) -> bool:
+        return self.owned is None or (self.chunks[ci][0] >= self.owned[0] and self.chunks[ci][1] <= self.owned[1])
 
     def masters_changed(self) -> None:
         """FlatParamStore hook: the fp32 masters were rewritten from outside (checkpoint load, broadcast, EMA swap): the
@@ -192,6 +214,9 @@ class FlatAdafactor:
 
     def step_chunk(self, ci: int, grad_scale: float = 1.0) -> None:
         if self._done[ci]:
+            return
+        if not self._mine(ci):          # another rank's shard
+            self._done[ci] = True
             return
         a = self._args(self.chunks[ci], self._beta2t, self._rel, grad_scale)
         call("nk_adafactor_chunk", C.byref(a), ops._stream())

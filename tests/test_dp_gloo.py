@@ -98,3 +98,66 @@ def test_mean_of_rank_gradients_equals_full_batch_gradient():
     mp.spawn(_worker_oracle, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
         assert out[r] < 1e-5, out[r]
+
+
+def _worker_sharded(rank, world, port, out):
+    """The sharded exchange (mode rs_ag) against the all-reduce one, with gloo on CPU: gradient slices arrive back to front as the UNet's
+    backward finalises them; each mode then applies the same update rule -- p -= lr * mean gradient -- (all-reduce: everywhere; rs_ag: the
+    owner on its shard, then shadows broadcast, masters gathered on demand).  Masters and shadows must agree exactly."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+
+    from neurosis_amd.dp import FlatDataParallel, shard_bounds
+
+    torch.manual_seed(0)
+    sizes = [1000, 37, 4096, 512, 2048, 64, 3000, 800]
+    offsets, total = [], 0
+    for n in sizes:
+        offsets.append(total)
+        total += (n + 63) // 64 * 64
+
+    def make_store():
+        master = torch.linspace(-1, 1, total)
+        store = SimpleNamespace(params=[None] * len(sizes), offsets=offsets, numel=total, master=master.clone(), shadow=master.to(torch.bfloat16),
+                                grad=torch.zeros(total), listeners=[], state=SimpleNamespace(wgrad_stream=None, aux_stream=None))
+        store._mark_fresh = lambda: None
+        store.refresh = lambda: store.shadow.copy_(store.master.to(torch.bfloat16))
+        return store
+
+    tb, eb = shard_bounds(make_store(), world)
+    ok_bounds = tb[0] == 0 and tb[-1] == len(sizes) and eb[0] == 0 and eb[-1] == total and all(eb[i] == (offsets + [total])[tb[i]] for i in range(world + 1))
+    results = {}
+    for mode in ("allreduce", "rs_ag"):
+        store = make_store()
+        unet = SimpleNamespace(grad_ready_hook=None)
+        dp = FlatDataParallel(unet, store, mode=mode, broadcast_params=False)
+        g = torch.Generator().manual_seed(100 + rank)
+        for step in range(3):
+            store.grad.copy_(torch.randn(total, generator=g))
+            for lo, hi in [(offsets[5], total), (offsets[2], offsets[5]), (0, offsets[2])]:        # three "blocks", back to front
+                dp.reducer.reduce_range(lo, hi)
+            scale = dp.finish()
+            lo_t, hi_t = dp.owned_tensors()
+            a, b = (offsets + [total])[lo_t], (offsets + [total])[hi_t]
+            store.master[a:b] -= 0.1 * scale * store.grad[a:b]                                      # the "optimizer", on the owned range
+            store.shadow[a:b] = store.master[a:b].to(torch.bfloat16)
+            dp.after_optimizer_step()
+        shadows_before_sync = store.shadow.clone()
+        dp.sync_masters()
+        results[mode] = (store.master.clone(), shadows_before_sync, dp.sharded, dp.reducer.take_counts())
+    same_master = torch.equal(results["allreduce"][0], results["rs_ag"][0])
+    same_shadow = torch.equal(results["allreduce"][1], results["rs_ag"][1])
+    fewer_bytes = results["rs_ag"][3][1] <= 0.76 * results["allreduce"][3][1]      # fp32 in + bf16 out vs fp32 both ways: 6/8 of the bytes per link
+    out[rank] = (ok_bounds, same_master, same_shadow, results["rs_ag"][2], not results["allreduce"][2], fewer_bytes)
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_equals_allreduce_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_sharded, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r] == (True, True, True, True, True, True), out[r]

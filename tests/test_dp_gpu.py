@@ -108,6 +108,70 @@ def test_flat_data_parallel_rccl_one_gpu_per_rank():
     assert out["cos"] >= 0.999 and out["err"] <= 5e-2, dict(out)
 
 
+def _worker_modes(rank, world, port, out):
+    """Three configurations of the exchange in one process pair (two ranks on cuda:0 over gloo), each from the same initial weights, three
+    training steps with the fused Adafactor: all-reduce / fp32 wire (the default), all-reduce / bf16 wire (bench.py --wire-dtype bf16), and
+    the sharded rs_ag mode (reduce to owner, optimizer on the owned shard, shadows gathered; masters gathered at the end)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neurosis_amd.dp import FlatDataParallel
+
+    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
+    res = {}
+    for tag, mode, wire in (("ar32", "allreduce", None), ("ar16", "allreduce", torch.bfloat16), ("rsag", "rs_ag", None)):
+        eng = _build(fx, shapes)
+        eng.overlap_optimizer = False
+        af = eng.configure_adafactor(scale_parameter=True, relative_step=False, warmup_init=False, lr=1e-3)
+        dp = FlatDataParallel(eng.model.diffusion_model, eng.store, wire_dtype=wire, mode=mode)
+        dp.attach_optimizer(af)
+        for _ in range(3):
+            _loss(eng, fx, slice(rank, rank + 1)).mean().backward()
+            scale = dp.finish()
+            eng.optimizer_step(grad_scale=scale, dp=dp)
+        eng.join_optimizer()
+        torch.cuda.synchronize()
+        shadow = eng.store.shadow.float().cpu()
+        stale = eng.store.master.cpu().clone()
+        dp.sync_masters()
+        torch.cuda.synchronize()
+        res[tag] = (eng.store.master.cpu(), shadow, stale, dp.sharded, dp.owned_tensors(), len(eng.store.params))
+        eng.model.diffusion_model.grad_ready_hook = None
+        del eng, dp, af
+        torch.cuda.empty_cache()
+    ref = res["ar32"][0]
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    # every rank ends every configuration with the same masters (gathered over gloo for the check)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {k: v[0] for k, v in res.items()})
+    same_across_ranks = all(torch.equal(gathered[0][k], gathered[r][k]) for k in res for r in range(world))
+    lo, hi = res["rsag"][4]
+    out[rank] = dict(same_across_ranks=same_across_ranks, rsag_vs_ar=rel(res["rsag"][0], ref), ar16_vs_ar=rel(res["ar16"][0], ref),
+                     shadow_rsag_vs_ar=rel(res["rsag"][1], res["ar32"][1]), sharded=res["rsag"][3] and not res["ar32"][3],
+                     owns_part=0 <= lo < hi <= res["rsag"][5] and (hi - lo) < res["rsag"][5],
+                     stale_before_sync=rel(res["rsag"][2], ref) > rel(res["rsag"][0], ref),
+                     moved=rel(ref, _build(fx, shapes).store.master.cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_modes_two_ranks_one_gpu():
+    """bf16 on the wire and the sharded rs_ag exchange against the default all-reduce, on the device, with the fused Adafactor."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_modes, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        o = out[r]
+        assert o["same_across_ranks"] and o["sharded"] and o["owns_part"], o
+        assert o["moved"] > 1e-5, o                                     # three steps did change the weights
+        # the same update up to the run-to-run noise of the split-K atomics: a small fraction of the distance the weights moved
+        assert o["rsag_vs_ar"] <= 0.02 * o["moved"] and o["shadow_rsag_vs_ar"] <= 1e-2, o
+        assert o["ar16_vs_ar"] <= 0.05 * o["moved"], o                 # bf16 wire: 8 significant bits per summand
+        assert o["stale_before_sync"], o                                # foreign shards' masters ARE stale until sync_masters()
+
+
 def test_engine_accumulate_helper_overwrites_then_adds():
     """DiffusionEngine.accumulate(i): micro-batch 0 overwrites the flat gradient buffer (no zero-fill between steps), later
     ones add; optimizer_step() resets the mode."""
