@@ -472,6 +472,239 @@ def _(t, N, C, H, W):
     return t.new_empty(N, C, H, W, dtype=torch.float32)
 
 
-OPS = ("linear_fwd", "linear_dgrad", "linear_wgrad", "colsum", "linear", "layernorm_fwd", "layernorm_bwd", "layernorm", "groupnorm_silu_fwd",
+# ---------------------------------------------------------------------------------------------------------------
+# upsample2x_nearest_cat: the two data-movement ops of the UNet decoder (openaimodel.py:140 F.interpolate(scale_factor=2, mode="nearest")
+# in Upsample.forward -- here folded into the following 3 x 3 convolution's gather, so only its BACKWARD exists as a kernel -- and :836
+# torch.cat([h, hs.pop()], dim=1) on channels-last tokens).
+# ---------------------------------------------------------------------------------------------------------------
+@_op("cat_channels")
+def cat_channels(a: Tensor, b: Tensor) -> Tensor:
+    out = torch.empty(a.shape[0], a.shape[1] + b.shape[1], dtype=BF16, device=a.device)
+    ops.call("nk_cat_channels", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1], b.shape[1], ops._stream())
+    return out
+
+
+@cat_channels.register_fake
+def _(a, b):
+    return a.new_empty(a.shape[0], a.shape[1] + b.shape[1])
+
+
+@_op("split_channels")
+def split_channels(x: Tensor, Ca: int) -> Tuple[Tensor, Tensor]:
+    rows, Cb = x.shape[0], x.shape[1] - Ca
+    a, b = torch.empty(rows, Ca, dtype=BF16, device=x.device), torch.empty(rows, Cb, dtype=BF16, device=x.device)
+    ops.call("nk_split_channels", x.data_ptr(), a.data_ptr(), b.data_ptr(), rows, Ca, Cb, ops._stream())
+    return a, b
+
+
+@split_channels.register_fake
+def _(x, Ca):
+    return x.new_empty(x.shape[0], Ca), x.new_empty(x.shape[0], x.shape[1] - Ca)
+
+
+def _cat_setup(ctx, inputs, output):
+    ctx.Ca = inputs[0].shape[1]
+
+
+def _cat_bwd(ctx, dout):
+    da, db = torch.ops.neurosis_hip.split_channels(dout.contiguous(), ctx.Ca)
+    return da, db
+
+
+cat_channels.register_autograd(_cat_bwd, setup_context=_cat_setup)
+
+
+@_op("upsample2x_nearest_bwd")
+def upsample2x_nearest_bwd(dup: Tensor, N: int, H: int, W: int) -> Tensor:
+    """dup [N*2H*2W, C] (gradient on the upsampled grid) -> [N*H*W, C]: the 2 x 2 sum-pool that is nearest-upsampling's adjoint"""
+    C_ = dup.shape[1]
+    dx = torch.empty(N * H * W, C_, dtype=BF16, device=dup.device)
+    ops.call("nk_upsample2x_bwd", dup.data_ptr(), dx.data_ptr(), N, H, W, C_, ops._stream())
+    return dx
+
+
+@upsample2x_nearest_bwd.register_fake
+def _(dup, N, H, W):
+    return dup.new_empty(N * H * W, dup.shape[1])
+
+
+@_op("upsample2x_nearest_conv")
+def upsample2x_nearest_conv(x: Tensor, w: Tensor, bias: Optional[Tensor], N: int, H: int, W: int) -> Tensor:
+    """Upsample.forward with use_conv (openaimodel.py:126-143): nearest x2 then 3 x 3 / padding 1 conv, the upsampled map never written"""
+    import ctypes as C
+
+    Cout, KH, KW, Cin = w.shape
+    d = ops._conv_desc(N, H, W, Cin, Cout, KH, KW, 1, 1, 1, 2 * H, 2 * W, True)
+    y = torch.empty(N * 4 * H * W, Cout, dtype=BF16, device=x.device)
+    ops.call("nk_conv2d_fwd", C.byref(d), x.data_ptr(), w.data_ptr(), ops._p(bias), None, None, y.data_ptr(), ops._stream())
+    return y
+
+
+@upsample2x_nearest_conv.register_fake
+def _(x, w, bias, N, H, W):
+    return x.new_empty(N * 4 * H * W, w.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# edm_loss: StandardDiffusionLoss "edm" arithmetic around the network (loss.py:117-157, denoiser.py:41-53, functions.py:91-94)
+# ---------------------------------------------------------------------------------------------------------------
+@_op("edm_prepare")
+def edm_prepare(x: Tensor, eps: Tensor, sigma: Tensor, c_in: Tensor, cpad: int) -> Tuple[Tensor, Tensor]:
+    """z_t = x + sigma * eps (fp32 NCHW) and the network input bf16(z_t * c_in) as channels-last tokens padded to cpad channels"""
+    B, Cc, H, W = x.shape
+    zt = torch.empty_like(x)
+    net_in = torch.empty(B * H * W, cpad, dtype=BF16, device=x.device)
+    ops.call("nk_edm_prepare", x.data_ptr(), eps.data_ptr(), sigma.data_ptr(), c_in.data_ptr(), zt.data_ptr(), net_in.data_ptr(), B, Cc, H * W, cpad, ops._stream())
+    return zt, net_in
+
+
+@edm_prepare.register_fake
+def _(x, eps, sigma, c_in, cpad):
+    return torch.empty_like(x), x.new_empty(x.shape[0] * x.shape[2] * x.shape[3], cpad, dtype=BF16)
+
+
+@_op("edm_loss_fwd")
+def edm_loss_fwd(net_out: Tensor, zt: Tensor, target: Tensor, c_out: Tensor, c_skip: Tensor, w: Tensor) -> Tensor:
+    """loss[b] = w[b] * mean((net_out * c_out + z_t * c_skip - target)^2): net_out bf16 tokens [B*H*W, Cpad], z_t / target fp32 NCHW"""
+    B, Cc, H, W = zt.shape
+    loss = torch.empty(B, dtype=torch.float32, device=zt.device)
+    ops.call("nk_edm_loss", net_out.data_ptr(), zt.data_ptr(), target.data_ptr(), c_out.data_ptr(), c_skip.data_ptr(), w.data_ptr(), loss.data_ptr(), None,
+             B, Cc, H * W, net_out.shape[1], 1.0, ops._stream())
+    return loss
+
+
+@edm_loss_fwd.register_fake
+def _(net_out, zt, target, c_out, c_skip, w):
+    return zt.new_empty(zt.shape[0], dtype=torch.float32)
+
+
+@_op("edm_loss_bwd")
+def edm_loss_bwd(dloss: Tensor, net_out: Tensor, zt: Tensor, target: Tensor, c_out: Tensor, c_skip: Tensor, w: Tensor) -> Tensor:
+    """d sum_b(dloss[b] * loss[b]) / d net_out, bf16 tokens"""
+    B, Cc, H, W = zt.shape
+    wg = (w * dloss.float()).contiguous()
+    dnet = torch.empty_like(net_out)
+    scratch = torch.empty(B, dtype=torch.float32, device=zt.device)
+    ops.call("nk_edm_loss", net_out.data_ptr(), zt.data_ptr(), target.data_ptr(), c_out.data_ptr(), c_skip.data_ptr(), wg.data_ptr(), scratch.data_ptr(),
+             dnet.data_ptr(), B, Cc, H * W, net_out.shape[1], 1.0, ops._stream())
+    return dnet
+
+
+@edm_loss_bwd.register_fake
+def _(dloss, net_out, zt, target, c_out, c_skip, w):
+    return torch.empty_like(net_out)
+
+
+@_op("edm_loss")
+def edm_loss(net_out: Tensor, zt: Tensor, target: Tensor, c_out: Tensor, c_skip: Tensor, w: Tensor) -> Tensor:
+    return torch.ops.neurosis_hip.edm_loss_fwd(net_out, zt, target, c_out, c_skip, w)
+
+
+@edm_loss.register_fake
+def _(net_out, zt, target, c_out, c_skip, w):
+    return zt.new_empty(zt.shape[0], dtype=torch.float32)
+
+
+def _edm_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _edm_bwd(ctx, dloss):
+    net_out, zt, target, c_out, c_skip, w = ctx.saved_tensors
+    return torch.ops.neurosis_hip.edm_loss_bwd(dloss.contiguous(), net_out, zt, target, c_out, c_skip, w), None, None, None, None, None
+
+
+edm_loss.register_autograd(_edm_bwd, setup_context=_edm_setup)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# flat_allreduce_{start, wait}: the data-parallel exchange of a flat gradient buffer as two ops (what Lightning's DDP reducer does
+# behind autograd hooks for the reference; neurosis_amd.dp.FlatGradReducer underneath: RCCL on its own stream, joined by `wait`).
+# The reducer is found by the buffer's address: one per flat gradient buffer and process.
+# ---------------------------------------------------------------------------------------------------------------
+_reducers: dict = {}
+
+
+def _reducer_for(flat: Tensor):
+    from .dp import FlatGradReducer
+
+    key = (flat.data_ptr(), flat.numel())
+    r = _reducers.get(key)
+    if r is None:
+        r = _reducers[key] = FlatGradReducer(flat)
+    return r
+
+
+@_op("flat_allreduce_start", mutates=("flat",))
+def flat_allreduce_start(flat: Tensor, lo: int, hi: int) -> None:
+    """begin summing flat[lo:hi] over the ranks (asynchronous: ordered behind the current stream, running on the exchange stream)"""
+    _reducer_for(flat).reduce_range(lo, hi)
+
+
+@flat_allreduce_start.register_fake
+def _(flat, lo, hi):
+    return None
+
+
+@_op("flat_allreduce_wait", mutates=("flat",))
+def flat_allreduce_wait(flat: Tensor) -> None:
+    """make the current stream wait for every reduction started on this buffer"""
+    _reducer_for(flat).finish()
+
+
+@flat_allreduce_wait.register_fake
+def _(flat):
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the fused entry points of round 3
+# ---------------------------------------------------------------------------------------------------------------
+@_op("conv2d_fwd_stats")
+def conv2d_fwd_stats(x: Tensor, w: Tensor, bias: Optional[Tensor], N: int, H: int, W: int, groups: int) -> Tuple[Tensor, Tensor]:
+    """3 x 3 / stride 1 / padding 1 convolution that also returns the GroupNorm sums of its output, [N, 2 * groups] fp32
+    (entry 2g = sum, 2g + 1 = sum of squares); from the kernel's epilogue where the halo-tile kernel takes the shape, else a statistics pass"""
+    import ctypes as C
+
+    Cout, KH, KW, Cin = w.shape
+    d = ops._conv_desc(N, H, W, Cin, Cout, KH, KW, 1, 1, 1, H, W, False)
+    y = torch.empty(N * H * W, Cout, dtype=BF16, device=x.device)
+    sums = torch.empty(N, 2 * groups, dtype=torch.float32, device=x.device)
+    tiles = ops.query("nk_conv2d_stats_tiles", C.byref(d), groups) if (KH, KW) == (3, 3) else 0
+    if tiles:
+        part = torch.empty(N, tiles, 2 * groups, dtype=torch.float32, device=x.device)
+        ops.call("nk_conv2d_fwd_stats", C.byref(d), x.data_ptr(), w.data_ptr(), ops._p(bias), None, None, y.data_ptr(), part.data_ptr(), groups, ops._stream())
+        ws = ops._ws(ops.query("nk_groupnorm_sums_ws_floats", N, tiles, groups), x.device)
+        ops.call("nk_groupnorm_sums_from_parts", part.data_ptr(), sums.data_ptr(), ws.data_ptr(), N, tiles, groups, ops._stream())
+    else:
+        ops.call("nk_conv2d_fwd", C.byref(d), x.data_ptr(), w.data_ptr(), ops._p(bias), None, None, y.data_ptr(), ops._stream())
+        ws = ops._ws(ops.query("nk_groupnorm_ws_floats", N, H * W, Cout, groups), x.device)
+        ops.call("nk_groupnorm_sums", y.data_ptr(), sums.data_ptr(), ws.data_ptr(), N, H * W, Cout, groups, ops._stream())
+    return y, sums
+
+
+@conv2d_fwd_stats.register_fake
+def _(x, w, bias, N, H, W, groups):
+    return x.new_empty(N * H * W, w.shape[0]), x.new_empty(N, 2 * groups, dtype=torch.float32)
+
+
+@_op("linear_dgrad_geglu")
+def linear_dgrad_geglu(dy: Tensor, w: Tensor, u: Tensor) -> Tensor:
+    """FeedForward backward through net[2] and the GEGLU in one launch: du [M, 2I] from dy [M, N], w [N, I], u = [a | g] [M, 2I]"""
+    M, N = dy.shape
+    I = w.shape[1]
+    du = torch.empty(M, 2 * I, dtype=BF16, device=dy.device)
+    ops.call("nk_linear_dgrad_geglu", dy.data_ptr(), w.data_ptr(), u.data_ptr(), du.data_ptr(), M, N, I, dy.stride(0), w.stride(0), u.stride(0), du.stride(0),
+             ops._stream())
+    return du
+
+
+@linear_dgrad_geglu.register_fake
+def _(dy, w, u):
+    return dy.new_empty(dy.shape[0], 2 * w.shape[1])
+
+
+OPS = ("cat_channels", "split_channels", "upsample2x_nearest_bwd", "upsample2x_nearest_conv", "edm_prepare", "edm_loss_fwd", "edm_loss_bwd", "edm_loss",
+       "flat_allreduce_start", "flat_allreduce_wait", "conv2d_fwd_stats", "linear_dgrad_geglu", "linear_fwd", "linear_dgrad", "linear_wgrad", "colsum", "linear", "layernorm_fwd", "layernorm_bwd", "layernorm", "groupnorm_silu_fwd",
        "groupnorm_silu_bwd", "groupnorm_silu", "geglu_fwd", "geglu_bwd", "geglu", "attention_fwd", "attention_bwd", "attention", "conv2d_fwd",
        "conv2d_dgrad", "conv2d_wgrad", "conv2d", "timestep_embedding", "nchw_to_nlc", "nlc_to_nchw")
