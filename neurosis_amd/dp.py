@@ -207,15 +207,19 @@ class FlatDataParallel:
         self.store._mark_fresh()
 
     def sync_masters(self) -> None:
-        """rs_ag: gather the fp32 masters of every shard (checkpoints, EMA swaps, anything that reads parameters other than through the
-        bf16 shadows).  The shadows are already current."""
+        """rs_ag: gather the fp32 masters of every shard AND the attached optimizers' statistics for it (checkpoints, EMA swaps, anything
+        that reads parameters other than through the bf16 shadows).  The shadows are already current."""
         if not self.sharded:
             return
         for r in range(self.world):
             a, b = self.owner_bounds[r], self.owner_bounds[r + 1]
+            src = dist.get_global_rank(self.group, r) if self.group is not None else r
             if b > a:
-                src = dist.get_global_rank(self.group, r) if self.group is not None else r
                 dist.broadcast(self.store.master[a:b], src=src, group=self.group)
+            for o in self._optimizers:
+                sa, sb = o.state_span(self.tensor_bounds[r], self.tensor_bounds[r + 1])
+                if sb > sa:
+                    dist.broadcast(o.state[sa:sb], src=src, group=self.group)
         for o in self.store.listeners:
             o.masters_changed()
 

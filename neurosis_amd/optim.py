@@ -163,6 +163,13 @@ class FlatAdafactor:
         self.chunks = cut
         self.owned = (tensor_lo, tensor_hi)
 
+    def state_span(self, tensor_lo: int, tensor_hi: int) -> tuple[int, int]:
+        """[lo, hi) of `self.state` (fp32 second-moment statistics) belonging to tensors [tensor_lo, tensor_hi): state is laid out in
+        tensor order, so a tensor-aligned shard's statistics are one contiguous span (rs_ag gathers them for checkpoints)"""
+        lo = int(self._tens_np[tensor_lo]["row_off"]) if tensor_lo < self.ntensors else self.state.numel()
+        hi = int(self._tens_np[tensor_hi]["row_off"]) if tensor_hi < self.ntensors else self.state.numel()
+        return lo, hi
+
     def _mine(self, ci: int) -> bool:
         return self.owned is None or (self.chunks[ci][0] >= self.owned[0] and self.chunks[ci][1] <= self.owned[1])
 

@@ -75,6 +75,10 @@ class DiffusionEngineMI355X(_Base):
         if world > 1:
             self.dp = FlatDataParallel(self.engine.model.diffusion_model, self.engine.store, wire_dtype=self._wire_dtype)
         self._apply_pending()
+        if self.dp is not None and self.dp.sharded:        # NK_DP_MODE=rs_ag: this rank updates its shard only
+            if getattr(self.engine, "adafactor", None) is None:
+                raise NotImplementedError("NK_DP_MODE=rs_ag needs the fused Adafactor (the optimizer that can be restricted to a shard)")
+            self.dp.attach_optimizer(self.engine.adafactor)
 
     def _apply_pending(self) -> None:
         """checkpoint state that arrived before the store / optimizer / EMA existed (Trainer.fit(ckpt_path=...))"""
@@ -112,7 +116,7 @@ class DiffusionEngineMI355X(_Base):
         (loss / acc).backward()
         if last:
             scale = self.dp.finish() if self.dp is not None else 1.0
-            self.engine.optimizer_step(grad_scale=scale)
+            self.engine.optimizer_step(grad_scale=scale, dp=self.dp)
             self._micro = 0
         else:
             self._micro += 1
@@ -128,6 +132,8 @@ class DiffusionEngineMI355X(_Base):
     # -- checkpoints: the reference's state_dict keys live under `engine.`; optimizer state rides along ------------------
     def on_save_checkpoint(self, checkpoint: dict) -> None:
         self.engine.join_optimizer()
+        if self.dp is not None:
+            self.dp.sync_masters()        # rs_ag: every rank's masters and optimizer statistics become whole again (a collective: all ranks call)
         opt = self.engine._torch_optimizer
         if opt is not None:
             checkpoint["nk_optimizer"] = opt.state_dict()

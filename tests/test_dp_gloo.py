@@ -132,6 +132,10 @@ def _worker_sharded(rank, world, port, out):
         store = make_store()
         unet = SimpleNamespace(grad_ready_hook=None)
         dp = FlatDataParallel(unet, store, mode=mode, broadcast_params=False)
+        ends = offsets + [total]
+        # a stand-in for the fused optimizer's statistics: one fp32 value per element, laid out in tensor order like FlatAdafactor.state
+        opt = SimpleNamespace(state=torch.zeros(total), restrict=lambda lo, hi: None, state_span=lambda lo, hi: (ends[lo], ends[hi]))
+        dp.attach_optimizer(opt)
         g = torch.Generator().manual_seed(100 + rank)
         for step in range(3):
             store.grad.copy_(torch.randn(total, generator=g))
@@ -142,11 +146,12 @@ def _worker_sharded(rank, world, port, out):
             a, b = (offsets + [total])[lo_t], (offsets + [total])[hi_t]
             store.master[a:b] -= 0.1 * scale * store.grad[a:b]                                      # the "optimizer", on the owned range
             store.shadow[a:b] = store.master[a:b].to(torch.bfloat16)
+            opt.state[a:b] += (scale * store.grad[a:b]) ** 2
             dp.after_optimizer_step()
         shadows_before_sync = store.shadow.clone()
         dp.sync_masters()
-        results[mode] = (store.master.clone(), shadows_before_sync, dp.sharded, dp.reducer.take_counts())
-    same_master = torch.equal(results["allreduce"][0], results["rs_ag"][0])
+        results[mode] = (store.master.clone(), shadows_before_sync, dp.sharded, dp.reducer.take_counts(), opt.state.clone())
+    same_master = torch.equal(results["allreduce"][0], results["rs_ag"][0]) and torch.equal(results["allreduce"][4], results["rs_ag"][4])
     same_shadow = torch.equal(results["allreduce"][1], results["rs_ag"][1])
     fewer_bytes = results["rs_ag"][3][1] <= 0.76 * results["allreduce"][3][1]      # fp32 in + bf16 out vs fp32 both ways: 6/8 of the bytes per link
     out[rank] = (ok_bounds, same_master, same_shadow, results["rs_ag"][2], not results["allreduce"][2], fewer_bytes)
