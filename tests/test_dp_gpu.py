@@ -120,7 +120,9 @@ def _worker_modes(rank, world, port, out):
     fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     res = {}
-    for tag, mode, wire in (("ar32", "allreduce", None), ("ar16", "allreduce", torch.bfloat16), ("rsag", "rs_ag", None)):
+    # ("again" repeats the default configuration: the run-to-run noise floor.  Adafactor's update has unit RMS whatever the gradient's size,
+    # so the fp32-atomic reordering noise of near-zero gradients -- the zero-initialised output layers -- moves those weights by whole steps.)
+    for tag, mode, wire in (("ar32", "allreduce", None), ("again", "allreduce", None), ("ar16", "allreduce", torch.bfloat16), ("rsag", "rs_ag", None)):
         eng = _build(fx, shapes)
         eng.overlap_optimizer = False
         af = eng.configure_adafactor(scale_parameter=True, relative_step=False, warmup_init=False, lr=1e-3)
@@ -147,7 +149,7 @@ def _worker_modes(rank, world, port, out):
     dist.all_gather_object(gathered, {k: v[0] for k, v in res.items()})
     same_across_ranks = all(torch.equal(gathered[0][k], gathered[r][k]) for k in res for r in range(world))
     lo, hi = res["rsag"][4]
-    out[rank] = dict(same_across_ranks=same_across_ranks, rsag_vs_ar=rel(res["rsag"][0], ref), ar16_vs_ar=rel(res["ar16"][0], ref),
+    out[rank] = dict(same_across_ranks=same_across_ranks, rsag_vs_ar=rel(res["rsag"][0], ref), ar16_vs_ar=rel(res["ar16"][0], ref), noise=rel(res["again"][0], ref),
                      shadow_rsag_vs_ar=rel(res["rsag"][1], res["ar32"][1]), sharded=res["rsag"][3] and not res["ar32"][3],
                      owns_part=0 <= lo < hi <= res["rsag"][5] and (hi - lo) < res["rsag"][5],
                      stale_before_sync=rel(res["rsag"][2], ref) > rel(res["rsag"][0], ref),
@@ -166,9 +168,11 @@ def test_exchange_modes_two_ranks_one_gpu():
         o = out[r]
         assert o["same_across_ranks"] and o["sharded"] and o["owns_part"], o
         assert o["moved"] > 1e-5, o                                     # three steps did change the weights
-        # the same update up to the run-to-run noise of the split-K atomics: a small fraction of the distance the weights moved
-        assert o["rsag_vs_ar"] <= 0.02 * o["moved"] and o["shadow_rsag_vs_ar"] <= 1e-2, o
-        assert o["ar16_vs_ar"] <= 0.05 * o["moved"], o                 # bf16 wire: 8 significant bits per summand
+        # the same update up to the run-to-run noise of the default configuration against itself (measured: 6 % of the distance moved, from
+        # unit-RMS updates of near-zero gradients); a wrongly cut shard or a missed broadcast would differ by the distance itself
+        floor = 2.0 * o["noise"] + 0.02 * o["moved"]
+        assert o["rsag_vs_ar"] <= floor and o["rsag_vs_ar"] <= 0.25 * o["moved"] and o["shadow_rsag_vs_ar"] <= 1e-2, o
+        assert o["ar16_vs_ar"] <= floor + 0.05 * o["moved"], o         # bf16 wire: 8 significant bits per summand
         assert o["stale_before_sync"], o                                # foreign shards' masters ARE stale until sync_masters()
 
 
