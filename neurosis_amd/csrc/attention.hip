@@ -633,14 +633,9 @@ static int attn_check(const NkAttnDesc* d) {
   return NK_OK;
 }
 static int attn_dp(int D) { return D <= 64 ? 64 : (D <= 96 ? 96 : 160); }
-// waves per workgroup: 4 x 32 rows.  A 2-wave variant (twice the workgroups for SDXL's L = 1024 layers, which give only
-// 640) is compiled but measured SLOWER (forward 72 vs 65 us, backward 200 vs 181 us: twice the K/V tile loads per query row
-// and half the waves sharing a tile); NK_ATTN_NW=2 selects it for experiments.
-static int attn_waves(int L, int heads_x_batch) {
-  (void)L; (void)heads_x_batch;
-  if (const char* e = getenv("NK_ATTN_NW")) return atoi(e) == 2 ? 2 : 4;
-  return 4;
-}
+// waves per workgroup: 4 x 32 rows.  (A 2-wave variant -- twice the workgroups for SDXL's L = 1024 layers, which give only 640 -- was
+// measured SLOWER: forward 72 vs 65 us, backward 200 vs 181 us, twice the K/V tile loads per query row and half the waves sharing a tile.)
+static constexpr int ATTN_NW = 4;
 
 template <typename K>
 static void set_smem(K kern, int bytes) {
@@ -660,17 +655,14 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
   p.scale = d->scale;
   p.causal = d->causal != 0;
   NK_CHECK_ARG(!d->causal || d->Lq == d->Lk);
-  const int nw = attn_waves(d->Lq, d->H * d->B);
+  constexpr int nw = ATTN_NW;
   dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
   const int dp = attn_dp(d->D);
   const int smem = 2 * 2 * 64 * (dp * 2 + 16);
 #define FWD_CASE(DP_)                                                                          \
-  if (dp == DP_ && nw == 4) {                                                                  \
-    set_smem(attn_fwd_kernel<DP_, 4>, smem);                                                   \
-    hipLaunchKernelGGL((attn_fwd_kernel<DP_, 4>), grid, dim3(256), smem, stream, p);           \
-  } else if (dp == DP_) {                                                                      \
-    set_smem(attn_fwd_kernel<DP_, 2>, smem);                                                   \
-    hipLaunchKernelGGL((attn_fwd_kernel<DP_, 2>), grid, dim3(128), smem, stream, p);           \
+  if (dp == DP_) {                                                                             \
+    set_smem(attn_fwd_kernel<DP_, ATTN_NW>, smem);                                                \
+    hipLaunchKernelGGL((attn_fwd_kernel<DP_, ATTN_NW>), grid, dim3(ATTN_NW * 64), smem, stream, p); \
   }
   FWD_CASE(64) FWD_CASE(96) FWD_CASE(160)
 #undef FWD_CASE
@@ -715,16 +707,13 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   // order: dQ kernel first (it also produces delta = rowsum(dO * O) for the dK / dV kernel), then dK / dV
   const int dp = attn_dp(d->D);
   {
-    const int nw = attn_waves(d->Lq, d->H * d->B);
+    constexpr int nw = ATTN_NW;
     dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
     const int smem = 2 * 2 * 64 * (dp * 2 + 16);
-#define Q_CASE(DP_)                                                                            \
-  if (dp == DP_ && nw == 4) {                                                                  \
-    set_smem(attn_bwd_dq_kernel<DP_, 4>, smem);                                                \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP_, 4>), grid, dim3(256), smem, stream, p);        \
-  } else if (dp == DP_) {                                                                      \
-    set_smem(attn_bwd_dq_kernel<DP_, 2>, smem);                                                \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP_, 2>), grid, dim3(128), smem, stream, p);        \
+#define Q_CASE(DP_)                                                                          \
+  if (dp == DP_) {                                                                             \
+    set_smem(attn_bwd_dq_kernel<DP_, ATTN_NW>, smem);                                                \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP_, ATTN_NW>), grid, dim3(ATTN_NW * 64), smem, stream, p); \
   }
     Q_CASE(64) Q_CASE(96) Q_CASE(160)
 #undef Q_CASE
@@ -733,16 +722,13 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   p.qsplit = attn_qsplit(d);
   p.dkv_part = p.qsplit > 1 ? delta_ws + (((long)d->B * d->H * d->Lq + 3) & ~3l) : nullptr;
   {
-    const int nw = attn_waves(d->Lk, d->H * d->B * p.qsplit);
+    constexpr int nw = ATTN_NW;
     dim3 grid(((d->Lk + nw * 32 - 1) / (nw * 32)) * p.qsplit, d->H, d->B);
     const int smem = 2 * (2 * 32 * (dp * 2 + 16) + 256);
-#define KV_CASE(DP_)                                                                           \
-  if (dp == DP_ && nw == 4) {                                                                  \
-    set_smem(attn_bwd_dkdv_kernel<DP_, 4>, smem);                                              \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DP_, 4>), grid, dim3(256), smem, stream, p);      \
-  } else if (dp == DP_) {                                                                      \
-    set_smem(attn_bwd_dkdv_kernel<DP_, 2>, smem);                                              \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DP_, 2>), grid, dim3(128), smem, stream, p);      \
+#define KV_CASE(DP_)                                                                          \
+  if (dp == DP_) {                                                                             \
+    set_smem(attn_bwd_dkdv_kernel<DP_, ATTN_NW>, smem);                                                \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DP_, ATTN_NW>), grid, dim3(ATTN_NW * 64), smem, stream, p); \
   }
     KV_CASE(64) KV_CASE(96) KV_CASE(160)
 #undef KV_CASE

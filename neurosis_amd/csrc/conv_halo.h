@@ -461,8 +461,7 @@ static int launch_halo_as(const NkGemmParams& p, hipStream_t stream) {
 }
 template <int STATS>
 static int launch_halo_s(const NkGemmParams& p, hipStream_t stream) {
-  int th = halo_tile_rows(p);
-  if (const char* e = getenv("NK_CONV_HALO_TH")) th = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : th);      // A/B runs
+  const int th = halo_tile_rows(p);
   const bool wide = p.N % 160 == 0;
   if (th == 8) return wide ? launch_halo_as<160, 4, STATS>(p, stream) : launch_halo_as<128, 4, STATS>(p, stream);
   return wide ? launch_halo_as<160, 2, STATS>(p, stream) : launch_halo_as<128, 2, STATS>(p, stream);
@@ -472,8 +471,7 @@ static int launch_halo(const NkGemmParams& p, hipStream_t stream) {
 }
 // pixel tiles per image of the launch `launch_halo` would make (the statistics epilogue writes one partial row per tile)
 static int halo_tiles_per_image(const NkGemmParams& p) {
-  int th = halo_tile_rows(p);
-  if (const char* e = getenv("NK_CONV_HALO_TH")) th = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : th);
+  const int th = halo_tile_rows(p);
   if (!th) return 0;
   return ((p.ga.W + CH_TW - 1) / CH_TW) * ((p.ga.H + th - 1) / th);
 }

@@ -16,13 +16,15 @@
 // gfx950's transposing ds_read_b64_tr_b16, so no operand is ever transposed in HBM.
 //
 // The kernels in this file, all over the same operand loaders, chosen per launch by shape (nk_gemm_dispatch):
-//   nk_gemm_kernel        128x128x64, 4 waves, register-staged double-buffered LDS          (first version; NK_GEMM_V1=1)
 //   nk_gemm_dma_kernel    128x128x64, 8 waves, LDS-DMA (global_load_lds) double buffer, two workgroups per CU: the general kernel
 //   nk_gemm_ring_kernel   the same tile with a 4-stage ring and counted vmcnt for grids of <= one workgroup per CU
 //   nk_gemm_sk_kernel     persistent stream-K over that tile for under-filled bf16-output grids (fix-up through a workspace)
 //   nk_gemm_xl_kernel     256x256x64, 16 waves, one workgroup per CU: large conv-forward grids (gathered A)
 //   nk_gemm_xl2g_kernel   256x256x64, 8 waves in two groups staggered by a barrier, four phases per k-slab: large Linear forward grids
-//   (nk_gemm_big_kernel, nk_gemm_xlp_kernel and the other wave shapes of nk_gemm_xl_kernel are measured variants kept opt-in)
+//   nk_gemm_g2_kernel     (gemm_g2.h) 128x160 / 128x128 two-group staggered ring at one workgroup per CU: the K = 640 / 1280 Linear shapes
+//   nk_conv3x3_halo_kernel (conv_halo.h) 3 x 3 / stride-1 convolutions from an LDS halo tile: each input byte staged once per 9 taps
+//   (variants that lost their A/B -- the register-staged first version, 256x128 "big", the software-pipelined 256x256, other wave shapes --
+//   were removed in round 3; HISTORY.md keeps their measurements)
 // All use an XCD-aware block->tile mapping with grouped tile order; bf16 outputs leave through a register-direct
 // permlane16_swap epilogue or an LDS-staged one (16 B per lane, row-contiguous), fp32 weight gradients through vector stores/atomics.
 //
@@ -66,172 +68,6 @@ __device__ __forceinline__ long gather_offset(const NkGather& g, int n, int bh, 
   valid = valid && ok;
   return (((long)n * g.H + h) * g.W + w) * g.C + c;
 }
-
-// ---------------------------------------------------------------------------------------------
-// Operand loader
-// ---------------------------------------------------------------------------------------------
-template <int MODE>
-struct Operand {
-  const bf16_t* P;
-  long ld;
-  int R;            // number of rows of this operand (M for A, N for B)
-  int r0;           // tile origin
-  // per-thread chunk coordinates
-  int fixed;        // KC: kc (0..7)        MC: rc (0..15)
-  int var0;         // KC: first row (tid>>3) MC: first k row (tid>>4)
-  // conv state
-  int pn[4], pbh[4], pbw[4];   // KCG: per-row pixel decode
-  int tkh, tkw, tc;            // MCG: fixed tap / channel of this thread's r-chunk
-  bool rvalid[4];              // KC*: row in range;  MC*: [0] = r-chunk in range
-
-  __device__ __forceinline__ void init(const bf16_t* p, long ld_, int R_, int r0_, int tid,
-                                       const NkGather& g) {
-    P = p; ld = ld_; R = R_; r0 = r0_;
-    if constexpr (MODE == OP_KC || MODE == OP_KCG) {
-      fixed = tid & 7;
-      var0 = tid >> 3;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int r = r0 + var0 + 32 * i;
-        rvalid[i] = r < R;
-        if constexpr (MODE == OP_KCG) {
-          unsigned p_ = rvalid[i] ? (unsigned)r : 0u;
-          unsigned n = fdiv(p_, g.fHoWo);
-          unsigned rem = p_ - n * g.fHoWo.d;
-          unsigned ph = fdiv(rem, g.fWo);
-          unsigned pw = rem - ph * g.fWo.d;
-          pn[i] = (int)n;
-          pbh[i] = (int)ph * g.rs + g.off_h;
-          pbw[i] = (int)pw * g.rs + g.off_w;
-        }
-      }
-    } else {
-      fixed = tid & 15;
-      var0 = tid >> 4;
-      int r = r0 + fixed * 8;
-      rvalid[0] = r < R;
-      if constexpr (MODE == OP_MCG) {
-        unsigned rr = rvalid[0] ? (unsigned)r : 0u;
-        unsigned tap = fdiv(rr, g.fC);
-        tc = (int)(rr - tap * g.fC.d);
-        unsigned kh = fdiv(tap, g.fKW);
-        tkh = (int)kh;
-        tkw = (int)(tap - kh * g.fKW.d);
-      }
-    }
-  }
-
-  // issue the 4 x 16-byte global loads of this thread for the k-tile [k0, k0+BK) clipped to kend
-  __device__ __forceinline__ void load(int k0, int kend, uint4_t (&v)[4], const NkGather& g,
-                                       const NkTapW& tw) const {
-    if constexpr (MODE == OP_KC) {
-      int k = k0 + fixed * 8;
-      bool kv = k < kend;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint4_t z = {0u, 0u, 0u, 0u};
-        if (kv && rvalid[i]) {
-          const bf16_t* p = P + (long)(r0 + var0 + 32 * i) * ld + k;
-          z = *(const uint4_t*)p;
-        }
-        v[i] = z;
-      }
-    } else if constexpr (MODE == OP_KCG) {
-      int k = k0 + fixed * 8;
-      bool kv = k < kend;
-      unsigned kk = kv ? (unsigned)k : 0u;
-      unsigned tap = fdiv(kk, g.fC);
-      int c = (int)(kk - tap * g.fC.d);
-      unsigned kh = fdiv(tap, g.fKW);
-      int kw = (int)(tap - kh * g.fKW.d);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint4_t z = {0u, 0u, 0u, 0u};
-        bool ok = kv && rvalid[i];
-        long off = gather_offset(g, pn[i], pbh[i], pbw[i], (int)kh, kw, c, ok);
-        if (ok) z = *(const uint4_t*)(P + off);
-        v[i] = z;
-      }
-    } else if constexpr (MODE == OP_MC) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = k0 + var0 + 16 * i;
-        uint4_t z = {0u, 0u, 0u, 0u};
-        if (k < kend && rvalid[0]) z = *(const uint4_t*)(P + (long)k * ld + r0 + fixed * 8);
-        v[i] = z;
-      }
-    } else if constexpr (MODE == OP_MCT) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = k0 + var0 + 16 * i;
-        uint4_t z = {0u, 0u, 0u, 0u};
-        if (k < kend && rvalid[0]) {
-          unsigned tap = fdiv((unsigned)k, tw.fCout);
-          unsigned co = (unsigned)k - tap * tw.fCout.d;
-          z = *(const uint4_t*)(P + (long)co * tw.co_stride + (long)tap * tw.tap_stride + r0 + fixed * 8);
-        }
-        v[i] = z;
-      }
-    } else {  // OP_MCG
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = k0 + var0 + 16 * i;
-        uint4_t z = {0u, 0u, 0u, 0u};
-        bool ok = (k < kend) && rvalid[0];
-        unsigned p_ = ok ? (unsigned)k : 0u;
-        unsigned n = fdiv(p_, g.fHoWo);
-        unsigned rem = p_ - n * g.fHoWo.d;
-        unsigned ph = fdiv(rem, g.fWo);
-        unsigned pw = rem - ph * g.fWo.d;
-        long off = gather_offset(g, (int)n, (int)ph * g.rs + g.off_h, (int)pw * g.rs + g.off_w, tkh, tkw,
-                                 tc, ok);
-        if (ok) z = *(const uint4_t*)(P + off);
-        v[i] = z;
-      }
-    }
-  }
-
-  // write the staged registers into this operand's LDS image
-  __device__ __forceinline__ void store(char* img, const uint4_t (&v)[4]) const {
-    if constexpr (MODE == OP_KC || MODE == OP_KCG) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int row = var0 + 32 * i;
-        int byte = row * 128 + ((fixed ^ (row & 7)) << 4);
-        *(uint4_t*)(img + byte) = v[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = var0 + 16 * i;
-        *(uint4_t*)(img + k * MC_ROW_BYTES + fixed * 16) = v[i];
-      }
-    }
-  }
-
-  // fragment (16 rows starting at `sub`, k sub-step ks of 32) in the 16x16x32 A/B operand layout:
-  // lane l holds elem(row = sub + (l&15), k = 32*ks + 8*(l>>4) + j), j = 0..7
-  static __device__ __forceinline__ bf16x8_t frag(const char* img, int sub, int ks, int lane) {
-    if constexpr (MODE == OP_KC || MODE == OP_KCG) {
-      int row = sub + (lane & 15);
-      int chunk = ks * 4 + (lane >> 4);
-      int byte = row * 128 + ((chunk ^ (row & 7)) << 4);
-      return *(const bf16x8_t*)(img + byte);
-    } else {
-      int g = lane >> 4, i = lane & 15;
-      int q = i >> 2, p = i & 3;
-      int k = ks * 32 + 8 * g + q;
-      int byte = k * MC_ROW_BYTES + (sub + 4 * p) * 2;
-      typedef __attribute__((address_space(3))) short4_t* lds_p;
-      short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + byte));
-      short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + byte + 4 * MC_ROW_BYTES));
-      short8_t r;
-      r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-      r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-      return __builtin_bit_cast(bf16x8_t, r);
-    }
-  }
-};
 
 // ---------------------------------------------------------------------------------------------
 // kernel
@@ -346,98 +182,6 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
   }
 }
 
-template <int AMODE, int BMODE, int OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_kernel(const NkGemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware bijective remap: blocks that share an XCD (bid % 8) get a contiguous tile range
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  // grouped tile order: the ~64 tiles an XCD runs at once (32 CUs x 2 workgroups) form a GROUP_M x 8 patch of
-  // the tile grid, so their A panels and B panels (8 + 8 panels of 128 x K) stay resident in that XCD's 4 MiB L2
-  // instead of every workgroup streaming the whole B operand from the Infinity Cache
-  const int ntn = (p.N + BN - 1) / BN;
-  const int ntm = (p.M + BM - 1) / BM;
-  const int per_group = GROUP_M * ntn;
-  const int group = wg / per_group;
-  const int first_m = group * GROUP_M;
-  const int gm = min(GROUP_M, ntm - first_m);
-  const int in_group = wg - group * per_group;
-  const int nt = in_group / gm;
-  const int mt = first_m + (in_group - nt * gm);
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int kbeg = blockIdx.y * p.ksplit_len;
-  const int kend = min(p.K, kbeg + p.ksplit_len);
-  const int nk = (kend - kbeg + BK - 1) / BK;
-
-  Operand<AMODE> opa;
-  Operand<BMODE> opb;
-  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
-  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
-
-  float4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-  uint4_t ra[4], rb[4];
-  if (nk > 0) {
-    opa.load(kbeg, kend, ra, p.ga, p.tw);
-    opb.load(kbeg, kend, rb, p.gb, p.tw);
-    opa.store(smem, ra);
-    opb.store(smem + OPND_BYTES, rb);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-    const bool more = (kt + 1) < nk;
-#ifndef ABL_NOLOAD
-    if (more) {
-      opa.load(kbeg + (kt + 1) * BK, kend, ra, p.ga, p.tw);
-      opb.load(kbeg + (kt + 1) * BK, kend, rb, p.gb, p.tw);
-    }
-#endif
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = Operand<AMODE>::frag(cur, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = Operand<BMODE>::frag(cur + OPND_BYTES, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#ifndef ABL_NOMFMA
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-#else
-      { asm volatile("" :: "v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]), "v"(bfr[0]), "v"(bfr[1]), "v"(bfr[2]), "v"(bfr[3])); }
-#endif
-    }
-#ifndef ABL_NOLDSWRITE
-    if (more) {
-      opa.store(nxt, ra);
-      opb.store(nxt + OPND_BYTES, rb);
-    }
-#else
-    { asm volatile("" :: "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rb[0]), "v"(rb[1]), "v"(rb[2]), "v"(rb[3])); }
-#endif
-    __syncthreads();
-  }
-
-  nk_gemm_epilogue<OUT_F32>(p, smem, acc, m0, n0, tid, lane, wm, wn);
-}
-
 // =============================================================================================
 // v2 main loop: LDS-DMA staging (global_load_lds_dwordx4).  Register staging costs a ds_write_b128 per 16 bytes,
 // and ds_write_b128 moves only ~79 B/clk/CU: at 128x128x64 tiles the LDS write path alone (830 clk per pair of
@@ -452,9 +196,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void nk_gemm_kernel(const NkGemmParams
 //             ds_read_b64_tr_b16 land on 8 disjoint 32-byte bank windows (conflict-free)
 // =============================================================================================
 __device__ __attribute__((aligned(64))) unsigned int nk_zero_page[16];
-#ifdef NK_CLOCK_STAMPS
-__device__ unsigned long long nk_clock_stamps[8192];   // ablation builds: (shader clocks, 100 MHz ticks) of the main loop per workgroup
-#endif
 
 typedef __attribute__((address_space(1))) const void* nk_gptr;
 typedef __attribute__((address_space(3))) void* nk_lptr;
@@ -628,10 +369,6 @@ struct OperandDMA {
         int k = k0 + mc_k(i);
         const int v = mc_var(i);
         bool ok = (k < kend) && mc_valid(v);
-#ifdef NK_ABL_MCG_CHEAP     // tools/ablate: what would the conv weight gradient cost with a free pixel decode?  (wrong addresses, clock only)
-        src[i] = ok ? P + (long)((k & 4095) * 64 + mc_chunk(v) * 8) : zp;
-        continue;
-#endif
         unsigned p_ = ok ? (unsigned)k : 0u;
         unsigned n = fdiv(p_, g.fHoWo);
         unsigned rem = p_ - n * g.fHoWo.d;
@@ -697,7 +434,7 @@ struct OperandDMA {
     } else if constexpr (MODE == OP_MCG) {
       if (mplain) {
         // (the general form below costs ~45 vector instructions per piece and slab -- two magic-number divisions and a five-term
-        // 64-bit offset; with a free decode the conv weight gradients ran 20-32 % faster, tools/ablate NK_ABL_MCG_CHEAP)
+        // 64-bit offset; with a free decode the conv weight gradients ran 20-32 % faster: an ablation build of round 2)
         const bf16_t* zp = (const bf16_t*)nk_zero_page;
         const int q = (int)fdiv(64u, g.fWo);
         const int rm = 64 - q * g.Wo;
@@ -842,9 +579,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
     opa.issue_next(kend, smem, p.ga, p.tw);
     opb.issue_next(kend, smem + V2_OPND_BYTES, p.gb, p.tw);
   }
-#ifdef NK_CLOCK_STAMPS
-  unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
   for (int kt = 0; kt < nk; ++kt) {
     // vmcnt(0) + barrier: tile kt has landed for every wave, and every wave is done reading the other buffer.  The wait is
     // spelled out: left to __syncthreads(), hipcc has been seen placing it AFTER the barrier (it orders the DMA against this
@@ -903,12 +637,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
     }
   }
   __syncthreads();
-#ifdef NK_CLOCK_STAMPS
-  if (tid == 0 && blockIdx.x < 4096) {
-    nk_clock_stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - st_t0;
-    nk_clock_stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
-  }
-#endif
   nk_gemm_epilogue<OUT_F32, BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
@@ -1383,117 +1111,9 @@ __global__ __launch_bounds__(SK_NT, 4) void nk_gemm_sk_kernel(const NkGemmParams
           if (s_li <= ts) break;
         }
       }
-      if (!(p.sk_debug & 1) || acc[0][0][0] == 123.456f) sk_epilogue<OUT_F32>(p, C, acc, m0, n0, lane, wm, wn);
+      sk_epilogue<OUT_F32>(p, C, acc, m0, n0, lane, wm, wn);
     }
   }
-}
-
-// =============================================================================================
-// "big" variant (opt-in, see use_big) for grids of >= 2 rounds: 256x128x64 tiles, 512 threads (8 waves as 4x2, 64x64 per wave), ONE workgroup
-// per CU, a THREE-stage LDS-DMA ring (3 x 48 KiB) with counted s_waitcnt vmcnt and raw s_barrier so that two tiles
-// (96 KiB per CU) are always in flight.  Why: the 128x128 kernel is fed by LDS-DMA at ~15 TB/s chip-wide (29 B/clk/CU,
-// ablation: removing the MFMAs saves only 16 %), i.e. it is bound by bytes-in-flight / latency; this variant needs
-// 25 % fewer bytes per FLOP and keeps 1.5x more bytes in flight at the same 2 waves per SIMD.
-// k-contiguous operands only (Linear forward, Conv2d forward incl. the VAE encoder): the transposing LDS reads of the
-// r-contiguous modes make hipcc drain vmcnt(0), which would defeat the ring.
-// =============================================================================================
-#define BIG_BM 256
-#define BIG_NT 1024
-#define BIG_STAGE_BYTES (32768 + 16384)
-#define BIG_NSTAGE 3
-#define BIG_SMEM_BYTES (BIG_NSTAGE * BIG_STAGE_BYTES)   // 147456 >= 256*132*4 = 135168 (epilogue staging)
-static_assert(BIG_SMEM_BYTES >= BIG_BM * CS_LD * 4, "big epilogue staging must fit");
-
-// 16 waves as 4 x 4, 64 x 32 per wave (the same wave tile, fragment reads and 4 waves per SIMD as the 128x128 kernel at two
-// workgroups per CU) -- but ONE 256x128 workgroup per CU: 48 KiB instead of 64 KiB through the 64 B/clk texture path per
-// 2 x (128x128x64) of MFMA work, and a 3-stage ring (two slabs in flight) in the LDS the second workgroup would have used.
-// NW = 8 (NK_GEMM_BIG=8): the same tile with 8 waves as 4 x 2, 64 x 64 per wave -- 8 fragment reads per 16 MFMAs instead of 6 per 8
-// (a third less LDS traffic per FLOP), 2 waves per SIMD, 6 DMA pieces per wave and slab.  Measured (tools/vs_library.py):
-// 813 TFLOP/s at 65536 x 1280 x 1280 against 861 for NW = 16 and 848 for the default 128 x 128 kernel -- LDS read traffic is
-// not what limits this loop either; the feed (bytes in flight per CU between HBM/L2 and LDS) is.
-template <int AMODE, int OUT_F32, int NW = 16>
-__global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void nk_gemm_big_kernel(const NkGemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NJ = NW == 16 ? 2 : 4;          // 16-column fragments per wave
-  constexpr int NPA = NW == 16 ? 2 : 4, NPB = NW == 16 ? 1 : 2;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = NW == 16 ? wave >> 2 : wave >> 1, wn = NW == 16 ? wave & 3 : wave & 1;
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ntn = (p.N + BN - 1) / BN;
-  const int ntm = (p.M + BIG_BM - 1) / BIG_BM;
-  constexpr int GM = 4;                 // 4 x 8 tile patches: 32 workgroups per XCD at a time
-  const int per_group = GM * ntn;
-  const int group = wg / per_group;
-  const int first_m = group * GM;
-  const int gm = min(GM, ntm - first_m);
-  const int in_group = wg - group * per_group;
-  const int nt = in_group / gm;
-  const int mt = first_m + (in_group - nt * gm);
-  const int m0 = mt * BIG_BM, n0 = nt * BN;
-
-  const int kend = p.K;
-  const int nk = (p.K + BK - 1) / BK;
-
-  OperandDMA<AMODE, NPA> opa;   // NW waves x NPA pieces x 8 rows = 256 rows
-  OperandDMA<OP_KC, NPB> opb;   // NW waves x NPB pieces x 8 rows = 128 rows
-  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
-  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
-
-  float4_t acc[4][NJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int t = 0; t < BIG_NSTAGE - 1; ++t)
-    if (t < nk) {
-      opa.issue(t * BK, kend, smem + t * BIG_STAGE_BYTES, p.ga, p.tw);
-      opb.issue(t * BK, kend, smem + t * BIG_STAGE_BYTES + 32768, p.gb, p.tw);
-    }
-  int cur_stage = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // this wave issued 3 pieces per slab, in order; slab kt has landed once at most the 3 pieces of slab kt+1 remain
-    if (kt + 1 < nk) {
-      if constexpr (NW == 16) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();   // every wave's share of slab kt is in LDS; every wave is done reading stage (kt-1)%3
-    const char* cur = smem + cur_stage * BIG_STAGE_BYTES;
-    bf16x8_t af[2][4], bfr[2][NJ];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[ks][i] = OperandDMA<OP_KC>::frag(cur, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) bfr[ks][j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * (NJ * 16) + j * 16, ks, lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < nk) {
-      int ns = cur_stage + 2; if (ns >= BIG_NSTAGE) ns -= BIG_NSTAGE;
-      opa.issue((kt + 2) * BK, kend, smem + ns * BIG_STAGE_BYTES, p.ga, p.tw);
-      opb.issue((kt + 2) * BK, kend, smem + ns * BIG_STAGE_BYTES + 32768, p.gb, p.tw);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-    if (++cur_stage == BIG_NSTAGE) cur_stage = 0;
-  }
-  __syncthreads();
-  nk_gemm_epilogue<OUT_F32, BIG_BM, NW * 64, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // =============================================================================================
@@ -1547,54 +1167,25 @@ __global__ __launch_bounds__((XL_BM / WM) * (XL_BN / WN) * 64, (XL_BM / WM) * (X
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slab kt has landed (this wave's share) ...
     __syncthreads();                                    // ... for every wave, and everyone is done with the other stage
     const char* cur = smem + (kt & 1) * XL_STAGE_BYTES;
-#ifndef XL_ABL_NODMA       // (tools/ablate: the main loop with one of its parts removed; never defined in the product build)
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * XL_STAGE_BYTES;
       opa.issue_next(kend, nxt, p.ga, p.tw);
       opb.issue_next(kend, nxt + 32768, p.gb, p.tw);
     }
-#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t af[MI], bfr[NJ];
-#ifndef XL_ABL_NOREAD
 #pragma unroll
       for (int i = 0; i < MI; ++i) af[i] = OperandDMA<OP_KC>::frag(cur, wm * WM + i * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) bfr[j] = OperandDMA<OP_KC>::frag(cur + 32768, wn * WN + j * 16, ks, lane);
-#else
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = __builtin_bit_cast(bf16x8_t, (uint4_t){(unsigned)(kt + i), (unsigned)lane, 0x3c003c00u, (unsigned)ks});
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, (uint4_t){(unsigned)(kt - j), (unsigned)wave, 0x3c003c00u, (unsigned)ks});
-#endif
-#ifndef XL_ABL_NOMFMA
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)   // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-#else
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {   // keep the fragment reads alive with one VALU op per pair
-          const uint4_t ua = __builtin_bit_cast(uint4_t, af[i]), ub = __builtin_bit_cast(uint4_t, bfr[j]);
-          acc[i][j][0] += __uint_as_float((ua[0] ^ ub[3]) & 0x3fffffffu);
-        }
-#endif
     }
   }
-#ifdef XL_ABL_NOEPI
-  {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t != 123.456f) return;      // (practically always: the stores below are kept alive but never run)
-  }
-#endif
 #pragma unroll
   for (int ib = 0; ib < MI / 4; ++ib)
 #pragma unroll
@@ -1606,146 +1197,6 @@ __global__ __launch_bounds__((XL_BM / WM) * (XL_BN / WN) * 64, (XL_BM / WM) * (X
     }
 }
 
-// Software-pipelined form of the 8-wave shape (128 x 64 per wave): a slab is four phases of 16 MFMAs -- (k sub-step, half of the
-// wave's rows) -- and the fragments of phase n + 1 are read from LDS while phase n's MFMAs run, ACROSS the slab boundary too: the
-// barrier sits in front of the last phase, whose MFMAs then cover the first fragment reads of the next slab (in the plain form all
-// waves leave the barrier together and queue on LDS with nothing to multiply).
-template <int AMODE>
-__global__ __launch_bounds__(512, 2) void nk_gemm_xlp_kernel(const NkGemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NP = 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ntn = (p.N + XL_BN - 1) / XL_BN, ntm = (p.M + XL_BM - 1) / XL_BM;
-  constexpr int GM = 4;
-  const int per_group = GM * ntn;
-  const int group = wg / per_group;
-  const int first_m = group * GM;
-  const int gm = min(GM, ntm - first_m);
-  const int in_group = wg - group * per_group;
-  const int nt = in_group / gm;
-  const int m0 = (first_m + (in_group - nt * gm)) * XL_BM, n0 = nt * XL_BN;
-  const int kend = p.K, nk = (p.K + BK - 1) / BK;
-
-  OperandDMA<AMODE, NP> opa;
-  OperandDMA<OP_KC, NP> opb;
-  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
-  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
-  float4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-  // Fragment reads are inline asm with hand-counted s_waitcnt lgkmcnt: hipcc waits lgkmcnt(0) in front of every MFMA group, which
-  // would drain the reads just issued for the NEXT phase.  LDS reads return in order, so "all but the youngest n" is exact.  The
-  // sched_barriers keep the MFMAs behind the waits (the compiler believes an asm's outputs are ready at once).
-  bf16x8_t a0[4], a1[4], b0[4], b1[4];
-  typedef __attribute__((address_space(3))) const char* lds_c;
-  const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
-  const unsigned x0 = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4);              // 16-byte slot of k sub-step 0; sub-step 1 is x0 ^ 64
-  const unsigned arow = lds0 + (unsigned)(wm * 128 + (lane & 15)) * 128u;
-  const unsigned brow = lds0 + 32768u + (unsigned)(wn * 64 + (lane & 15)) * 128u;
-  const unsigned a_k0 = arow + x0, a_k1 = arow + (x0 ^ 64u), b_k0 = brow + x0, b_k1 = brow + (x0 ^ 64u);
-#define XLP_RD4(f, addr, OFF)                                                                                  \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[0]) : "v"(addr), "n"((OFF)));                          \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[1]) : "v"(addr), "n"((OFF) + 2048));                   \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[2]) : "v"(addr), "n"((OFF) + 4096));                   \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[3]) : "v"(addr), "n"((OFF) + 6144))
-#define XLP_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
-  auto mm = [&](int h, const bf16x8_t (&a)[4], const bf16x8_t (&b)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[h * 4 + i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  opa.start(0);
-  opb.start(0);
-  if (nk > 0) {
-    opa.issue_next(kend, smem, p.ga, p.tw);
-    opb.issue_next(kend, smem + 32768, p.gb, p.tw);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nk > 1) {
-      opa.issue_next(kend, smem + XL_STAGE_BYTES, p.ga, p.tw);
-      opb.issue_next(kend, smem + XL_STAGE_BYTES + 32768, p.gb, p.tw);
-    }
-    XLP_RD4(a0, a_k0, 0);
-    XLP_RD4(b0, b_k0, 0);
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned so = (unsigned)(kt & 1) * XL_STAGE_BYTES, sn = so ^ XL_STAGE_BYTES;
-    const unsigned ca0 = a_k0 + so, ca1 = a_k1 + so, cb1 = b_k1 + so, na0 = a_k0 + sn, nb0 = b_k0 + sn;
-    __builtin_amdgcn_sched_barrier(0);
-    XLP_RD4(a1, ca0, 8192);        // (k0, rows 64..127)
-    XLP_WAIT(4);                   // a0, b0 are in
-    mm(0, a0, b0);
-    XLP_RD4(a0, ca1, 0);           // (k1, rows 0..63)
-    XLP_RD4(b1, cb1, 0);
-    XLP_WAIT(8);                   // a1
-    mm(1, a1, b0);
-    XLP_RD4(a1, ca1, 8192);        // (k1, rows 64..127)
-    XLP_WAIT(4);                   // a0, b1
-    mm(0, a0, b1);
-    // every fragment of slab kt is in registers (its stage may be overwritten) and slab kt + 1 has landed -- for this wave; the
-    // barrier makes both true for the workgroup.  (On the last slab the reads below fetch a stale stage and are never used.)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // slab kt + 2 goes into the stage just freed, one 1 KiB piece behind every second MFMA of the last phase: issued in a
-    // burst right after the barrier the pieces of all waves queue on the CU's one address path with no MFMA in flight.
-    // (Past the end the sources are the zero page and the stage is never read: no branch.)
-    char* cur = smem + (kt & 1) * XL_STAGE_BYTES;
-    const bf16_t* sa[NP];
-    const bf16_t* sb[NP];
-    opa.next_sources(kend, sa, p.ga, p.tw);
-    opb.next_sources(kend, sb, p.gb, p.tw);
-    __builtin_amdgcn_sched_barrier(0);
-    XLP_RD4(a0, na0, 0);
-    XLP_RD4(b0, nb0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[4 + i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      opa.fire(i, sa[i], cur);
-      opb.fire(i, sb[i], cur + 32768);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#undef XLP_RD4
-#undef XLP_WAIT
-#pragma unroll
-  for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float4_t pair[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { pair[i][0] = acc[ib * 4 + i][2 * half]; pair[i][1] = acc[ib * 4 + i][2 * half + 1]; }
-      reg_epilogue_64x32<0>(p, p.C, pair, m0 + wm * 128 + ib * 64, n0 + wn * 64 + half * 32, lane);
-    }
-}
-
-// =============================================================================================
-// Two-group phased form of the 256 x 256 kernel (8 waves = 2 row groups x 4, 128 x 64 per wave).  A k-slab is FOUR phases, each
-//   { LDS fragment reads + at most one operand unit of LDS-DMA }  barrier  { 16 MFMAs on one quadrant of the wave's tile }  barrier
-// and the second group runs one barrier BEHIND the first (it takes one extra barrier before the loop, the first group one after
-// it), so at every moment one group's four waves -- one per SIMD -- multiply while the other group reads and stages: the MFMA pipes
-// and the memory path alternate owners instead of idling together.  The slab's operands are four 16 KiB units (A rows 0-127 and
-// 128-255, B rows 0-127 and 128-255; unit Ag is read by group g only), staged by all eight waves, never drained:
-//   phase 0 of slab t: A1(t+1)   phase 1: A0(t+1)   phase 3: B0(t+2), B1(t+2) into the CURRENT stage, then s_waitcnt vmcnt(4)
-// With intervals numbered so that group 0 reads in 8t+2q and multiplies in 8t+2q+1 (group 1 one later), the last reads of slab t
-// retire by 8t+4 (B), 8t+5 (A0), 8t+6 (A1) and its buffers are first overwritten in 8t+6 (B), 8t+10 (A0), 8t+8 (A1); slab t+1
-// is first read in 8t+8, after every wave has passed the vmcnt(4) of its phase 3 of slab t (all but the four B pieces just
-// issued have landed) and the barrier behind it.
-// =============================================================================================
 template <int AMODE>
 __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1905,13 +1356,10 @@ static int launch_xl_as(const NkGemmParams& p, hipStream_t stream) {
 }
 template <int AMODE>
 static int launch_xl(const NkGemmParams& p, hipStream_t stream) {
-  // NK_GEMM_XL_WAVES: unset = by operand mode (dense k-contiguous A: the two-group phased kernel, +3..6 % on the Linear shapes;
-  // gathered A: the 16-wave kernel -- the gather's address arithmetic sits in the phased kernel's read phases, where only one wave
-  // per SIMD is there to absorb it: conv forward 781-785 vs 835-840 TFLOP/s); 12 / 16 force one of them; 8, 4, 9 = the variants of
-  // DESIGN 3.1's table
-  static int shape = -1;
-  if (shape < 0) { const char* e = getenv("NK_GEMM_XL_WAVES"); shape = e ? atoi(e) : 0; }
-  if (shape == 12 || (shape == 0 && AMODE == OP_KC)) {
+  // by operand mode: dense k-contiguous A -> the two-group phased kernel (+3..6 % on the Linear shapes); gathered A -> the 16-wave kernel
+  // (the gather's address arithmetic would sit in the phased kernel's read phases, where only one wave per SIMD is there to absorb it:
+  // conv forward 781-785 vs 835-840 TFLOP/s)
+  if (AMODE == OP_KC) {
     static bool gattr = false;
     auto kern = nk_gemm_xl2g_kernel<AMODE>;
     if (!gattr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES); gattr = true; }
@@ -1919,70 +1367,22 @@ static int launch_xl(const NkGemmParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(512), XL_SMEM_BYTES, stream, p);
     return nk_check_launch("nk_gemm_xl2g_kernel");
   }
-  if (shape == 9) {
-    static bool pattr = false;
-    auto kern = nk_gemm_xlp_kernel<AMODE>;
-    if (!pattr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES); pattr = true; }
-    dim3 grid(((p.M + XL_BM - 1) / XL_BM) * ((p.N + XL_BN - 1) / XL_BN), 1, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(512), XL_SMEM_BYTES, stream, p);
-    return nk_check_launch("nk_gemm_xlp_kernel");
-  }
-  if (shape == 8) return launch_xl_as<AMODE, 128, 64>(p, stream);
-  if (shape == 4) return launch_xl_as<AMODE, 128, 128>(p, stream);
   return launch_xl_as<AMODE, 64, 64>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static bool use_big(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
-  // EXPERIMENTAL, opt-in (NK_GEMM_BIG=1): measured 5-10 % SLOWER than the 128x128 kernel at two workgroups per CU on
-  // every SDXL shape (e.g. 16384x5120x640: 653 vs 717 TFLOP/s), so it is not dispatched by default; kept as the base of
-  // the 256x256 variant planned next.
-  static int dis = -1;
-  if (dis < 0) { const char* e = getenv("NK_GEMM_BIG"); dis = (e && (e[0] == '1' || e[0] == '8')) ? 0 : 1; }
-  if (dis || p.nbatch || out_f32 || splitk != 1 || bmode != OP_KC || !(amode == OP_KC || amode == OP_KCG)) return false;
-  long tiles = (long)((p.M + BIG_BM - 1) / BIG_BM) * ((p.N + BN - 1) / BN);
-  return tiles >= 256 && p.K >= 4 * BK;
-}
-
-template <int AMODE>
-static int launch_big(const NkGemmParams& p, hipStream_t stream) {
-  static bool attr_set = false;
-  static int nw = 0;
-  auto kern = nk_gemm_big_kernel<AMODE, 0, 16>;
-  auto kern8 = nk_gemm_big_kernel<AMODE, 0, 8>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_SMEM_BYTES);
-    const char* e = getenv("NK_GEMM_BIG");
-    nw = (e && e[0] == '8') ? 8 : 16;
-    attr_set = true;
-  }
-  dim3 grid(((p.M + BIG_BM - 1) / BIG_BM) * ((p.N + BN - 1) / BN), 1, 1);
-  if (nw == 8) hipLaunchKernelGGL(kern8, grid, dim3(512), BIG_SMEM_BYTES, stream, p);
-  else hipLaunchKernelGGL(kern, grid, dim3(BIG_NT), BIG_SMEM_BYTES, stream, p);
-  return nk_check_launch("nk_gemm_big_kernel");
-}
-
-static bool use_v1() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NK_GEMM_V1"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
-
 template <int AMODE, int BMODE, int OUT_F32>
 static int launch(const NkGemmParams& p_in, int splitk, hipStream_t stream) {
   NkGemmParams p2 = p_in;
   const NkGemmParams& p = p2;
   static bool attr_set = false;
-  auto kern1 = nk_gemm_kernel<AMODE, BMODE, OUT_F32>;
-  auto kern4 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32, 4>;
-  auto kern8 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32, 8>;
+  auto kern8 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32, 8>;      // 8 waves per 128 x 128 tile: +4..14 % over 4 waves on every SDXL shape
+  auto kernr = nk_gemm_ring_kernel<AMODE, BMODE, OUT_F32>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)kern4, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
     (void)hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)kernr, hipFuncAttributeMaxDynamicSharedMemorySize, RING_SMEM_BYTES);
     attr_set = true;
   }
   int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
@@ -1991,27 +1391,16 @@ static int launch(const NkGemmParams& p_in, int splitk, hipStream_t stream) {
      // panels, least at gm = sqrt(T/8).  (A fixed 8 gave a 100-tile weight gradient 8 x 1.5 patches: 10 panels per XCD where 7 do.)
     int per_xcd = (ntm * ntn + 7) / 8, g = 1;
     while ((g + 1) * (g + 1) <= per_xcd) ++g;
-    if (const char* e = getenv("NK_GEMM_GROUP_M")) g = atoi(e);
-    p2.group_m = g < 1 ? 1 : (g > GROUP_M ? GROUP_M : g);
+    p2.group_m = g > GROUP_M ? GROUP_M : g;
   }
-  // 8 waves per 128x128 tile by default: measured +4..14 % over 4 waves on every SDXL shape (A/B: NK_GEMM_NW=4)
-  int nw = 8;
-  if (const char* e = getenv("NK_GEMM_NW")) nw = atoi(e);
-  int ring = 1;
-  if (const char* e = getenv("NK_GEMM_RING")) ring = atoi(e);
-  // (the ring at one workgroup per CU on LARGE grids was measured too: 723 vs 830 TFLOP/s at 65536 x 1280 x 1280 -- three slabs in
-  // flight do not make up for two waves per SIMD meeting at a barrier every k-step)
-  if (ring && !use_v1() && nw == 8 && !p.nbatch && (long)ntm * ntn * splitk <= 256) {
-    auto kernr = nk_gemm_ring_kernel<AMODE, BMODE, OUT_F32>;
-    static bool rattr = false;
-    if (!rattr) { (void)hipFuncSetAttribute((const void*)kernr, hipFuncAttributeMaxDynamicSharedMemorySize, RING_SMEM_BYTES); rattr = true; }
+  // under-filled grids (at most one workgroup per CU): the four-stage ring.  (The ring on LARGE grids was measured too: 723 vs 830 TFLOP/s
+  // at 65536 x 1280 x 1280 -- three slabs in flight do not make up for two waves per SIMD meeting at a barrier every k-step.)
+  if (!p.nbatch && (long)ntm * ntn * splitk <= 256) {
     hipLaunchKernelGGL(kernr, grid, dim3(512), RING_SMEM_BYTES, stream, p);
     return nk_check_launch("nk_gemm_ring_kernel");
   }
-  if (use_v1()) hipLaunchKernelGGL(kern1, grid, dim3(NTHREADS), SMEM_BYTES, stream, p);
-  else if (nw == 8) hipLaunchKernelGGL(kern8, grid, dim3(512), V2_SMEM_BYTES, stream, p);
-  else hipLaunchKernelGGL(kern4, grid, dim3(NTHREADS), V2_SMEM_BYTES, stream, p);
-  return nk_check_launch("nk_gemm_kernel");
+  hipLaunchKernelGGL(kern8, grid, dim3(512), V2_SMEM_BYTES, stream, p);
+  return nk_check_launch("nk_gemm_dma_kernel");
 }
 
 
@@ -2110,16 +1499,12 @@ static int launch_sk(NkGemmParams& p, hipStream_t stream) {
   const long ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nk = (p.K + BK - 1) / BK;
   const long T = ntm * ntn * (p.nbatch ? p.nbatch : 1), W = T * nk;
   // persistent grid: two workgroups per CU, at least ~4 k-steps each
-  int max_grid = SK_MAX_GRID, min_iters = 4;
-  if (const char* e = getenv("NK_SK_GRID")) max_grid = atoi(e);
-  if (max_grid < 8 || max_grid > SK_MAX_GRID) max_grid = SK_MAX_GRID;
-  max_grid &= ~7;
-  if (const char* m = getenv("NK_SK_MIN_ITERS")) min_iters = atoi(m) > 0 ? atoi(m) : 4;
+  const int max_grid = SK_MAX_GRID & ~7, min_iters = 4;
   long grid = (W / min_iters) & ~7l;
   if (grid > max_grid) grid = max_grid;
   if (grid < 8) grid = 8;
   p.sk_chunked = T >= 64;
-  { const char* d = getenv("NK_SK_DEBUG"); p.sk_debug = d ? atoi(d) : 0; }
+  { const char* d = getenv("NK_SK_DEBUG"); p.sk_debug = d ? atoi(d) & 2 : 0; }      // fault injection for tests/test_health_gpu.py
   if (int e = sk_prepare(p, (int)grid, stream)) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SK_NT), SK_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_sk_kernel");
@@ -2140,9 +1525,7 @@ static int pick_splitk(int M, int N, int K, int max_split) {
   // on the other stream (dgrad chain vs weight-gradient stream).
   int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int nk = (K + BK - 1) / BK;
-  int lo = 96, hi = 192;
-  if (const char* e = getenv("NK_SPLIT_LO")) lo = atoi(e);
-  if (const char* e = getenv("NK_SPLIT_HI")) hi = atoi(e);
+  const int lo = 96, hi = 192;
   if (tiles >= lo) return 1;
   int s = 1;
   while (s < max_split && tiles * s < hi && nk / (s * 2) >= 8) s *= 2;
@@ -2172,14 +1555,14 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   if (!out_f32) NK_CHECK_ARG((p.ldc & 7) == 0 || (p.N & 7) != 0);
   if (p.fRowsPerBatch.d == 0) p.fRowsPerBatch = make_fastdiv(1);
 
-  if (p.dbias || (p.nbatch && p.dbias_b[0])) NK_CHECK_ARG(amode == OP_MC && out_f32 && !use_v1());      // weight-gradient launches only
+  if (p.dbias || (p.nbatch && p.dbias_b[0])) NK_CHECK_ARG(amode == OP_MC && out_f32);      // weight-gradient launches only
   if (p.geglu_u) {   // the fused GEGLU backward lives in the LDS-staged epilogue of the 128 x 128 data-parallel / ring kernels only
     NK_CHECK_ARG(amode == OP_KC && bmode == OP_MC && !out_f32 && !p.nbatch && (p.N & 7) == 0 && (p.ld_u & 7) == 0 && !p.bias && !p.rowvec && !p.residual);
     set_split(p, 1);
     return launch<OP_KC, OP_MC, 0>(p, 1, stream);
   }
   // 3 x 3 / stride 1 / padding 1 convolutions over whole 64-channel slabs: the halo-tile kernel (conv_halo.h)
-  if (!use_v1() && use_halo(p, amode, bmode, out_f32)) return launch_halo(p, stream);
+  if (use_halo(p, amode, bmode, out_f32)) return launch_halo(p, stream);
   if (p.stats_part) {      // the GroupNorm statistics epilogue exists in the halo-tile kernel only
     nk_set_error(__FILE__, __LINE__, "statistics epilogue on a convolution the halo-tile kernel does not take (ask nk_conv2d_stats_tiles first)");
     return NK_ERR_ARG;
@@ -2187,7 +1570,7 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
 
   // two-group staggered ring at one workgroup per CU (gemm_g2.h): Linear forward / dgrad / wgrad shapes whose 128 x 160 (or
   // 128 x 128) tiles come out in whole rounds of 256
-  if (!use_v1() && (!p.nbatch || p.nbatch <= NK_MAX_BATCH) && use_g2(p, amode, bmode, out_f32, 1) && (g2_mode() == 2 || !use_xl(p, amode, bmode, out_f32, 1))) {
+  if ((!p.nbatch || p.nbatch <= NK_MAX_BATCH) && use_g2(p, amode, bmode, out_f32, 1) && (g2_mode() == 2 || !use_xl(p, amode, bmode, out_f32, 1))) {
     if (p.accumulate == 2) p.accumulate = 0;       // no K split here: "destination known zero" means plain stores
     if (amode == OP_KC && bmode == OP_KC) return out_f32 ? launch_g2<OP_KC, OP_KC, 1>(p, stream) : launch_g2<OP_KC, OP_KC, 0>(p, stream);
     if (amode == OP_KC && bmode == OP_MC) return out_f32 ? launch_g2<OP_KC, OP_MC, 1>(p, stream) : launch_g2<OP_KC, OP_MC, 0>(p, stream);
@@ -2196,7 +1579,7 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
     return out_f32 ? launch_g2<OP_MC, OP_MC, 1>(p, stream) : launch_g2<OP_MC, OP_MC, 0>(p, stream);
   }
 
-  if (!use_v1() && use_sk(p, out_f32)) {
+  if (use_sk(p, out_f32)) {
     const long ntm_ = (p.M + BM - 1) / BM, ntn_ = (p.N + BN - 1) / BN, nk_ = (p.K + BK - 1) / BK;
     if (ntm_ * ntn_ * (p.nbatch ? p.nbatch : 1) * nk_ < (1l << 22)) {   // share arithmetic is 32-bit: W * grid < 2^31
       if (p.accumulate == 2) p.accumulate = 0;     // "destination known zero" only matters to the atomic split-K path
@@ -2213,7 +1596,7 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   }
   int splitk = 1;
   if (out_f32 && allow_splitk) splitk = pick_splitk(p.M * (p.nbatch ? p.nbatch : 1), p.N, p.K, 32);
-  if (p.nbatch) NK_CHECK_ARG(p.nbatch <= NK_MAX_BATCH && !use_v1());
+  if (p.nbatch) NK_CHECK_ARG(p.nbatch <= NK_MAX_BATCH);
   set_split(p, splitk);
   // accumulate: 0 = overwrite, 1 = add, 2 = the destination is known to be zero (flat gradient buffer right after
   // zero_grad): plain stores when there is a single K split, atomics otherwise -- and no memset either way
@@ -2238,8 +1621,6 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
 
   if (use_xl(p, amode, bmode, out_f32, splitk))
     return amode == OP_KC ? launch_xl<OP_KC>(p, stream) : launch_xl<OP_KCG>(p, stream);
-  if (use_big(p, amode, bmode, out_f32, splitk))
-    return amode == OP_KC ? launch_big<OP_KC>(p, stream) : launch_big<OP_KCG>(p, stream);
 
 #define NK_CASE(A_, B_)                                                          \
   if (amode == A_ && bmode == B_) {                                              \

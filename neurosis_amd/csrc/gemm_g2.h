@@ -474,14 +474,9 @@ static bool use_g2(const NkGemmParams& p, int amode, int bmode, int out_f32, int
         (conv && (bmode == OP_KC || bmode == OP_MCT))))
     return false;
   if (p.K < 2 * BK) return false;
-  {  // NK_GEMM_G2_MASK (A/B runs): bit 0 forward (KC x KC), bit 1 dgrad (KC x MC), bit 2 wgrad (MC x MC), bit 3 conv forward
-     // (KCG x KC), bit 4 conv dgrad (KCG x MCT), bit 5 the BATCHED weight gradients alone; default 59
-    int mask = 59;  // not the single weight gradients (in the two-stream step they do better with the co-resident 128 x 128 kernels: 187.6 vs
-                    // 189.0 ms); the batched ones (three 1280 x 1280 per launch = 240 tiles, one round) do: 49.7 vs 65.4 us alone, 177.2 vs 177.6 ms/step
-    if (const char* e = getenv("NK_GEMM_G2_MASK")) mask = atoi(e);
-    const int bit = conv ? (bmode == OP_KC ? 8 : 16) : (amode == OP_KC && bmode == OP_KC) ? 1 : (amode == OP_KC ? 2 : (p.nbatch ? 36 : 4));
-    if (!(mask & bit)) return false;     // (bit 5 = 32: the batched weight gradients alone)
-  }
+  // not the SINGLE weight gradients: in the two-stream step they do better with the co-resident 128 x 128 kernels (187.6 vs 189.0 ms);
+  // the batched ones (three 1280 x 1280 per launch = 240 tiles, one round) do better here: 49.7 vs 65.4 us alone, 177.2 vs 177.6 ms/step
+  if (amode == OP_MC && bmode == OP_MC && !p.nbatch) return false;
   const int bn = g2_bn(p.N);
   if (!bn) return false;
   if (mode == 2) return true;

@@ -53,7 +53,7 @@ struct NkGemmParams {
   unsigned sk_epoch;        // (unused: no per-launch state, so a launch replayed from a hipGraph is a fresh one)
   float* sk_ws;             // [grid][128*128] fp32 partial tiles in accumulator-register order
   int sk_chunked;           // 1: each XCD owns a contiguous eighth of the tile list
-  int sk_debug;             // NK_SK_DEBUG: 1 = no epilogue stores (ablation), 2 = every fix-up wait gives up at once (tests the fail-closed path)
+  int sk_debug;             // NK_SK_DEBUG=2 (fault injection): every fix-up wait gives up at once -- tests the fail-closed path
   unsigned* sk_health;      // backward-health word (errors.hip): raised when a fix-up wait gives up
   // weight-gradient launches (A = dy, r-contiguous): the bias gradient dbias[m] (+)= sum_k A(m, k), accumulated by the first column tile of
   // every row block with one extra MFMA per row block and k sub-step against a fragment of ones (the dy panel is already in registers)

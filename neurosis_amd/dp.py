@@ -163,8 +163,7 @@ class FlatDataParallel:
                 ops.join_wgrad_stream(self.store.params[0])
                 self.reducer.reduce_range(lo, hi)
             else:
-                # (under graph replay the small parameter-gradient reductions of the slice run on a third stream)
-                self.reducer.reduce_range(lo, hi, also_wait=[self.store.state.wgrad_stream, self.store.state.aux_stream])
+                self.reducer.reduce_range(lo, hi, also_wait=self.store.state.wgrad_stream)
 
     def no_sync(self, flag: bool = True) -> None:
         """Gradient accumulation: skip the exchange on all but the last micro-batch (DDP's no_sync)."""

@@ -99,15 +99,7 @@ class ChainGraphs:
             pair = self.pairs[key] = _Pair()
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=self.owner.device)
-            self.pool, self.pool_w, self.pool_a = (torch.cuda.graph_pool_handle() for _ in range(3))
-            # NK_GRAPH_AUX=1: a third stream for the few-microsecond reductions (bias column sums, LayerNorm parameter gradients),
-            # ~600 per step that otherwise queue between the weight-gradient GEMMs of the side stream.  Measured: the side stream
-            # then ends 1.0-1.5 ms after the main chain instead of 4.0, the main chain is 2.4 ms slower, the step does not move
-            # (177.9 / 177.5 vs 178.0 / 177.3 ms, alternating): off by default.
-            st = ops.state_of(self.owner)
-            if st.wgrad_stream is not None and os.environ.get("NK_GRAPH_AUX", "0") == "1":
-                if st.aux_stream is None:
-                    st.aux_stream = torch.cuda.Stream(device=self.owner.device)
+            self.pool, self.pool_w = (torch.cuda.graph_pool_handle() for _ in range(2))
             self.ticks = torch.zeros(1, dtype=torch.int32, device=self.owner.device)   # backward replays so far, counted on the device
         if not pair.warm or self.broken:
             return self._warm(pair, fwd, inputs)
@@ -207,28 +199,19 @@ class ChainGraphs:
             if module is None:
                 self.ticks.add_(1)        # (the tail after the last block may hold no launch at all: an empty graph cannot be instantiated)
             cur[0].capture_end()
-            g_m, g_w, g_a = cur[0], None, None
+            g_m, g_w = cur[0], None
             parked, st.deferred = st.deferred, ([] if side is not None else None)
             if parked:
-                aux = st.aux_stream
-                for stream, pool, part in ((side, self.pool_w, [e for e in parked if aux is None or not e[2]]),
-                                           (aux, self.pool_a, [e for e in parked if aux is not None and e[2]])):
-                    if not part:
-                        continue
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.stream(stream):
-                        g.capture_begin(pool=pool, capture_error_mode="thread_local")
-                        try:
-                            for fn, _reads, _small in part:
-                                fn()
-                        finally:
-                            g.capture_end()
-                    if stream is side:
-                        g_w = g
-                    else:
-                        g_a = g
-                held.append(parked)       # the closures hold what W_k / A_k read: nothing of it may be recycled by a later M capture
-            segments.append((g_m, g_w, g_a, module))
+                g_w = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    g_w.capture_begin(pool=self.pool_w, capture_error_mode="thread_local")
+                    try:
+                        for fn, _reads in parked:
+                            fn()
+                    finally:
+                        g_w.capture_end()
+                held.append(parked)       # the closures hold what W_k reads: nothing of it may be recycled by a later M capture
+            segments.append((g_m, g_w, module))
 
         def boundary(module):
             cut(module)
@@ -252,26 +235,20 @@ class ChainGraphs:
 
     def _replay_backward(self, pair: _Pair) -> None:
         st = ops.state_of(self.owner)
-        side, aux = st.wgrad_stream, st.aux_stream
+        side = st.wgrad_stream
         main = torch.cuda.current_stream()
         hook = self.hook()
-        for g_m, g_w, g_a, module in pair.segments:
+        for g_m, g_w, module in pair.segments:
             g_m.replay()
             if g_w is not None:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     g_w.replay()
-            if g_a is not None:
-                aux.wait_stream(main)
-                with torch.cuda.stream(aux):
-                    g_a.replay()
             if hook is not None and module is not None:
                 hook(module)
             self.replays += 1
         if side is not None:
             main.wait_stream(side)
-        if aux is not None:
-            main.wait_stream(aux)
 
 
 def _tree_map(fn: Callable, obj):

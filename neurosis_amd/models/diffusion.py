@@ -71,10 +71,10 @@ class DiffusionEngine(nn.Module):
         self.overlap_optimizer = os.environ.get("NK_OPT_OVERLAP", "1") != "0"
         self._optimizer_stream: Optional[torch.cuda.Stream] = None
         self._optimizer_in_flight = False
-        # NK_OPT_STREAM=1: stream the update of each top-level UNet block behind that block's backward (_grads_ready).  Off by
-        # default -- measured 187.4 vs 184.9 ms/step (tools/ab_step.py, interleaved): the HBM-bound update steals bandwidth from a
-        # backward whose two streams already contend, while after backward it overlaps the next step's frozen VAE encoder for free.
-        self.stream_optimizer = os.environ.get("NK_OPT_STREAM", "0") == "1"
+        # stream_optimizer = True: stream the update of each top-level UNet block behind that block's backward (_grads_ready).  Off by
+        # default -- measured 187.4 vs 184.9 ms/step (interleaved): the HBM-bound update steals bandwidth from a backward whose two streams
+        # already contend, while after backward it overlaps the next step's frozen VAE encoder for free.
+        self.stream_optimizer = False
         self._streaming_step = False
         self._last_micro_batch = True
         self.store: Optional[FlatParamStore] = None

@@ -329,13 +329,10 @@ class SpatialTransformer(nn.Module):
         def bwd(dy: Tensor):
             dh = b_out(dy)
             dctx = None
-            cut = ops.fine_cut(self.proj_out.weight)                    # hipGraph capture: a finer cut than the top-level blocks, so that a
-            for b in reversed(blocks):                                  # transformer block's weight gradients start when ITS chain is done
+            for b in reversed(blocks):
                 dh, dc = b(dh)
                 if dc is not None:
                     dctx = dc if dctx is None else ops.add(dctx, dc)
-                if cut is not None:
-                    cut(None)
             blocks.clear()
             dx = b_gn(b_in(dh), dy)   # GroupNorm backward + the "+ x_in" branch
             return dx, dctx

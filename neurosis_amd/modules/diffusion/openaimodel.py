@@ -60,7 +60,6 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
 
         def bwd(dy: Tensor):
             demb = None
-            cut = ops.fine_cut(next(self.parameters(), None))      # (hipGraph capture: cut after every layer of the block)
             for kind, b in reversed(bwds):
                 if dy is None:
                     break
@@ -72,8 +71,6 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 else:
                     dyi, _ = b(dy)
                     dy = None if dyi is None else dyi.t
-                if cut is not None:
-                    cut(None)
             bwds.clear()
             return dy, demb
 
@@ -439,7 +436,7 @@ class UNetModel(nn.Module):
         # (frozen_stamp: the captured kernels read the weights' bf16 shadows by address -- a flat store keeps them in place, free
         # parameters get new ones whenever they change; ~0.4 ms of host time per call for the SDXL UNet's 1 700 tensors)
         return self._nk_graphs.run(lambda t, ts, c, yy: self.fwd(Img(t, N, H, W), ts, c, yy), [x.t, timesteps, context, y],
-                                   extra_key=(N, H, W, frozen_stamp(self), self.training, os.environ.get("NK_KV_HOIST", "1")))
+                                   extra_key=(N, H, W, frozen_stamp(self), self.training))
 
     def fwd(self, x: Img, timesteps: Tensor, context: Optional[Tensor], y: Optional[Tensor]):
         """x: Img with channels padded to a multiple of 8.  Returns (out Img (padded channels), bwd);
@@ -451,7 +448,7 @@ class UNetModel(nn.Module):
         if self.num_classes is not None:
             lab, b_label = self._mlp_fwd(self.label_emb[0], y, need_dx=False)
             emb = ops.add(emb, lab)
-        if context is not None and os.environ.get("NK_KV_HOIST", "1") != "0":     # (read per call: tools/ab_step.py flips it)
+        if context is not None:
             self._project_context(context)
         hs: List[Img] = []
         tape = []

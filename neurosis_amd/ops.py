@@ -52,14 +52,13 @@ class EngineState:
         # 203.9 ms/step in round 1, +5.5 ms in round 2: 210 more cross-stream event waits per step delay the weight-gradient GEMMs
         # queued behind them).  Under hipGraph replay those waits are gone -- the parked launches become part of each segment's
         # side-stream graph -- and the main chain sheds ~4 ms of small kernels: 177.2 / 177.1 vs 178.2 / 178.7 ms/step (bench.py,
-        # alternating).  So: on where the chain replays from graphs (the default), off with NK_GRAPH=0; NK_LN_SIDE=0|1 overrides.
-        self.norm_params_on_side_stream = os.environ.get("NK_LN_SIDE", "0" if os.environ.get("NK_GRAPH", "unet") == "0" else "1") == "1"
+        # alternating).  So: on where the chain replays from graphs (the default), off with NK_GRAPH=0.
+        self.norm_params_on_side_stream = os.environ.get("NK_GRAPH", "unet") != "0"
         # hipGraph capture of a backward chain (neurosis_amd/graphs.py): while `deferred` is a list, on_wgrad_stream() parks the
         # side-stream work there instead of launching it, and the chain reports the end of each top-level block to
         # `segment_hook`, which captures the parked launches as that segment's own graph
         self.deferred: Optional[list] = None
         self.segment_hook: Optional[Callable] = None
-        self.aux_stream = None      # graph replay: a third stream for the small parameter-gradient reductions (graphs.py)
         EngineState._live.add(self)
 
     def derived(self) -> "EngineState":
@@ -90,17 +89,6 @@ state = EngineState()
 state.param_epoch = 0  # process-wide "some parameter changed" counter (keys of captured graphs); bumped by every store
 
 
-def fine_cut(p):
-    """The hipGraph capture's segment hook for cuts INSIDE a top-level block (after every layer, after every transformer block), or
-    None.  With cuts at top-level blocks only (23 segments) a block's weight gradients start when the whole block's chain is done
-    and the side stream ends 4.0 ms after the main chain; with the fine cuts (126 segments) 0.1-0.3 ms after it
-    (tools/side_lag_graph.py) -- but the main chain is that much slower beside the busier side stream, and the step does not move
-    (182.4 / 182.2 fine vs 182.1 / 183.0 coarse, alternating on one box).  NK_GRAPH_FINE=1 selects the fine cuts; default coarse."""
-    if p is None or os.environ.get("NK_GRAPH_FINE", "0") != "1":
-        return None
-    return state_of(p).segment_hook
-
-
 def state_of(p) -> EngineState:
     """The engine state that governs parameter `p`: its own tag, its store's, or the default."""
     if p is not None:
@@ -121,7 +109,7 @@ def wgrad_mode(p=None) -> int:
     return 2 if st.assume_zeroed else 0
 
 
-def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None, small: bool = False) -> None:
+def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None) -> None:
     """Run `fn` (kernels that only WRITE parameter gradients of `owner`'s engine) on that engine's side stream if it has one.
 
     Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads them until the optimizer /
@@ -135,9 +123,7 @@ def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None, small: b
         fn()
         return
     if st.deferred is not None:
-        # `small`: a few-microsecond reduction (bias column sums, LayerNorm parameter gradients).  Under graph replay those go to a
-        # third stream of their own (neurosis_amd/graphs.py): ~600 of them per step otherwise sit between the weight-gradient GEMMs
-        st.deferred.append((fn, reads, small))
+        st.deferred.append((fn, reads))
         return
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -224,8 +210,6 @@ def join_wgrad_stream(owner=None) -> None:
         side = st.wgrad_stream
         if side is not None and st.deferred is None:
             torch.cuda.current_stream().wait_stream(side)
-            if st.aux_stream is not None:
-                torch.cuda.current_stream().wait_stream(st.aux_stream)
         return
     seen = set()
     for st in list(EngineState._live):
@@ -670,14 +654,9 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
         dx = torch.empty_like(x)
         ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
         acc = state_of(weight).grad_accumulate
-        if not state_of(weight).norm_params_on_side_stream and os.environ.get("NK_LN_FUSED", "0") == "1":
-            # NK_LN_FUSED=1: ONE pass over x and dy (nk_layernorm_bwd: input gradient + per-block partials of the gamma / beta gradients,
-            # 6 B/elem instead of 10).  Off by default: in the real step it measured 180.6 vs 178.7 ms (tools/ab_step.py) -- these
-            # 10-20 MB tensors are latency-bound, the second read of x, dy by the parameter kernel comes out of the Infinity Cache, and
-            # the fused kernel's 72 extra accumulator registers per lane cost it the waves that hide latency.
-            call("nk_layernorm_bwd", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add), dx.data_ptr(),
-                 grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, int(acc), _stream())
-            return dx
+        # (two kernels, not the one-pass nk_layernorm_bwd the C-ABI also offers: in the real step the fused form measured 180.6 vs 178.7 ms --
+        # these 10-20 MB tensors are latency-bound, the parameter kernel's second read of x, dy comes out of the Infinity Cache, and the fused
+        # kernel's 72 extra accumulator registers per lane cost it the waves that hide latency)
         call("nk_layernorm_bwd_dx", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
              dx.data_ptr(), M, Cc, _stream())
 
@@ -686,7 +665,7 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
                  grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, int(acc), _stream())
 
         if state_of(weight).norm_params_on_side_stream:
-            on_wgrad_stream(params, dy, x, mean, rstd, ws, owner=weight, small=True)
+            on_wgrad_stream(params, dy, x, mean, rstd, ws, owner=weight)
         else:
             params()
         return dx

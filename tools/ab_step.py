@@ -1,5 +1,5 @@
 """In-process A/B of training-step variants (same device, interleaved rounds): prints ms/step per variant.
-usage: ab_step.py [variant ...]   a variant is a built-in name ("no g2", "batch", "mask7", "hp main stream", ...) or ENV=VALUE[,ENV=VALUE...];
+usage: ab_step.py [variant ...]   a variant is a built-in name ("no g2", "no batch", "no halo conv", "hp main stream", ...) or ENV=VALUE[,ENV=VALUE...];
 "base" always runs.  With no arguments every built-in runs."""
 import os; os.environ.setdefault("NK_GRAPH", "0")   # this tool watches / flips the Python-side launches: keep the eager chain
 import os, sys, time, torch
@@ -23,10 +23,10 @@ def main():
     variants["no g2"] = lambda: os.environ.__setitem__("NK_GEMM_G2", "0")
     variants["no batch"] = lambda: setattr(est, "batch_wgrads", False)
     variants["ln params on side stream"] = lambda: setattr(est, "norm_params_on_side_stream", True)
-    variants["g2 wgrad, no batch"] = lambda: (setattr(est, "batch_wgrads", False), os.environ.__setitem__("NK_GEMM_G2_MASK", "63"))
-    variants["g2 wgrad"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "63")
+    variants["no halo conv"] = lambda: os.environ.__setitem__("NK_CONV_HALO", "0")
+    variants["no stream-K"] = lambda: os.environ.__setitem__("NK_GEMM_SK", "0")
+    variants["streamed optimizer"] = lambda: setattr(eng, "stream_optimizer", True)
     variants["hp main stream"] = lambda: None
-    variants["hp main + g2 wgrad"] = lambda: os.environ.__setitem__("NK_GEMM_G2_MASK", "63")
     asked = [a for a in sys.argv[1:] if "=" in a]
     for name in asked:              # extra variants from the command line: ENV=VALUE[,ENV=VALUE...]
         kv = [a.split("=", 1) for a in name.split(",")]
@@ -36,7 +36,7 @@ def main():
         variants = {k: v for k, v in variants.items() if k == "base" or k in sys.argv[1:]}
     def restore():
         est.wgrad_stream = side; est.batch_wgrads = True; eng.stream_optimizer = False; est.norm_params_on_side_stream = False
-        os.environ["NK_GEMM_G2"] = "1"; os.environ.pop("NK_GEMM_G2_MASK", None)
+        for k in ("NK_GEMM_G2", "NK_CONV_HALO", "NK_GEMM_SK"): os.environ.pop(k, None)
         for k in extra_env: os.environ.pop(k, None)
     for _ in range(3): step()
     import gc; gc.collect(); gc.freeze()      # (the cyclic GC's full collections otherwise show up as 200+ ms steps: DESIGN section 7)

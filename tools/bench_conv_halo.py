@@ -37,7 +37,7 @@ for (N, H, W, Ci, Co) in SHAPES:
     bias = torch.randn(Co, device="cuda")
     res = rb(N * H * W, Co)
     out, us = {}, {}
-    for mode, env in (("gather", {"NK_CONV_HALO": "0"}), ("halo4", {"NK_CONV_HALO_TH": "4"}), ("halo", {})):
+    for mode, env in (("gather", {"NK_CONV_HALO": "0"}), ("halo", {})):
         os.environ.update(env)
         out[mode] = ops.conv2d_fwd(x, w, bias, residual=res, need_dx=False)[0].t.float()
         us[mode] = t(lambda: ops.conv2d_fwd(x, w, bias, residual=res, need_dx=False))
@@ -49,5 +49,5 @@ for (N, H, W, Ci, Co) in SHAPES:
     d = float((out["gather"] - out["halo"]).abs().max())
     ref = float(out["gather"].abs().max())
     tf = lambda u: fl / u / 1e6
-    print(f"{N} x {H}x{W} {Ci:4d} -> {Co:4d}: gather {us['gather']:8.1f} us {tf(us['gather']):5.0f} TF/s | halo TH4 {us['halo4']:8.1f} us {tf(us['halo4']):5.0f} | halo auto {us['halo']:8.1f} us"
+    print(f"{N} x {H}x{W} {Ci:4d} -> {Co:4d}: gather {us['gather']:8.1f} us {tf(us['gather']):5.0f} TF/s | halo {us['halo']:8.1f} us"
           f" {tf(us['halo']):5.0f} TF/s | conv + output sums: statistics pass {us['gather+gn']:8.1f} us, epilogue {us['halo+gn']:8.1f} us | max diff {d:.3g} of {ref:.3g}", flush=True)
