@@ -13,10 +13,11 @@ Two exchange modes (NK_DP_MODE, or FlatDataParallel(mode=...)):
   rs_ag                the sharded form SURVEY 5 / 8(e) describes: the flat buffers are cut into `world` contiguous, TENSOR-ALIGNED shards
                        (factored Adafactor statistics never cross a shard); a slice's elements are REDUCED TO THEIR OWNER only
                        (reduce-scatter at tensor granularity), the owner runs the fused optimizer on its shard (1/world of the update:
-                       11.4 -> ~1.4 ms per rank at 8 ranks for SDXL), and the new bf16 shadows -- all the next forward needs -- are
-                       gathered (each rank broadcasts its shard).  fp32 bytes in + bf16 bytes out: 25 % fewer bytes per link than the
-                       all-reduce.  The fp32 MASTERS of foreign shards go stale; `sync_masters()` gathers them where they are needed
-                       (checkpoints, EMA swaps).  Built and tested with gloo (world 2, CPU and two ranks on one GPU); not yet measured
+                       11.4 -> ~1.4 ms per rank at 8 ranks for SDXL), and what the next forward reads is gathered (each rank broadcasts
+                       its shard): the bf16 shadows, plus the fp32 masters of the 1-D parameters -- biases and norm scales / shifts, which
+                       the kernels read in fp32 straight from the master buffer -- packed into one small buffer per shard (0.1 % of
+                       the elements).  fp32 bytes in + bf16 bytes out: 25 % fewer bytes per link than the all-reduce.  The fp32 MASTERS
+                       of foreign shards' matrices go stale; `sync_masters()` gathers them where they are needed (checkpoints, EMA swaps).  Built and tested with gloo (world 2, CPU and two ranks on one GPU); not yet measured
                        on RCCL, so not the default.
 """
 from __future__ import annotations
@@ -137,8 +138,16 @@ class FlatDataParallel:
             raise ValueError(f"FlatDataParallel: mode must be 'allreduce' or 'rs_ag', got {self.mode!r}")
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.owner_bounds = self.tensor_bounds = None
+        self._vec_index = None
         if self.mode == "rs_ag" and world > 1:
             self.tensor_bounds, self.owner_bounds = shard_bounds(store, world)
+            # element indices of every shard's 1-D parameters (read as fp32 masters by the forward kernels: gathered with the shadows)
+            self._vec_index = []
+            for r in range(world):
+                spans = [torch.arange(store.offsets[t], store.offsets[t] + store.params[t].numel())
+                         for t in range(self.tensor_bounds[r], self.tensor_bounds[r + 1]) if store.params[t] is not None and store.params[t].dim() < 2]
+                idx = torch.cat(spans) if spans else torch.zeros(0, dtype=torch.long)
+                self._vec_index.append(idx.to(store.master.device))
         self.reducer = FlatGradReducer(store.grad, group, wire_dtype, owner_bounds=self.owner_bounds)
         self.world = self.reducer.world
         self.rank = self.reducer.rank
@@ -203,6 +212,15 @@ class FlatDataParallel:
                 dist.broadcast(self.store.shadow[a:b], src=src, group=self.group)
                 self.reducer.collectives += 1
                 self.reducer.wire_bytes += int((b - a) * self.store.shadow.element_size() * (self.world - 1) / self.world)
+            idx = self._vec_index[r]
+            if idx.numel():
+                src = dist.get_global_rank(self.group, r) if self.group is not None else r
+                pack = self.store.master[idx] if r == self.rank else torch.empty(idx.numel(), dtype=self.store.master.dtype, device=idx.device)
+                dist.broadcast(pack, src=src, group=self.group)
+                if r != self.rank:
+                    self.store.master[idx] = pack
+                self.reducer.collectives += 1
+                self.reducer.wire_bytes += int(idx.numel() * 4 * (self.world - 1) / self.world)
         self.store._mark_fresh()
 
     def sync_masters(self) -> None:

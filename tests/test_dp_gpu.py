@@ -149,11 +149,19 @@ def _worker_modes(rank, world, port, out):
     dist.all_gather_object(gathered, {k: v[0] for k, v in res.items()})
     same_across_ranks = all(torch.equal(gathered[0][k], gathered[r][k]) for k in res for r in range(world))
     lo, hi = res["rsag"][4]
+    store0 = _build(fx, shapes).store
+
+    def worst(tag):      # the three tensors that differ most from the default run: (index, dims, owner is this rank, relative difference)
+        rows = []
+        for t, (p, off) in enumerate(zip(store0.params, store0.offsets)):
+            a, b = res[tag][0][off:off + p.numel()], ref[off:off + p.numel()]
+            rows.append((float((a - b).norm() / (b.norm() + 1e-12)), t, p.dim(), lo <= t < hi))
+        return sorted(rows, reverse=True)[:3]
     out[rank] = dict(same_across_ranks=same_across_ranks, rsag_vs_ar=rel(res["rsag"][0], ref), ar16_vs_ar=rel(res["ar16"][0], ref), noise=rel(res["again"][0], ref),
                      shadow_rsag_vs_ar=rel(res["rsag"][1], res["ar32"][1]), sharded=res["rsag"][3] and not res["ar32"][3],
                      owns_part=0 <= lo < hi <= res["rsag"][5] and (hi - lo) < res["rsag"][5],
                      stale_before_sync=rel(res["rsag"][2], ref) > rel(res["rsag"][0], ref),
-                     moved=rel(ref, _build(fx, shapes).store.master.cpu()))
+                     moved=rel(ref, store0.master.cpu()), worst_rsag=worst("rsag"), worst_ar16=worst("ar16"))
     dist.barrier()
     dist.destroy_process_group()
 
