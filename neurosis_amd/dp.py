@@ -14,9 +14,9 @@ Two exchange modes (NK_DP_MODE, or FlatDataParallel(mode=...)):
                        (factored Adafactor statistics never cross a shard); a slice's elements are REDUCED TO THEIR OWNER only
                        (reduce-scatter at tensor granularity), the owner runs the fused optimizer on its shard (1/world of the update:
                        11.4 -> ~1.4 ms per rank at 8 ranks for SDXL), and what the next forward reads is gathered (each rank broadcasts
-                       its shard): the bf16 shadows, plus the fp32 masters of the 1-D parameters -- biases and norm scales / shifts, which
-                       the kernels read in fp32 straight from the master buffer -- packed into one small buffer per shard (0.1 % of
-                       the elements).  fp32 bytes in + bf16 bytes out: 25 % fewer bytes per link than the all-reduce.  The fp32 MASTERS
+                       its shard): the bf16 shadows, plus the fp32 masters of the parameters the kernels read in fp32 straight from the master
+                       buffer -- biases, norm scales / shifts, the two channel-padded convolutions' weights -- packed into one small
+                       buffer per shard (0.1 % of the elements).  fp32 bytes in + bf16 bytes out: 25 % fewer bytes per link than the all-reduce.  The fp32 MASTERS
                        of foreign shards' matrices go stale; `sync_masters()` gathers them where they are needed (checkpoints, EMA swaps).  Built and tested with gloo (world 2, CPU and two ranks on one GPU); not yet measured
                        on RCCL, so not the default.
 """
@@ -141,11 +141,15 @@ class FlatDataParallel:
         self._vec_index = None
         if self.mode == "rs_ag" and world > 1:
             self.tensor_bounds, self.owner_bounds = shard_bounds(store, world)
-            # element indices of every shard's 1-D parameters (read as fp32 masters by the forward kernels: gathered with the shadows)
+            # element indices of every shard's parameters that the forward reads as fp32 MASTERS, not through the bf16 shadows: the 1-D ones
+            # (biases, norm scales / shifts) and the weights of channel-padded convolutions (nn.Conv2d.padded: the 4-channel latent's conv_in /
+            # out, whose 8-channel stand-ins are rebuilt from the masters).  Gathered with the shadows.
+            padded = {id(m.weight) for m in (unet.modules() if hasattr(unet, "modules") else ()) if getattr(m, "padded", False) and hasattr(m, "weight")}
             self._vec_index = []
             for r in range(world):
                 spans = [torch.arange(store.offsets[t], store.offsets[t] + store.params[t].numel())
-                         for t in range(self.tensor_bounds[r], self.tensor_bounds[r + 1]) if store.params[t] is not None and store.params[t].dim() < 2]
+                         for t in range(self.tensor_bounds[r], self.tensor_bounds[r + 1])
+                         if store.params[t] is not None and (store.params[t].dim() < 2 or id(store.params[t]) in padded)]
                 idx = torch.cat(spans) if spans else torch.zeros(0, dtype=torch.long)
                 self._vec_index.append(idx.to(store.master.device))
         self.reducer = FlatGradReducer(store.grad, group, wire_dtype, owner_bounds=self.owner_bounds)

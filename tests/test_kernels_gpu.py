@@ -399,7 +399,7 @@ def test_stream_k_under_contention(ops, monkeypatch):
 
 
 def test_256x256_kernels_agree_bit_for_bit():
-    """The two-group phased kernel (Linear forward) against the 16-wave and the 128x128 kernels (same accumulation order =>
+    """The two-group phased kernel (Linear forward) against the 128x128 kernels (same accumulation order =>
     identical bits; the Linear dgrad shapes ride along as a stability check), each in its own process over seeded inputs at ragged and full SDXL shapes, repeated under load from a second
     stream: tools/race_screen_xl.py."""
     import subprocess

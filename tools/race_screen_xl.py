@@ -1,0 +1,83 @@
+"""Race screen for the 256x256 two-group phased kernel (the default for dense A: Linear forward): it and the 128x128 kernels (NK_GEMM_XL=0;
+also what every Linear dgrad runs on) accumulate every output element in the same order, so their outputs must agree BIT FOR BIT; each configuration runs in its own process over the same seeded inputs, many
+repeats per shape, while a second stream keeps the chip busy with other GEMMs (memory load moves DMA landing times).
+python tools/race_screen_xl.py [repeats]"""
+import hashlib, os, subprocess, sys
+
+DGRAD_SHAPES = [(4096, 1280, 5120), (16384, 640, 2560), (4000, 328, 3600), (8192, 2048, 7680)]
+SHAPES = [(65536, 1280, 1280), (4096, 3840, 1280), (4096, 10240, 1280), (16384, 5120, 640), (16300, 4104, 264), (4000, 3600, 328), (8192, 7680, 2048), (32768, 2048, 320)]
+
+
+def worker(repeats):
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from neurosis_amd import ops
+
+    side = torch.cuda.Stream()
+    noise_a = torch.randn(8192, 2048, device="cuda").to(torch.bfloat16)
+    noise_b = torch.randn(2048, 2048, device="cuda").to(torch.bfloat16)
+    for M, N, K in SHAPES:
+        g = torch.Generator(device="cuda").manual_seed(M + 7 * N + 13 * K)
+        x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda", generator=g)
+        h = hashlib.sha256()
+        first = None
+        for r in range(repeats):
+            if r % 2:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        ops.gemm_nn(noise_a, noise_b)
+            y = ops.gemm_nt(x, w, b)
+            torch.cuda.synchronize()
+            if first is None:
+                first = y.clone()
+                h.update(y.view(torch.int16).cpu().numpy().tobytes())
+            elif not torch.equal(first, y):
+                print(f"UNSTABLE {M} {N} {K} repeat {r}: {int((first != y).sum())} elements differ", flush=True)
+        print(f"fwd {M} {N} {K} {h.hexdigest()}", flush=True)
+    # input gradients dx[M, K] = dy[M, N] w[N, K] + dx_add: W is read r-contiguous (transposing LDS reads)
+    for M, N, K in DGRAD_SHAPES:
+        g = torch.Generator(device="cuda").manual_seed(3 * M + 5 * N + K)
+        dy = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda", generator=g) * N ** -0.5).to(torch.bfloat16)
+        add = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        h = hashlib.sha256()
+        first = None
+        for r in range(repeats):
+            if r % 2:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        ops.gemm_nn(noise_a, noise_b)
+            y = ops.gemm_nn(dy, w, add)
+            torch.cuda.synchronize()
+            if first is None:
+                first = y.clone()
+                h.update(y.view(torch.int16).cpu().numpy().tobytes())
+            elif not torch.equal(first, y):
+                print(f"UNSTABLE dgrad {M} {N} {K} repeat {r}: {int((first != y).sum())} elements differ", flush=True)
+        print(f"dgrad {M} {N} {K} {h.hexdigest()}", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        worker(int(sys.argv[2]))
+        sys.exit(0)
+    repeats = sys.argv[1] if len(sys.argv) > 1 else "12"
+    configs = {"default": {}, "128x128": {"NK_GEMM_XL": "0"}}
+    outs = {}
+    for name, extra in configs.items():
+        env = dict(os.environ, **extra)
+        outs[name] = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", repeats], env=env, capture_output=True, text=True).stdout.strip().splitlines()
+    bad = 0
+    ref = outs["default"]
+    for i, line in enumerate(ref):
+        others = [outs[n][i] if i < len(outs[n]) else "<missing>" for n in configs if n != "default"]
+        same = all(o == line for o in others) and "UNSTABLE" not in line
+        bad += not same
+        print(("ok   " if same else "DIFF ") + line + ("" if same else "   |   " + "   |   ".join(others)))
+    if len(ref) < len(SHAPES) + len(DGRAD_SHAPES) or any(len(o) != len(ref) for o in outs.values()):
+        bad += 1
+        print("worker output incomplete", {n: len(o) for n, o in outs.items()})
+    print("race screen:", "clean" if not bad else f"{bad} problems")
+    sys.exit(1 if bad else 0)
