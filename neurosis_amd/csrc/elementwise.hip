@@ -279,75 +279,114 @@ extern "C" int nk_conv_weight_flip(const void* w, void* wt, int Cout, int Cin, i
 
 // ------------------------------------------------------------------------------------------------
 // 3 x 3 / stride 1 / padding 1 convolution of an image with 3 or 4 REAL channels (stored padded to 8): the VAE's conv_in
-// (modules/diffusion/model.py:519, 3 -> 128 at 1024^2) and the UNet's (openaimodel.py:622-624, 4 -> 320).  27 or 36 MACs per output
-// are nothing for the MFMA engine to chew on -- as an implicit GEMM with K = 72 the gather kernel spent several ms per step decoding
-// taps for a 1 GB output; here it is a plain FMA kernel: a thread owns 4 output channels (their 27 / 36 weights live in registers as
-// fp32) and walks pixels; the 32 threads of a pixel write its 128 channels as one 256-byte row.  HBM-bound (the output).
+// (modules/diffusion/model.py:519, 3 -> 128 at 1024^2) and the UNet's (openaimodel.py:622-624, 4 -> 320).  As an implicit GEMM with K = 72
+// the gather kernel spent 1.5 ms decoding taps for a 1 GB output, and a plain FMA kernel (a thread = 4 output channels, 108 FMAs and 9 unpacked
+// 16-byte loads per pixel) took 3.65 ms: VALU-bound.  Here K = (tap, 4 channels) = 36, padded to 64 = two v_mfma_f32_16x16x32_bf16 steps:
+// a wave owns 128 output channels (their 16 weight fragments live in registers for the whole launch) and walks groups of 16 pixels; a lane
+// fetches the two or three 8-byte (4-channel) taps its k-group covers straight from HBM/L2 into the A fragment -- no LDS, no unpacking --
+// and the 16 x 128 outputs leave through the tile engine's permlane16_swap epilogue as 16-byte stores.  HBM-bound (the output).
+// (Channel 3 of a 3-channel image is zero padding in x and in the channel-padded weights, so one kernel serves both.)
 // ------------------------------------------------------------------------------------------------
-template <int CR>
 __global__ __launch_bounds__(256) void conv3x3_few_channels_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
-                                                                   bf16_t* __restrict__ y, int N, int H, int W, int Cout, int pix_per_block) {
-  const int cg = threadIdx.x & 31, pl = threadIdx.x >> 5;       // 4-channel group inside this block's 128 channels; pixel lane (8 pixels per pass)
-  const int co = blockIdx.y * 128 + cg * 4;
-  const bool live = co < Cout;
-  float wr[4][9 * CR], b4[4];
+                                                                   bf16_t* __restrict__ y, int N, int H, int W, int Cout, int groups_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int co_base = blockIdx.y * 128;
+  // weight fragments: block b = output channels co_base + 16 b + r; k-step 0 holds taps 2g, 2g + 1; k-step 1 holds tap 8 (k-group 0 only)
+  bf16x8_t wf[8][2];
 #pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    b4[o] = (live && bias) ? bias[co + o] : 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      uint4_t v = {0u, 0u, 0u, 0u};
-      if (live) v = *(const uint4_t*)(w + ((long)(co + o) * 9 + t) * 8);
-      float f[8];
-      unpack8(v, f);
-#pragma unroll
-      for (int c = 0; c < CR; ++c) wr[o][t * CR + c] = f[c];
+  for (int b = 0; b < 8; ++b) {
+    const int co = co_base + b * 16 + r;
+    uint2_t t0 = {0u, 0u}, t1 = {0u, 0u}, t8 = {0u, 0u};
+    if (co < Cout) {
+      t0 = *(const uint2_t*)(w + ((long)co * 9 + 2 * g) * 8);
+      t1 = *(const uint2_t*)(w + ((long)co * 9 + 2 * g + 1) * 8);
+      if (g == 0) t8 = *(const uint2_t*)(w + ((long)co * 9 + 8) * 8);
     }
+    wf[b][0] = __builtin_bit_cast(bf16x8_t, (uint4_t){t0.x, t0.y, t1.x, t1.y});
+    wf[b][1] = __builtin_bit_cast(bf16x8_t, (uint4_t){t8.x, t8.y, 0u, 0u});
   }
-  const long total = (long)N * H * W;
-  const long p0 = (long)blockIdx.x * pix_per_block;
-  for (int it = pl; it < pix_per_block; it += 8) {
-    const long pix = p0 + it;
-    if (pix >= total) break;
-    const int n = (int)(pix / ((long)H * W));
-    const int rem = (int)(pix - (long)n * H * W);
-    const int py = rem / W, px = rem - py * W;
-    float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+  // after the epilogue's row swap lane group g holds channels (g & 1) * 16 + (g >> 1) * 8 .. + 7 of each 32-channel pair
+  const int nloc = (g & 1) * 16 + (g >> 1) * 8;
+  float bv[4][8];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-      uint4_t v = {0u, 0u, 0u, 0u};
-      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = *(const uint4_t*)(x + (((long)n * H + yy) * W + xx) * 8);
-      float f[8];
-      unpack8(v, f);
+  for (int h = 0; h < 4; ++h)
 #pragma unroll
-      for (int c = 0; c < CR; ++c)
-#pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o] += f[c] * wr[o][t * CR + c];
+    for (int e = 0; e < 8; ++e) {
+      const int co = co_base + h * 32 + nloc + e;
+      bv[h][e] = (bias && co < Cout) ? bias[co] : 0.f;
     }
-    if (live) {
-      uint2_t out;
-      out.x = pack2bf(acc[0], acc[1]);
-      out.y = pack2bf(acc[2], acc[3]);
-      *(uint2_t*)(y + pix * Cout + co) = out;
+  const long total = (long)N * H * W;
+  const long gw = (long)blockIdx.x * 4 + wave;                 // this wave's first group of 16 pixels
+  const int HW = H * W;
+  // tap offsets of this lane's k-group
+  const int ta = 2 * g, tb = 2 * g + 1;
+  const int dya = ta / 3 - 1, dxa = ta % 3 - 1, dyb = tb / 3 - 1, dxb = tb % 3 - 1;
+
+  auto fetch = [&](long grp, uint2_t& a, uint2_t& b, uint2_t& c) {
+    a = (uint2_t){0u, 0u}; b = a; c = a;
+    const long pix = grp * 16 + r;
+    if (pix >= total) return;
+    const int n = (int)(pix / HW);
+    const int rem = (int)(pix - (long)n * HW);
+    const int py = rem / W, px = rem - py * W;
+    const bf16_t* img = x + (long)n * HW * 8;
+    int yy = py + dya, xx = px + dxa;
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) a = *(const uint2_t*)(img + ((long)yy * W + xx) * 8);
+    yy = py + dyb; xx = px + dxb;
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) b = *(const uint2_t*)(img + ((long)yy * W + xx) * 8);
+    if (g == 0) {
+      yy = py + 1; xx = px + 1;
+      if (yy < H && xx < W) c = *(const uint2_t*)(img + ((long)yy * W + xx) * 8);
+    }
+  };
+
+  const long gstride = (long)gridDim.x * 4;
+  uint2_t na, nb, nc;
+  long grp = gw;
+  fetch(grp, na, nb, nc);
+  for (int it = 0; it < groups_per_wave; ++it, grp += gstride) {
+    if (grp * 16 >= total) break;
+    const bf16x8_t x0 = __builtin_bit_cast(bf16x8_t, (uint4_t){na.x, na.y, nb.x, nb.y});
+    const bf16x8_t x1 = __builtin_bit_cast(bf16x8_t, (uint4_t){nc.x, nc.y, 0u, 0u});
+    if (it + 1 < groups_per_wave) fetch(grp + gstride, na, nb, nc);       // the next group's taps fly during this group's MFMAs and stores
+    float4_t acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][0], x0, (float4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][1], x1, acc[b], 0, 0, 0);
+    }
+    // acc[b][e] = y[pixel r][channel co_base + 16 b + 4 g + e]
+    const long pix = grp * 16 + r;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a_own = acc[2 * h][e], b_own = acc[2 * h + 1][e];
+        auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a_own), __float_as_uint(b_own), false, false);
+        v[e] = __uint_as_float(sw[0]) + bv[h][e];
+        v[4 + e] = __uint_as_float(sw[1]) + bv[h][4 + e];
+      }
+      const int co = co_base + h * 32 + nloc;
+      if (pix < total && co < Cout) *(uint4_t*)(y + pix * Cout + co) = pack8(v);
     }
   }
 }
 extern "C" int nk_conv3x3_few_channels_fwd(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cout, int cin_real,
                                            void* stream) {
-  // x [N][H][W][8] bf16 (channels >= cin_real are padding), w [Cout][3][3][8] bf16, y [N][H][W][Cout] bf16, bias [Cout] fp32 or NULL
-  NK_CHECK_ARG(x && w && y && N > 0 && H > 0 && W > 0 && Cout > 0 && (Cout & 3) == 0);
+  // x [N][H][W][8] bf16 (channels >= cin_real are zero padding), w [Cout][3][3][8] bf16 (likewise), y [N][H][W][Cout] bf16, bias [Cout] fp32 or NULL
+  NK_CHECK_ARG(x && w && y && N > 0 && H > 0 && W > 0 && Cout > 0 && (Cout & 7) == 0);
   NK_CHECK_ARG(cin_real == 3 || cin_real == 4);
-  const long total = (long)N * H * W;
-  // ~8 blocks per CU and column slab; at least 64 pixels per block so that the weight preload (a few hundred loads) is amortised
-  long per = (total + 2047) / 2048;
-  if (per < 64) per = 64;
-  per = (per + 7) / 8 * 8;
-  dim3 grid((unsigned)((total + per - 1) / per), (unsigned)((Cout + 127) / 128));
-  if (cin_real == 3)
-    hipLaunchKernelGGL(conv3x3_few_channels_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, N, H, W, Cout, (int)per);
-  else
-    hipLaunchKernelGGL(conv3x3_few_channels_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, N, H, W, Cout, (int)per);
+  NK_CHECK_ARG((long)N * H * W < (1l << 31));
+  const long groups = ((long)N * H * W + 15) / 16;
+  // a wave keeps 16 weight fragments in registers: at least 32 pixel groups per wave to amortise loading them, ~8 workgroups per CU
+  long blocks = (groups + 4 * 32 - 1) / (4 * 32);
+  if (blocks > 2048) blocks = 2048;
+  const int per_wave = (int)((groups + blocks * 4 - 1) / (blocks * 4));
+  dim3 grid((unsigned)blocks, (unsigned)((Cout + 127) / 128));
+  hipLaunchKernelGGL(conv3x3_few_channels_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, N, H, W, Cout,
+                     per_wave);
   return nk_check_launch("conv3x3_few_channels_kernel");
 }
 

@@ -560,7 +560,7 @@ def conv2d_fwd(x: Img, weight: Tensor, bias: Optional[Tensor], stride: int = 1, 
         ws = _ws(query("nk_groupnorm_sums_ws_floats", x.N, tiles, stats_groups), dev)
         call("nk_groupnorm_sums_from_parts", part.data_ptr(), sums_out.data_ptr(), ws.data_ptr(), x.N, tiles, stats_groups, _stream())
     elif (cin_real in (3, 4) and Cin == 8 and KH == 3 and KW == 3 and stride == 1 and pad_t == 1 and not asym_pad and not upsample and rowvec is None
-          and residual is None and Cout % 4 == 0):
+          and residual is None and Cout % 8 == 0):
         call("nk_conv3x3_few_channels_fwd", x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), y.data_ptr(), x.N, x.H, x.W, Cout, cin_real, _stream())
     else:
         call("nk_conv2d_fwd", C.byref(d), x.t.data_ptr(), w2d(weight).data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(), _stream())
