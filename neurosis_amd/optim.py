@@ -61,12 +61,15 @@ class FlatAdafactor:
         if query("nk_adafactor_tensor_bytes") != AF_TENSOR_DTYPE.itemsize:
             raise RuntimeError("FlatAdafactor: tensor table layout differs from the HIP library's")
         if chunk_bytes is None:
-            # gradient bytes per chunk of tensors (five launches each).  Measured on the SDXL UNet: 128 MB chunks (gradients
-            # re-read from the Infinity Cache) 19.2 images/s, 1-4 GB chunks 19.9-20.0: the dependent small launches cost more
-            # than the second and third gradient read from HBM, so chunks are large.
+            # gradient bytes per chunk of tensors (five launches each).  64 MB: a chunk's gradients are re-read (second-moment pass, update-RMS
+            # pass, apply pass) out of the 256 MB Infinity Cache instead of HBM -- 14 instead of 22 HBM bytes per parameter.  Round 1, with the
+            # update IN LINE behind backward, measured the opposite (128 MB chunks 19.2 images/s, 1-4 GB chunks 19.9-20.0: the ~800 dependent
+            # small launches cost more than the re-reads); since the update runs on its own stream beside the next step's VAE encoder, what
+            # counts is the HBM bandwidth it takes from that encoder: steady-state step 172.2 / 172.8 / 173.8 / 174.8 ms at 64 / 128 / 256 /
+            # 2048 MB (one box, bench.py, round 3).
             import os
 
-            chunk_bytes = int(os.environ.get("NK_AF_CHUNK_MB", "2048")) << 20
+            chunk_bytes = int(os.environ.get("NK_AF_CHUNK_MB", "64")) << 20
         # `boundaries`: tensor indices at which a new chunk must begin (the first parameter of every top-level UNet block), so
         # that a block's update can be issued as soon as that block's gradients are final, while backward is still running
         bounds = set(int(b) for b in (boundaries or ()))
