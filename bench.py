@@ -14,7 +14,7 @@ all-reduce over RCCL, overlapped with backward) -> fused Adafactor (or AdamW) up
 Nothing is skipped or cached inside the timed region.  Weak scaling: every rank processes its own 4 images.
 
 Prints ONE JSON line on rank 0 (see the task contract); extra objects:
-  roofline     -- the dominant kernel (the MFMA tile engine nk_gemm_kernel<...>, ~88 % of the step's FLOPs):
+  roofline     -- the dominant kernel (the MFMA tile engine: nk_gemm_*_kernel<...> and nk_conv3x3_halo_kernel<...>, ~88 % of the step's FLOPs):
                   algorithmic FLOPs of every launch (2*M*N*K) / its duration from HIP events recorded around each
                   launch on the launch stream during an instrumented replay of the same step.
   cpu_baseline -- the CPU oracle's training step on the host cores (bounded sample, see `sample`).
@@ -284,16 +284,14 @@ def pmc_traffic():
     import csv
 
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = os.path.join(prof, "r02_pmc_summary.csv")
-    if not os.path.exists(path):
-        path = os.path.join(prof, "r01_pmc_summary.csv")
+    path = next((p for p in (os.path.join(prof, f"r0{r}_pmc_summary.csv") for r in (3, 2, 1)) if os.path.exists(p)), "")
     try:
         rows = list(csv.reader(open(path)))[1:]
     except OSError:
         return None, None
     n = b = 0.0
     for r in rows:
-        if r[0].startswith("void nk_gemm"):
+        if r[0].startswith("void nk_gemm") or r[0].startswith("void nk_conv3x3_halo"):      # the tile engine's kernel families
             n += float(r[1])
             b += float(r[1]) * (float(r[2]) + float(r[3]))
     return (round(b / n), "profiles/" + os.path.basename(path)) if n else (None, None)
@@ -506,7 +504,7 @@ def main():
         traffic, traffic_src = pmc_traffic()
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "frac_in_step": round(ach / PEAK_BF16_TFLOPS, 4), "achieved_serialized": round(ach_s, 2), "frac_serialized": round(ach_s / PEAK_BF16_TFLOPS, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "nk_gemm_*_kernel<*> (MFMA tile engine: linear+conv fwd/dgrad/wgrad)", "launches_per_step": n,
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "nk_gemm_*_kernel<*> + nk_conv3x3_halo_kernel<*> (MFMA tile engine: linear+conv fwd/dgrad/wgrad)", "launches_per_step": n,
                     "avg_launch_us": round(ms * 1e3 / n, 2), "avg_launch_us_serialized": round(mss * 1e3 / ns, 2), "algorithmic_tflop_per_step": round(f / 1e12, 2),
                     "algorithmic_gflop_per_launch": round(f / n / 1e9, 2), "kernel_ms_per_step": round(ms, 2), "kernel_ms_per_step_serialized": round(mss, 2),
                     "by_entry_point": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in per.items()},

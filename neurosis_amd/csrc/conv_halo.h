@@ -373,8 +373,14 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
     // (LDS) -> the columns of a GroupNorm group -> part[img][tile][2 * group + {0, 1}].  The ring is free: every wave is past the loop.
     __syncthreads();
     float* const cs = (float*)ring;            // [8 waves][HN columns][2]
+    // sum over the 16 lanes of a DPP row (= the 16 pixels of a row block), in every lane: four VALU instructions with DPP operands.
+    // (`__shfl_xor` compiled to ds_bpermute_b32 for all four steps: 128 LDS round trips per wave, 313 us of a 1.8 ms launch at the VAE's
+    // 1024^2 level.)  Same pairing as the xor butterfly -- quad, quad pair, row half, row -- so the sums are bit-identical to it.
     auto lane16_sum = [](float x) {
-      x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1, 0, 3, 2]
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2, 3, 0, 1]
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
       return x;
     };
 #pragma unroll

@@ -3,7 +3,7 @@ per kernel HBM bytes per dispatch (2 x FETCH_SIZE KB on gfx950 + WRITE_SIZE KB),
 the kernel-trace run) and MFMA busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128))."""
 import csv, os, sys
 P = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"      # round prefix of the files under profiles/
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"      # round prefix of the files under profiles/
 def load(name):
     r = list(csv.reader(open(os.path.join(P, name)))); return r[0], {row[0][:100]: row for row in r[1:]}
 hf, F = load(f"{R}_pmc_fetch_size.csv"); hw, W = load(f"{R}_pmc_write_size.csv"); hm, M = load(f"{R}_pmc_mfma.csv"); hs, S = load(f"{R}_bench_kernel_stats.csv")
@@ -24,5 +24,6 @@ with open(os.path.join(P, f"{R}_pmc_summary.csv"), "w", newline="") as fo:
         o.writerow([k, n, f"{f:.4g}", f"{w:.4g}", f"{d:.0f}" if d else "", f"{(f + w) / d:.0f}" if d else "", f"{u:.3f}" if u is not None else ""])
 for k, n, f, w, d, u in rows[:26]:
     print(f"{k[:58]:58s} n={n:5d} rd={f/1e6:9.1f}MB wr={w/1e6:8.1f}MB dur={(d or 0)/1e3:8.1f}us {((f+w)/d if d else 0):6.0f} GB/s mfma={u if u is not None else -1:.3f}")
-tn = sum(r[1] for r in rows if r[0].startswith("void nk_gemm")); tb = sum(r[1] * (r[2] + r[3]) for r in rows if r[0].startswith("void nk_gemm"))
+te = lambda r: r[0].startswith("void nk_gemm") or r[0].startswith("void nk_conv3x3_halo")
+tn = sum(r[1] for r in rows if te(r)); tb = sum(r[1] * (r[2] + r[3]) for r in rows if te(r))
 print("tile engine: launches", tn, "avg HBM bytes/launch %.1f MB" % (tb / tn / 1e6))
