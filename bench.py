@@ -323,6 +323,9 @@ def main():
     ap.add_argument("--wire-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: dtype of the gradient all-reduce (fp32 = what Lightning DDP exchanges for the reference's fp32 parameters; "
                          "bf16 halves the bytes on xGMI and sums in bf16)")
+    ap.add_argument("--stream-optimizer", action="store_true",
+                    help="N = 1 A/B: issue each top-level UNet block's Adafactor update behind that block's backward (DiffusionEngine.stream_optimizer) "
+                         "instead of the whole update after backward")
     ap.add_argument("--dp-mode", choices=["allreduce", "rs_ag"], default=os.environ.get("NK_DP_MODE", "allreduce"),
                     help="N > 1: allreduce = flat all-reduce of every gradient slice, the whole optimizer on every rank (default, what Lightning DDP does); "
                          "rs_ag = slices reduced to tensor-aligned owner shards, optimizer on the owned shard, bf16 shadows gathered (neurosis_amd/dp.py)")
@@ -353,6 +356,8 @@ def main():
     lib.load()  # fail loudly if the HIP library is missing
     eng = build_engine(device, (args.res, args.res), None if args.precomputed_te else build_conditioner(device))
     unet = eng.model.diffusion_model
+    if args.stream_optimizer:
+        eng.stream_optimizer = True
     if args.optimizer == "adafactor":
         eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)   # configs/sdxl/sdxl.example.yaml:158-164
     dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if args.wire_dtype == "bf16" else None, mode=args.dp_mode) if world > 1 else None

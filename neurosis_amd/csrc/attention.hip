@@ -18,6 +18,7 @@
 #include "../../include/neurosis_hip.h"
 #include "nk_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct AttnParams {
   const bf16_t *Q, *K, *V, *dO;
@@ -75,6 +76,18 @@ struct TileLoader {
   static constexpr int PER = (ROWS * CPR + NT - 1) / NT;
   static constexpr int RS = DP * 2 + 16;
   uint4_t v[PER];
+  // Whole tiles (every row inside the tensor, head dim == DP) are fetched from `tile = base + row0 * stride`, a wave-uniform pointer, plus
+  // ONE per-thread byte offset computed once (piece i lies NT / CPR rows further: a wave-uniform step): one load instruction per piece.
+  // (The general form below recomputes row / chunk / 64-bit address / two bounds predicates per piece per tile: ~100 of the ~330 vector
+  // instructions of a forward iteration.)
+  static __device__ __forceinline__ int piece_offset(long stride, int tid) {
+    return (int)(((tid / CPR) * stride + (tid % CPR) * 8) * 2);
+  }
+  __device__ __forceinline__ void load_full(const bf16_t* tile, long stride, int off0) {
+    static_assert((ROWS * CPR) % NT == 0 && NT % CPR == 0, "whole pieces of whole rows only");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = *(const uint4_t*)((const char*)(tile + (long)i * (NT / CPR) * stride) + off0);
+  }
   __device__ __forceinline__ void load(const bf16_t* base, long stride, int row0, int nrows, int D, int tid) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -138,22 +151,27 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p
   // iteration, whatever its arithmetic (MFMA busy 0.18).  Two register sets, named statically (the loop is unrolled by two).
   // (head dims > 64 keep one tile ahead: their tiles are larger and a second register set would spill)
   constexpr int PFD = 1;   // (two ahead, a second register set, measured +1..2 % only: the loop was not waiting on global memory)
-  TileLoader<64, DP, NW * 64> lkA, lvA, lkB, lvB;
+  TileLoader<64, DP, NW * 64> lkA, lvA;
+  const int koff = TileLoader<64, DP, NW * 64>::piece_offset(p.sk, tid);      // (K and V share it: the whole-tile path asks for sk == sv)
   lkA.load(Kb, p.sk, 0, p.Lk, p.D, tid);
   lvA.load(Vb, p.sv, 0, p.Lk, p.D, tid);
   lkA.store(smem, tid);
   lvA.store(smem + TILE, tid);
-  if (PFD == 2 && nt > 1) {
-    lkA.load(Kb, p.sk, 64, p.Lk, p.D, tid);
-    lvA.load(Vb, p.sv, 64, p.Lk, p.D, tid);
-  }
   __syncthreads();
 
+  // MASKED: tile t reaches past Lk, or the causal variant -- scores are masked.  PF_WHOLE: the tile prefetched in this iteration lies wholly
+  // inside K / V and the head dim is DP (TileLoader::load_full).  Compile-time flags on purpose: as run-time, wave-uniform branches hipcc
+  // flattened them into the common path -- 33 adds + 32 compares + 33 selects per iteration for a mask only the last tile needs, and the
+  // general loader's address / bounds arithmetic, together ~180 of ~330 vector instructions per iteration of a VALU-bound loop.
   auto iteration = [&](int t, TileLoader<64, DP, NW * 64>& useK, TileLoader<64, DP, NW * 64>& useV, TileLoader<64, DP, NW * 64>& pfK,
-                       TileLoader<64, DP, NW * 64>& pfV) {
+                       TileLoader<64, DP, NW * 64>& pfV, auto masked_tag, auto pf_whole_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value, PF_WHOLE = decltype(pf_whole_tag)::value;
     const char* kt = smem + (t & 1) * 2 * TILE;
     const char* vt = kt + TILE;
-    if (t + PFD < nt) {
+    if constexpr (PF_WHOLE) {
+      pfK.load_full(Kb + (long)(t + PFD) * 64 * p.sk, p.sk, koff);
+      pfV.load_full(Vb + (long)(t + PFD) * 64 * p.sv, p.sv, koff);
+    } else if (t + PFD < nt) {
       pfK.load(Kb, p.sk, (t + PFD) * 64, p.Lk, p.D, tid);
       pfV.load(Vb, p.sv, (t + PFD) * 64, p.Lk, p.D, tid);
     }
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p
     // keys beyond Lk exist only in the last tile (wave-uniform branch); the causal variant (text transformers, L = 77)
     // masks every tile it visits
     const int kbase = t * 64;
-    if (kbase + 64 > p.Lk || p.causal) {
+    if constexpr (MASKED) {
       const int last = p.causal ? min(p.Lk - 1, q0 + ql) : p.Lk - 1;   // highest visible key of this lane's query
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
@@ -282,13 +300,18 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p
     }
     __syncthreads();
   };
-  if constexpr (PFD == 2) {
-    for (int t = 0; t < nt; t += 2) {
-      iteration(t, lkA, lvA, lkB, lvB);
-      if (t + 1 < nt) iteration(t + 1, lkB, lvB, lkA, lvA);
+  {
+    static_assert(PFD == 1, "one tile ahead");
+    using T = std::true_type;
+    using F = std::false_type;
+    // tiles [0, nwhole) lie wholly inside K / V and need no mask; the prefetch of tile t + 1 may use the whole-tile loader while t + 1 < nwhole
+    const int nwhole = (p.causal || p.D != DP || DP != 64 || p.sk != p.sv) ? 0 : p.Lk / 64;
+    int t = 0;
+    if constexpr (DP == 64) {
+      for (; t + 1 < nwhole; ++t) iteration(t, lkA, lvA, lkA, lvA, F{}, T{});
     }
-  } else {
-    for (int t = 0; t < nt; ++t) iteration(t, lkA, lvA, lkA, lvA);
+    for (; t < nwhole; ++t) iteration(t, lkA, lvA, lkA, lvA, F{}, F{});
+    for (; t < nt; ++t) iteration(t, lkA, lvA, lkA, lvA, T{}, F{});
   }
 
   l += __shfl_xor(l, 32, 64);
@@ -358,6 +381,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dkdv_kernel(const AttnPar
 
   const int nt = max(t_hi - t_lo, 0);
   TileLoader<32, DP, NW * 64> lq, ld_;
+  const int qoff = TileLoader<32, DP, NW * 64>::piece_offset(p.sq, tid), dooff = TileLoader<32, DP, NW * 64>::piece_offset(p.sdo, tid);
   float st_lse = 0.f, st_dl = 0.f;
   auto load_stats = [&](int q0) {
     if (tid < 32) {
@@ -380,14 +404,21 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dkdv_kernel(const AttnPar
   store_stats(smem);
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
+  // (PF_WHOLE: the query tile prefetched in this iteration lies wholly inside Q / dO -- compile-time, as in the forward kernel)
+  auto iteration = [&](int t, auto pf_whole_tag) {
+    constexpr bool PF_WHOLE = decltype(pf_whole_tag)::value;
     const char* st = smem + (t & 1) * STAGE;
     const char* qt = st;
     const char* dot = st + TILE;
     const float* s_lse = (const float*)(st + 2 * TILE);
     const float* s_dl = s_lse + 32;
-    const bool more = t + 1 < nt;
-    if (more) {
+    const bool more = PF_WHOLE || t + 1 < nt;
+    if constexpr (PF_WHOLE) {
+      const int qn = (t_lo + t + 1) * 32;
+      lq.load_full(Qb + (long)qn * p.sq, p.sq, qoff);
+      ld_.load_full(dOb + (long)qn * p.sdo, p.sdo, dooff);
+      if (tid < 32) { st_lse = lse[qn + tid] * LOG2E; st_dl = dl[qn + tid]; }
+    } else if (more) {
       lq.load(Qb, p.sq, (t_lo + t + 1) * 32, p.Lq, p.D, tid);
       ld_.load(dOb, p.sdo, (t_lo + t + 1) * 32, p.Lq, p.D, tid);
       load_stats((t_lo + t + 1) * 32);
@@ -424,6 +455,15 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dkdv_kernel(const AttnPar
       store_stats(nx);
     }
     __syncthreads();
+  };
+  {
+    // iterations whose PREFETCHED tile (t_lo + t + 1) lies wholly inside Q / dO: (t_lo + t + 2) * 32 <= Lq
+    int t = 0;
+    if constexpr (DP == 64) {
+      const int nw = p.D == DP ? min(nt - 1, p.Lq / 32 - t_lo - 1) : 0;
+      for (; t < nw; ++t) iteration(t, std::true_type{});
+    }
+    for (; t < nt; ++t) iteration(t, std::false_type{});
   }
 
 #pragma unroll
@@ -549,17 +589,24 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParam
 
   const int nt = (p.Lk + 63) / 64;
   TileLoader<64, DP, NW * 64> lk, lv;
+  const int koff = TileLoader<64, DP, NW * 64>::piece_offset(p.sk, tid);
   lk.load(Kb, p.sk, 0, p.Lk, p.D, tid);
   lv.load(Vb, p.sv, 0, p.Lk, p.D, tid);
   lk.store(smem, tid);
   lv.store(smem + TILE, tid);
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
+  // (MASKED / PF_WHOLE: compile-time flags as in the forward kernel -- the key mask of the last tile and the general loader's arithmetic
+  // stay out of the common path)
+  auto iteration = [&](int t, auto masked_tag, auto pf_whole_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value, PF_WHOLE = decltype(pf_whole_tag)::value;
     const char* kt = smem + (t & 1) * 2 * TILE;
     const char* vt = kt + TILE;
-    const bool more = t + 1 < nt;
-    if (more) {
+    const bool more = PF_WHOLE || t + 1 < nt;
+    if constexpr (PF_WHOLE) {
+      lk.load_full(Kb + (long)(t + 1) * 64 * p.sk, p.sk, koff);
+      lv.load_full(Vb + (long)(t + 1) * 64 * p.sv, p.sv, koff);
+    } else if (more) {
       lk.load(Kb, p.sk, (t + 1) * 64, p.Lk, p.D, tid);
       lv.load(Vb, p.sv, (t + 1) * 64, p.Lk, p.D, tid);
     }
@@ -578,7 +625,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParam
         float pv = EXP2(s[r] * c - lse2);
         dp[r] = pv * (dp[r] - dlt);             // (the softmax scale multiplies dQ once, after the loop)
       }
-      if (t * 64 + hf * 32 + 32 > p.Lk) {   // keys beyond Lk exist only in the last tile (wave-uniform branch)
+      if constexpr (MASKED) {   // keys beyond Lk exist only in the last tile
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] = (t * 64 + hf * 32 + acc_row(r, h5)) < p.Lk ? dp[r] : 0.f;
       }
@@ -597,6 +644,17 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParam
       lv.store(nx + TILE, tid);
     }
     __syncthreads();
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    const int nwhole = (p.D != DP || DP != 64 || p.sk != p.sv) ? 0 : p.Lk / 64;
+    int t = 0;
+    if constexpr (DP == 64) {
+      for (; t + 1 < nwhole; ++t) iteration(t, F{}, T{});
+    }
+    for (; t < nwhole; ++t) iteration(t, F{}, F{});
+    for (; t < nt; ++t) iteration(t, T{}, F{});
   }
 
 #pragma unroll
