@@ -39,8 +39,10 @@ __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __
     unpack8(*(const uint4_t*)(dy + row * I + ch * 8), d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      da[e] = d[e] * gelu_erf(g[e]);
-      dg[e] = d[e] * a[e] * dgelu_erf(g[e]);
+      float cdf, pdf;
+      normal_cdf_pdf(g[e], cdf, pdf);
+      da[e] = d[e] * (g[e] * cdf);
+      dg[e] = d[e] * a[e] * (cdf + g[e] * pdf);
     }
     *(uint4_t*)(du + row * 2 * I + ch * 8) = pack8(da);
     *(uint4_t*)(du + row * 2 * I + I + ch * 8) = pack8(dg);

@@ -141,8 +141,10 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
         unpack8(*(const uint4_t*)(p.geglu_u + (long)m * p.ld_u + p.N + n), g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          da[e] = v[e] * gelu_erf(g[e]);
-          dg[e] = v[e] * a[e] * dgelu_erf(g[e]);
+          float cdf, pdf;
+          normal_cdf_pdf(g[e], cdf, pdf);
+          da[e] = v[e] * (g[e] * cdf);
+          dg[e] = v[e] * a[e] * (cdf + g[e] * pdf);
         }
         *(uint4_t*)(C + (long)m * p.ldc + n) = pack8(da);
         *(uint4_t*)(C + (long)m * p.ldc + p.N + n) = pack8(dg);
