@@ -1,7 +1,7 @@
 """HIP path against fixtures produced by the reference's own `StandardDiffusionLoss._forward / get_loss /
 apply_noise_offset` (edm/l2, edm/l1, edm/l2 + noise offset, rf/l2) and its own `DiffusionEngine.encode_first_stage /
 training_step` (tests/golden/make_golden.py: loss_class_case, engine_case).  Tolerances as in test_modules_gpu.py
-(bf16 MFMA operands vs an fp32 CPU reference): per-sample loss 1e-2 relative, gradient cosine >= 0.99, latents 3e-2."""
+(bf16 MFMA operands vs an fp32 CPU reference): per-sample loss 1e-2 relative, gradient cosine >= 0.9985 (l1: 0.995, rf: 0.998, through the VAE: 0.996), latents 3e-2."""
 import json
 from functools import partial
 from pathlib import Path
@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from tests.golden.make_golden import LOSS_CLASS_CASES, UNET_TINY, VAE_TINY, synth_state_dict
-from tests.util import cosine, rel_err
+from tests.util import check_grad_cosines, cosine, rel_err
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -52,9 +52,10 @@ def test_hip_loss_class_matches_the_reference_class(tag):
     torch.cuda.synchronize()
     named = dict(net.named_parameters())
     gmax = max(case["grad_norms"].values())
-    for k, g in case["grads"].items():
-        if float(g.norm()) > 1e-2 * gmax:
-            assert cosine(named[k].grad, g) >= 0.99, (tag, k, cosine(named[k].grad, g))
+    # measured worst >= 2-D / 1-D: edm_l2 0.99909 / 0.99936, edm_l2_offset 0.99918 / 0.99947, rf_l2 0.99896 / 0.99928, edm_l1 0.99620 / 0.99768 (the
+    # l1 loss's gradient is a SIGN: one flipped element of the bf16 network output moves it by a whole unit)
+    fm, fv = {"edm_l1": (0.995, 0.995), "rf_l2": (0.998, 0.998)}.get(tag, (0.9985, 0.998))
+    check_grad_cosines(f"loss class {tag}", named, case["grads"], floor_matrix=fm, floor_vector=fv, keep=lambda k, g: float(g.norm()) > 1e-2 * gmax)
     for k, n in case["grad_norms"].items():
         if n > 1e-2 * gmax:
             assert abs(float(named[k].grad.norm()) - n) <= 6e-2 * n, (tag, k)
@@ -92,9 +93,8 @@ def test_engine_methods_match_the_reference_engine():
     loss.backward()
     torch.cuda.synchronize()
     named = dict(eng.model.diffusion_model.named_parameters())
-    for k, g in e["grads"].items():
-        if float(g.norm()) > 1e-6:
-            assert cosine(named[k].grad, g) >= 0.99, k
+    # (through the bf16 VAE encoder as well: measured worst 0.99702 / 0.99708)
+    check_grad_cosines("reference engine training_step", named, e["grads"], floor_matrix=0.996, floor_vector=0.996, keep=lambda k, g: float(g.norm()) > 1e-6)
 
 
 def test_optimizer_and_ema_state_survive_a_checkpoint_round_trip():

@@ -3,7 +3,7 @@ reference and (b) the CPU oracle, on the same seeded inputs.
 
 Tolerances (bf16 activations / bf16 MFMA operands / fp32 accumulation vs an fp32 CPU path), as stated in
 SURVEY section 8(c): network outputs within 3e-2 of the output's max magnitude with cosine >= 0.999,
-per-sample loss within 1e-2 relative, parameter gradients cosine >= 0.99 (>= 0.999 on the large matrices) and
+per-sample loss within 1e-2 relative, parameter gradients cosine >= 0.9985 on matrices and kernels (0.999 for the SD1.5 shape), >= 0.997 on 1-D parameters, and
 gradient norms within 5e-2 relative.
 """
 import json
@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from tests.golden.make_golden import synth_state_dict
-from tests.util import bf16_round, cosine, rel_err
+from tests.util import bf16_round, check_grad_cosines, cosine, rel_err
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -63,11 +63,9 @@ def test_unet_against_reference_golden(name, store):
     assert rel_err(loss, fx["loss"]) <= 1e-2, (loss.tolist(), fx["loss"].tolist())
     loss.mean().backward()
     grads = dict(net.named_parameters())
-    worst = 1.0
-    for k, g in fx["grads"].items():
-        c = cosine(grads[k].grad, g)
-        worst = min(worst, c)
-        assert c >= 0.99, (k, c)
+    # measured worst (round 3): SD1.5-shaped 0.99940 / 0.99875 (>= 2-D / 1-D), SDXL-shaped 0.99891 / 0.99879 -- bf16 activations through a
+    # 16-channel-per-group toy network; floors just under them (round 2 asked 0.99 of every parameter)
+    check_grad_cosines(f"unet golden {name}", grads, fx["grads"], floor_matrix=0.999 if "sd15" in name else 0.9985, floor_vector=0.997)
     bad = []
     for k, n in fx["grad_norms"].items():
         mine = float(grads[k].grad.float().norm())
@@ -76,7 +74,6 @@ def test_unet_against_reference_golden(name, store):
         if abs(mine - n) > 5e-2 * n + 5e-4:
             bad.append((k, mine, n))
     assert not bad, bad[:8]
-    assert worst >= 0.99
 
 
 def test_unet_checkpoint_flag_is_numerically_neutral():
@@ -253,8 +250,7 @@ def test_rectified_flow_objective_fused_against_reference():
     assert rel_err(loss, rf["loss"]) <= 1e-2, (loss.tolist(), rf["loss"].tolist())
     loss.mean().backward()
     grads = dict(net.named_parameters())
-    for k, g in rf["grads"].items():
-        assert cosine(grads[k].grad, g) >= 0.99, (k, cosine(grads[k].grad, g))
+    check_grad_cosines("rectified-flow loss", grads, rf["grads"], floor_matrix=0.9985, floor_vector=0.997)      # measured 0.99909
     gmax = max(rf["grad_norms"].values())      # analytically-zero gradients (a projection in front of a one-channel-per-group GroupNorm) are
     bad = [(k, float(grads[k].grad.float().norm()), n) for k, n in rf["grad_norms"].items()      # rounding noise on the bf16 path: absolute floor
            if abs(float(grads[k].grad.float().norm()) - n) > 5e-2 * n + 1e-3 * gmax]

@@ -4,7 +4,7 @@ Encoder / regularizer / Decoder stack on the same weights, image and posterior n
 the pieces it adds (softmax backward, unfused attention backward).
 
 Tolerances as for the UNet (bf16 activations vs fp32 CPU): outputs 3e-2 of max magnitude / cosine 0.999, loss 1e-2 relative,
-parameter gradients cosine >= 0.99, gradient norms within 5e-2 relative (+ an absolute floor for analytically-zero ones).
+parameter gradients cosine >= 0.999, gradient norms within 5e-2 relative (+ an absolute floor for analytically-zero ones).
 """
 import json
 from pathlib import Path
@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from tests.golden.make_golden import synth_state_dict
-from tests.util import cosine, rel_err
+from tests.util import check_grad_cosines, cosine, rel_err
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -72,9 +72,7 @@ def test_reconstruction_step_against_reference(tag):
     assert abs(float(loss) - float(case["loss"])) <= 1e-2 * abs(float(case["loss"]))
     assert abs(float(reg_log["kl_loss"]) - float(case["kl_loss"])) <= 1e-2 * float(case["kl_loss"])
     grads = dict(eng.named_parameters())
-    for k, g in case["grads"].items():
-        c = cosine(grads[k].grad, g)
-        assert c >= 0.99, (k, c)
+    check_grad_cosines("autoencoder reconstruction step", grads, case["grads"], floor_matrix=0.999, floor_vector=0.999)    # measured 0.99942 / 0.99975
     bad = []
     gmax = max(case["grad_norms"].values())
     for k, n in case["grad_norms"].items():
