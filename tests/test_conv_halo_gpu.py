@@ -19,6 +19,9 @@ HALO_CASES = [  # N, H, W, Cin, Cout, rowvec, residual
     (1, 64, 64, 192, 256, False, False),       # three slabs: the halo double buffer wraps
     (3, 8, 32, 320, 128, True, True),          # five slabs, three images, two tile rows
     (1, 128, 128, 128, 128, False, True),      # the VAE's 128-channel shape at a small size: 512 tiles, two rounds
+    (3, 96, 96, 128, 320, True, True),         # 432 tiles of 4 x 32: a second, partial round on 256 CUs; two column tiles
+    (4, 98, 96, 64, 160, False, True),         # 300 tiles, ONE slab per tile, ragged bottom row
+    (5, 64, 64, 256, 128, True, False),        # 320 tiles x 4 slabs, 128-wide column tiles
 ]
 
 
@@ -61,7 +64,8 @@ def test_halo_matches_gather_and_repeats_bitwise():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("case", [(2, 32, 64, 128, 128), (1, 64, 64, 256, 512), (2, 16, 32, 320, 320), (1, 30, 62, 128, 256), (4, 32, 32, 1280, 1280)])
+@pytest.mark.parametrize("case", [(2, 32, 64, 128, 128), (1, 64, 64, 256, 512), (2, 16, 32, 320, 320), (1, 30, 62, 128, 256), (4, 32, 32, 1280, 1280),
+                                  (3, 96, 96, 128, 320), (4, 98, 96, 64, 160)])       # (the last two: more tiles than CUs)
 def test_halo_statistics_epilogue(case):
     """The GroupNorm statistics epilogue: the convolution's output is bit-identical with and without it, the sums it emits are those of
     the tensor it wrote (against the stand-alone statistics pass), and GroupNorm consumes them instead of its own first pass."""
