@@ -30,11 +30,6 @@
 // Linear forward (KC x KC), dgrad (KC x MC) and wgrad (MC x MC, also the batched form); convolutions keep the gather kernels.
 #pragma once
 
-#ifndef G2_ABL
-#define G2_ABL 0       // tools/ablate: 1 = no DMA in the loop, 2 = no fragment reads, 3 = no MFMAs, 5 = every piece issued in the R phase,
-                       // 6 = prefetch distance three with every piece issued in the MFMA phase (measured slower: 63.0 vs 56.8 us at
-                       // 4096 x 1280 x 5120 forward, 23.2 vs 21.0 dgrad 1280^2 -- pieces among the MFMAs lengthen the phase that is critical)
-#endif
 #define G2_BM 128
 #define G2_STAGE_BYTES 36864                     // A image 16 KiB + B image up to 20 KiB
 #define G2_NS 4
@@ -342,11 +337,6 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
     if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");        \
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             \
   } while (0)
-#define G2_WAIT_TWO_SLABS()                                           \
-  do {                                                                \
-    if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");       \
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             \
-  } while (0)
 
   const bf16_t* sa[OpG2<AMODE, 128>::NPW];
   const bf16_t* sb[OpG2<BMODE, BN_>::NPW];
@@ -355,54 +345,27 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
   oa.fire(sa, smem, wave); ob.fire(sb, smem + 16384, wave);
   oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);
   oa.fire(sa, smem + G2_STAGE_BYTES, wave); ob.fire(sb, smem + G2_STAGE_BYTES + 16384, wave);
-#if G2_ABL == 6   // prefetch distance THREE, every piece issued in the MFMA phase (the R phase keeps only fragment reads + the wait)
-  oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);
-  oa.fire(sa, smem + 2 * G2_STAGE_BYTES, wave); ob.fire(sb, smem + 2 * G2_STAGE_BYTES + 16384, wave);
-  oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);             // sources of slab 3, fired in the first M phase
-  G2_WAIT_TWO_SLABS();
-  G2_BAR();
-  if (grp == 1) { G2_BAR(); }
-  unsigned so = 0, sn = 3 * G2_STAGE_BYTES;                         // stage of slab t / of slab t + 3
-#else
   oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);             // sources of slab 2, fired in the first R phase
   G2_WAIT_ONE_SLAB();
   G2_BAR();
   if (grp == 1) { G2_BAR(); }                                       // the second group runs one barrier behind
 
   unsigned so = 0, sn = 2 * G2_STAGE_BYTES;                         // stage of slab t / of slab t + 2
-#endif
   for (int t = 0; t < nk; ++t) {
     // ---- R: fragment reads of slab t, DMA of slab t + 2, wait for slab t + 1 ----
     __builtin_amdgcn_sched_barrier(0);
-#if G2_ABL != 2
     g2_read<BF, BN_, NJ>(bfr, fb, so);
     g2_read<AF, 128, 2>(af, fa, so);
-#endif
-#if G2_ABL != 1 && G2_ABL != 6
     oa.fire(sa, smem + sn, wave);                        // the two A pieces here, the two or three B pieces behind the barrier, in the
-#if G2_ABL == 5                                          // MFMA phase: a piece costs the issuing wave 60-120 cycles, and with all of them
-    ob.fire(sb, smem + sn + 16384, wave);                // here the R phase outlasted the partner group's MFMAs (61 -> 56 us at 4096x1280x5120)
-#endif
-#endif
-#if G2_ABL == 5 || G2_ABL == 6
-    G2_WAIT_ONE_SLAB();                                  // (6: slabs t + 1 and t + 2 are in flight here; leave the younger one)
-#else
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but the two A pieces just issued: slab t + 1 is complete (this wave's share)
-#endif
     G2_BAR();
     // ---- M: the wave's MFMAs; the next slab's source addresses are computed in their shadow ----
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-#if G2_ABL == 6
-    oa.fire(sa, smem + sn, wave);
-#endif
-#if G2_ABL != 5 && G2_ABL != 1
     ob.fire(sb, smem + sn + 16384, wave);
-#endif
     oa.next_sources(p.K, sa);
     ob.next_sources(p.K, sb);
-#if G2_ABL != 3
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -417,9 +380,6 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
           accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nk_ones_frag(), grp ? af[ks * 2 + 1] : af[ks * 2], accb, 0, 0, 0);
       }
     }
-#else
-    { asm volatile("" :: "v"(bfr[0]), "v"(bfr[NJ]), "v"(af[0]), "v"(af[2])); }
-#endif
     __builtin_amdgcn_s_setprio(0);
     G2_BAR();
     so += G2_STAGE_BYTES; if (so == G2_NS * G2_STAGE_BYTES) so = 0;
