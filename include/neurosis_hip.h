@@ -40,6 +40,12 @@ int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add, void* dx,
 /* dw[N,K] (+)= dy[M,N]^T @ x[M,K]   fp32.  accumulate: 0 overwrite, 1 add, 2 destination is known to be all zero */
 /* nk_linear_dgrad of FeedForward.net[2] with the GEGLU backward in its epilogue (modules/attention.py:50-74): du[M][2I] =
  * [d * gelu(g) | d * a * gelu'(g)], d = dy[M][N] @ w[N][I], u = [a | g] [M][2I] saved by the forward */
+/* FeedForward.net[0] = GEGLU (modules/attention.py:50-57) in one launch: u[M, 2I] = x @ w^T + bias (kept for the backward) and
+ * h[M, I] = u[:, :I] * gelu_erf(u[:, I:]).  Only for shapes nk_linear_fwd_geglu_ok() accepts (whole 256-column tiles on the 256 x 256
+ * two-group kernel); otherwise NK_ERR_ARG: call nk_linear_fwd then nk_geglu_fwd. */
+long nk_linear_fwd_geglu_ok(int M, int I, int K);
+int nk_linear_fwd_geglu(const void* x, const void* w, const float* bias, void* u, void* h, int M, int I, int K, long ldx, long ldw, long ldu,
+                        long ldh, void* stream);
 int nk_linear_dgrad_geglu(const void* dy, const void* w, const void* u, void* du, int M, int N, int I, long lddy, long ldw, long ldu,
                           long lddu, void* stream);
 int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy, long ldx,

@@ -1199,7 +1199,9 @@ __global__ __launch_bounds__((XL_BM / WM) * (XL_BN / WN) * 64, (XL_BM / WM) * (X
     }
 }
 
-template <int AMODE>
+// GEGLU = 1: the FeedForward projection with its GEGLU (modules/attention.py:50-57) in the epilogue -- see NkGemmParams::geglu_h.  Column tile nt
+// covers a-columns [128 nt, 128 nt + 128) and the gate columns I + the same: tile row blocks (16 rows of B) alternate a / gate.
+template <int AMODE, int GEGLU = 0>
 __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1222,8 +1224,17 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
   OperandDMA<OP_KC, 2> b0, b1;
   a0.init(p.A, p.lda, p.M, m0, tid, p.ga);
   a1.init(p.A, p.lda, p.M, m0 + 128, tid, p.ga);
-  b0.init(p.B, p.ldb, p.N, n0, tid, p.gb);
-  b1.init(p.B, p.ldb, p.N, n0 + 128, tid, p.gb);
+  if constexpr (GEGLU) {
+    // a wave stages one 16-row block of each B half (kc_row = wave * 16 + ...): block gb = wave (b0) or 8 + wave (b1) of the tile holds
+    // weight rows (gb odd ? I : 0) + n0 / 2 + (gb >> 1) * 16 + (0..15); the loader is given r0 such that r0 + kc_row lands there
+    const int I = p.N >> 1, wv = tid >> 6;
+    const int gb0 = wv, gb1 = 8 + wv;
+    b0.init(p.B, p.ldb, p.N, ((gb0 & 1) ? I : 0) + (n0 >> 1) + (gb0 >> 1) * 16 - wv * 16, tid, p.gb);
+    b1.init(p.B, p.ldb, p.N, ((gb1 & 1) ? I : 0) + (n0 >> 1) + (gb1 >> 1) * 16 - wv * 16, tid, p.gb);
+  } else {
+    b0.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+    b1.init(p.B, p.ldb, p.N, n0 + 128, tid, p.gb);
+  }
   a0.start(0); a1.start(0); b0.start(0); b1.start(0);
   float4_t acc[8][4];
 #pragma unroll
@@ -1317,6 +1328,42 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
 #undef X2_RDB
 #undef X2_BAR
 #undef X2_MM
+  if constexpr (GEGLU) {
+    // the wave's four column blocks are (a, gate, a, gate) of a-columns abase .. abase + 31: the lane holds a and gate of the same four j
+    const int I = p.N >> 1;
+    const int abase = (n0 >> 1) + wn * 32;
+    const int cl = (lane >> 4) * 4;
+    float4_t ba[2], bg[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      ba[q] = p.bias ? *(const float4_t*)(p.bias + abase + q * 16 + cl) : (float4_t){0.f, 0.f, 0.f, 0.f};
+      bg[q] = p.bias ? *(const float4_t*)(p.bias + I + abase + q * 16 + cl) : (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    NkGemmParams ph = p;               // the GEGLU output: [M][I], no bias (it is inside a and g already)
+    ph.N = I; ph.ldc = p.ld_h; ph.bias = nullptr;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      float4_t pa[4][2], pg[4][2], phh[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          pa[i][q] = acc[ib * 4 + i][2 * q];
+          pg[i][q] = acc[ib * 4 + i][2 * q + 1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // what the consumer of u would read: the bf16-rounded a and g
+            const float av = bf2f(f2bf(pa[i][q][r] + ba[q][r])), gv = bf2f(f2bf(pg[i][q][r] + bg[q][r]));
+            phh[i][q][r] = av * gelu_erf(gv);
+          }
+        }
+      const int mb = m0 + wm * 128 + ib * 64;
+      reg_epilogue_64x32<0>(p, p.C, pa, mb, abase, lane);           // u[:, a-columns]  (+ bias[abase ..])
+      reg_epilogue_64x32<0>(p, p.C, pg, mb, I + abase, lane);       // u[:, I + a-columns]  (+ bias[I + abase ..])
+      reg_epilogue_64x32<0>(ph, p.geglu_h, phh, mb, abase, lane);
+    }
+    return;
+  }
 #pragma unroll
   for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -1363,10 +1410,16 @@ static int launch_xl(const NkGemmParams& p, hipStream_t stream) {
   // conv forward 781-785 vs 835-840 TFLOP/s)
   if (AMODE == OP_KC) {
     static bool gattr = false;
-    auto kern = nk_gemm_xl2g_kernel<AMODE>;
-    if (!gattr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES); gattr = true; }
+    auto kern = nk_gemm_xl2g_kernel<OP_KC, 0>;
+    auto kerng = nk_gemm_xl2g_kernel<OP_KC, 1>;
+    if (!gattr) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES);
+      (void)hipFuncSetAttribute((const void*)kerng, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES);
+      gattr = true;
+    }
     dim3 grid(((p.M + XL_BM - 1) / XL_BM) * ((p.N + XL_BN - 1) / XL_BN), 1, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(512), XL_SMEM_BYTES, stream, p);
+    if (p.geglu_h) hipLaunchKernelGGL(kerng, grid, dim3(512), XL_SMEM_BYTES, stream, p);
+    else hipLaunchKernelGGL(kern, grid, dim3(512), XL_SMEM_BYTES, stream, p);
     return nk_check_launch("nk_gemm_xl2g_kernel");
   }
   return launch_xl_as<AMODE, 64, 64>(p, stream);
@@ -1558,6 +1611,16 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   if (p.fRowsPerBatch.d == 0) p.fRowsPerBatch = make_fastdiv(1);
 
   if (p.dbias || (p.nbatch && p.dbias_b[0])) NK_CHECK_ARG(amode == OP_MC && out_f32);      // weight-gradient launches only
+  if (p.geglu_h) {   // the fused GEGLU forward lives in the 256 x 256 two-group kernel only: the caller asks nk_linear_fwd_geglu_ok first
+    NK_CHECK_ARG(amode == OP_KC && bmode == OP_KC && !out_f32 && !p.nbatch && (p.N & 255) == 0 && (p.ld_h & 7) == 0 && !p.rowvec && !p.residual && p.alpha == 1.0f);
+    NK_CHECK_ARG(((uintptr_t)p.geglu_h & 15) == 0 && (!p.bias || ((uintptr_t)p.bias & 15) == 0));
+    if (!use_xl(p, amode, bmode, out_f32, 1)) {
+      nk_set_error(__FILE__, __LINE__, "fused GEGLU forward on a shape the 256 x 256 kernel does not take (ask nk_linear_fwd_geglu_ok first)");
+      return NK_ERR_ARG;
+    }
+    set_split(p, 1);
+    return launch_xl<OP_KC>(p, stream);
+  }
   if (p.geglu_u) {   // the fused GEGLU backward lives in the LDS-staged epilogue of the 128 x 128 data-parallel / ring kernels only
     NK_CHECK_ARG(amode == OP_KC && bmode == OP_MC && !out_f32 && !p.nbatch && (p.N & 7) == 0 && (p.ld_u & 7) == 0 && !p.bias && !p.rowvec && !p.residual);
     set_split(p, 1);
@@ -1646,3 +1709,8 @@ int nk_halo_tiles_per_image(const NkGemmParams& p) {
   return halo_tiles_per_image(p);
 }
 
+
+// 1 when nk_linear_fwd_geglu takes this FeedForward projection (the 256 x 256 two-group kernel's shape rule, whole 256-column tiles)
+int nk_geglu_fwd_fusable(const NkGemmParams& p) {
+  return (p.N & 255) == 0 && use_xl(p, OP_KC, OP_KC, 0, 1) ? 1 : 0;
+}

@@ -64,6 +64,11 @@ struct NkGemmParams {
   // a = geglu_u[m][n], g = geglu_u[m][N + n] (ld_u elements per row) -- i.e. C is dL/du [M][2N]
   const bf16_t* geglu_u;
   long ld_u;
+  // GEGLU FORWARD fused into the FeedForward projection (the 256 x 256 two-group kernel only): C = u [M][N = 2 I] as always, and
+  // geglu_h[m][j] = a * gelu(g), a = u[m][j], g = u[m][I + j] (ld_h elements per row).  The kernel pairs the two halves by reading the
+  // weight rows of a column tile as 16 a-rows, 16 gate-rows, 16 a-rows, ...: a lane then holds a and g of the same j.
+  bf16_t* geglu_h;
+  long ld_h;
   // halo-tile 3 x 3 convolution (conv_halo.h)
   int halo_nb;              // images in the batch (0: not a convolution the halo kernel may take)
   float* stats_part;        // statistics epilogue: [halo_nb][pixel tiles per image][2 * stats_groups] partial sums of the OUTPUT
@@ -75,3 +80,4 @@ enum { NK_OP_KC = 0, NK_OP_KCG = 1, NK_OP_MC = 2, NK_OP_MCT = 3, NK_OP_MCG = 4 }
 
 int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int allow_splitk, hipStream_t stream);
 int nk_halo_tiles_per_image(const NkGemmParams& p);
+int nk_geglu_fwd_fusable(const NkGemmParams& p);

@@ -60,6 +60,32 @@ extern "C" int nk_linear_dgrad(const void* dy, const void* w, const void* dx_add
   return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_MC, 0, 0, (hipStream_t)stream);
 }
 
+static NkGemmParams geglu_fwd_params(const void* x, const void* w, const float* bias, void* u, void* h, int M, int I, int K, long ldx, long ldw,
+                                      long ldu, long ldh) {
+  NkGemmParams p = zero_params();
+  p.A = (const bf16_t*)x; p.lda = ldx;
+  p.B = (const bf16_t*)w; p.ldb = ldw;
+  p.M = M; p.N = 2 * I; p.K = K;
+  p.C = u; p.ldc = ldu;
+  p.bias = bias;
+  p.geglu_h = (bf16_t*)h; p.ld_h = ldh;
+  return p;
+}
+extern "C" long nk_linear_fwd_geglu_ok(int M, int I, int K) {
+  // 1 when nk_linear_fwd_geglu takes this shape (else: nk_linear_fwd followed by nk_geglu_fwd)
+  if (M <= 0 || I <= 0 || K <= 0 || (I & 127) || (K & 7)) return 0;
+  NkGemmParams p = geglu_fwd_params(nullptr, nullptr, nullptr, nullptr, (void*)16, M, I, K, K, K, 2l * I, I);
+  return nk_geglu_fwd_fusable(p);
+}
+extern "C" int nk_linear_fwd_geglu(const void* x, const void* w, const float* bias, void* u, void* h, int M, int I, int K, long ldx, long ldw,
+                                   long ldu, long ldh, void* stream) {
+  // FeedForward.net[0] (GEGLU, modules/attention.py:50-57) in one launch: u[M, 2I] = x[M, K] @ w[2I, K]^T + bias (kept for the backward) and
+  // h[M, I] = u[:, :I] * gelu(u[:, I:]) from the same accumulators -- the stand-alone GEGLU forward kernel and its read of u are gone
+  NK_CHECK_ARG(x && w && u && h && M > 0 && I > 0 && K > 0);
+  NkGemmParams p = geglu_fwd_params(x, w, bias, u, h, M, I, K, ldx, ldw, ldu, ldh);
+  return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_KC, 0, 0, (hipStream_t)stream);
+}
+
 extern "C" int nk_linear_dgrad_geglu(const void* dy, const void* w, const void* u, void* du, int M, int N, int I, long lddy, long ldw,
                                      long ldu, long lddu, void* stream) {
   // FeedForward backward through net[2] and the GEGLU in one launch (modules/attention.py:60-74): d = dy[M,N] @ w[N,I] is the gradient of

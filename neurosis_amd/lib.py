@@ -37,6 +37,7 @@ SIGNATURES: dict[str, list] = {
     "nk_linear_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, f32, vp],
     "nk_linear_dgrad": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "nk_linear_dgrad_geglu": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
+    "nk_linear_fwd_geglu": [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "nk_linear_wgrad": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp],
     "nk_linear_fwd_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, vp],
     "nk_linear_wgrad_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, i32, vp],
@@ -107,6 +108,7 @@ SIZE_QUERIES: dict[str, list] = {
     "nk_groupnorm_sums_ws_floats": [i32, i32, i32],
     "nk_conv2d_stats_tiles": [cdp, i32],
     "nk_conv2d_dgrad_flipped_ok": [cdp],
+    "nk_linear_fwd_geglu_ok": [i32, i32, i32],
     "nk_layernorm_ws_floats": [i32, i32],
     "nk_colsum_ws_floats": [i64, i32],
     "nk_batchnorm_ws_floats": [i64, i32],

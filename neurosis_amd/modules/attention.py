@@ -59,8 +59,8 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
 
     def fwd(self, x: Tensor, residual: Optional[Tensor] = None):
-        u, b_proj = linear_module_fwd(self.net[0].proj, x)
-        g = ops.geglu_fwd(u)[0]
+        proj = self.net[0].proj
+        u, g, b_proj = ops.linear_geglu_fwd(x, proj.weight, proj.bias)       # the GEGLU rides in the projection's epilogue where it can
         y, b_out = linear_module_fwd(self.net[2], g, residual)
 
         def bwd(dy: Tensor):

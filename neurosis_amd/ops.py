@@ -473,7 +473,30 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
     """nn.Linear forward on a token matrix, with optional fused residual add.
     bwd(dy, dx_add=None) -> dx (None if need_dx is False); writes weight.grad / bias.grad."""
     y = gemm_nt(x, w2d(weight), bias, residual)
+    return y, _linear_bwd(x, weight, bias, need_dx)
 
+
+def linear_geglu_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor]):
+    """FeedForward.net[0] = GEGLU (modules/attention.py:50-57): u = x @ weight^T + bias [M, 2I] and h = u[:, :I] * gelu(u[:, I:]) [M, I].
+    One launch (the GEGLU in the projection's epilogue, nk_linear_fwd_geglu) where the 256 x 256 kernel takes the shape -- the two SDXL
+    FeedForward widths at batch 4 -- else the GEMM followed by the GEGLU kernel.  Returns (u, h, bwd); bwd(du) as linear_fwd's."""
+    _check2d(x, "x")
+    M, K = x.shape
+    I2 = weight.shape[0]
+    I = I2 // 2
+    wq = w2d(weight)
+    if I2 % 2 == 0 and x.is_contiguous() and query("nk_linear_fwd_geglu_ok", M, I, K):
+        u = torch.empty(M, I2, dtype=BF16, device=x.device)
+        h = torch.empty(M, I, dtype=BF16, device=x.device)
+        call("nk_linear_fwd_geglu", x.data_ptr(), wq.data_ptr(), _p(bias), u.data_ptr(), h.data_ptr(), M, I, K, x.stride(0), wq.stride(0), u.stride(0), h.stride(0),
+             _stream())
+    else:
+        u = gemm_nt(x, wq, bias, None)
+        h = geglu_fwd(u)[0]
+    return u, h, _linear_bwd(x, weight, bias, True)
+
+
+def _linear_bwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], need_dx: bool):
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None, geglu_u: Optional[Tensor] = None):
         """geglu_u = the [a | g] matrix whose GEGLU produced x (FeedForward): the returned gradient is then d/du [M, 2K], the GEGLU
         backward applied in the input-gradient GEMM's epilogue (nk_linear_dgrad_geglu)"""
@@ -502,7 +525,7 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
             return du
         return gemm_nn(dy, w2d(weight), dx_add)
 
-    return y, bwd
+    return bwd
 
 
 # ------------------------------------------------------------------------------------------------

@@ -688,6 +688,27 @@ def _(x, w, bias, N, H, W, groups):
     return x.new_empty(N * H * W, w.shape[0]), x.new_empty(N, 2 * groups, dtype=torch.float32)
 
 
+@_op("linear_fwd_geglu")
+def linear_fwd_geglu(x: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """FeedForward.net[0] (GEGLU): u = x @ w^T + bias [M, 2I] and h = u[:, :I] * gelu(u[:, I:]) [M, I] -- one launch where the 256 x 256 kernel
+    takes the shape (ops.linear_geglu_fwd), else the projection followed by the GEGLU kernel"""
+    M, K = x.shape
+    I = w.shape[0] // 2
+    if x.is_contiguous() and w.is_contiguous() and ops.query("nk_linear_fwd_geglu_ok", M, I, K):
+        u = torch.empty(M, 2 * I, dtype=BF16, device=x.device)
+        h = torch.empty(M, I, dtype=BF16, device=x.device)
+        ops.call("nk_linear_fwd_geglu", x.data_ptr(), w.data_ptr(), ops._p(bias), u.data_ptr(), h.data_ptr(), M, I, K, x.stride(0), w.stride(0), u.stride(0),
+                 h.stride(0), ops._stream())
+        return u, h
+    u = torch.ops.neurosis_hip.linear_fwd(x, w, bias)
+    return u, torch.ops.neurosis_hip.geglu_fwd(u)
+
+
+@linear_fwd_geglu.register_fake
+def _(x, w, bias):
+    return x.new_empty(x.shape[0], w.shape[0]), x.new_empty(x.shape[0], w.shape[0] // 2)
+
+
 @_op("linear_dgrad_geglu")
 def linear_dgrad_geglu(dy: Tensor, w: Tensor, u: Tensor) -> Tensor:
     """FeedForward backward through net[2] and the GEGLU in one launch: du [M, 2I] from dy [M, N], w [N, I], u = [a | g] [M, 2I]"""
@@ -705,6 +726,6 @@ def _(dy, w, u):
 
 
 OPS = ("cat_channels", "split_channels", "upsample2x_nearest_bwd", "upsample2x_nearest_conv", "edm_prepare", "edm_loss_fwd", "edm_loss_bwd", "edm_loss",
-       "flat_allreduce_start", "flat_allreduce_wait", "conv2d_fwd_stats", "linear_dgrad_geglu", "linear_fwd", "linear_dgrad", "linear_wgrad", "colsum", "linear", "layernorm_fwd", "layernorm_bwd", "layernorm", "groupnorm_silu_fwd",
+       "flat_allreduce_start", "flat_allreduce_wait", "conv2d_fwd_stats", "linear_dgrad_geglu", "linear_fwd_geglu", "linear_fwd", "linear_dgrad", "linear_wgrad", "colsum", "linear", "layernorm_fwd", "layernorm_bwd", "layernorm", "groupnorm_silu_fwd",
        "groupnorm_silu_bwd", "groupnorm_silu", "geglu_fwd", "geglu_bwd", "geglu", "attention_fwd", "attention_bwd", "attention", "conv2d_fwd",
        "conv2d_dgrad", "conv2d_wgrad", "conv2d", "timestep_embedding", "nchw_to_nlc", "nlc_to_nchw")

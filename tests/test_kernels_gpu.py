@@ -429,3 +429,36 @@ def test_colsum_batched_and_linear_fwd_batched(ops):
     outs = ops.gemm_nt_batched([dev(x)] * 11, [dev(w) for w in ws_])
     for w, o in zip(ws_, outs):
         assert_close(o, x @ w.t(), TOL_BF16, "linear_fwd_batched")
+
+
+@pytest.mark.parametrize("shape", [(4096, 5120, 1280), (16384, 2560, 640), (1000, 384, 256)])
+def test_feedforward_projection_with_fused_geglu_forward(ops, shape):
+    """FeedForward.net[0] (modules/attention.py:50-57): the GEGLU in the projection's epilogue (nk_linear_fwd_geglu, the two SDXL widths at batch 4)
+    gives bit for bit what the projection followed by the GEGLU kernel gives -- u, the saved pre-activation, and h -- and both agree with torch;
+    a shape the 256 x 256 kernel does not take (the third) falls back to the two launches behind the same call."""
+    import torch.nn.functional as F
+
+    from neurosis_amd.lib import query
+
+    M, I, K = shape
+    x, w = rnd(M, K), rnd(2 * I, K, scale=K ** -0.5)
+    b = torch.randn(2 * I, generator=torch.Generator().manual_seed(9)) * 0.1
+    wp = torch.nn.Parameter(w.float().cuda())
+    bp = torch.nn.Parameter(b.cuda())
+    fused = bool(query("nk_linear_fwd_geglu_ok", M, I, K))
+    assert fused is (M >= 4096)
+    u, h, bwd = ops.linear_geglu_fwd(dev(x), wp, bp)
+    u2, _ = ops.linear_fwd(dev(x), wp, bp)
+    h2 = ops.geglu_fwd(u2)[0]
+    assert torch.equal(u, u2) and torch.equal(h, h2)
+    ur = F.linear(x.float(), w.float(), b)
+    assert_close(u, ur, 2e-2, "geglu projection u")
+    uq = u.float().cpu()
+    assert_close(h, uq[:, :I] * F.gelu(uq[:, I:]), 2e-2, "geglu h")
+    # the backward closure is the projection's: weight / bias / input gradients of du
+    du = rnd(M, 2 * I, seed=5)
+    dx = bwd(dev(du))
+    ops.join_wgrad_stream()
+    assert_close(dx, du.float() @ w.float(), 2e-2, "geglu projection dx")
+    assert_close(wp.grad, du.float().t() @ x.float(), 1e-2, "geglu projection dw")
+    assert_close(bp.grad, du.float().sum(0), 1e-2, "geglu projection db")

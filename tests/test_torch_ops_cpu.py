@@ -44,6 +44,8 @@ def test_meta_kernels_give_the_right_shapes():
     y, sums = o.conv2d_fwd_stats(m(2 * 32 * 32, 64), m(128, 3, 3, 64), None, 2, 32, 32, 32)
     assert y.shape == (2048, 128) and sums.shape == (2, 64) and sums.dtype == f32
     assert o.linear_dgrad_geglu(m(256, 64), m(64, 128), m(256, 256)).shape == (256, 256)
+    u, h = o.linear_fwd_geglu(m(256, 64), m(512, 64), None)
+    assert u.shape == (256, 512) and h.shape == (256, 256)
     assert o.nchw_to_nlc(m(2, 4, 8, 8, dtype=torch.float32), 8).shape == (128, 8)
     assert o.nlc_to_nchw(m(128, 8), 2, 4, 8, 8).shape == (2, 4, 8, 8)
 

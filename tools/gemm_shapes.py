@@ -18,6 +18,10 @@ shapes = []
 def flops(name, args):
     if name in ("nk_linear_fwd_batched", "nk_linear_wgrad_batched"):      # key carries the count: "x3 per launch"
         key = (f"{name[:-8]}[x{args[3]}]", args[4], args[5], args[6])
+    elif name == "nk_linear_fwd_geglu":
+        key = (name, args[5], 2 * args[6], args[7])
+    elif name == "nk_linear_dgrad_geglu":
+        key = (name, args[4], args[6], args[5])
     elif name.startswith("nk_linear"):
         key = (name, args[5], args[6], args[7]) if name == "nk_linear_fwd" else ((name, args[4], args[5], args[6]) if name == "nk_linear_dgrad" else (name, args[3], args[4], args[5]))
     else:
