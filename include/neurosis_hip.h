@@ -70,6 +70,10 @@ int nk_gemm_sk_status(void);
  *   nk_debug_raise_health(stream): test hook, raises the word the way a kernel would. */
 int nk_health_status(void);
 int nk_health_clear(void);
+/* Data parallelism: nk_health_export writes this rank's word (0 / 1) to a device int32 the caller owns; the caller reduces it over the ranks
+ * (MAX) and hands the result to nk_health_import, which raises the local word if any rank's was raised.  Both stream-ordered. */
+int nk_health_export(int* dst, void* stream);
+int nk_health_import(const int* src, void* stream);
 int nk_debug_raise_health(void* stream);
 
 /* `count` (<= 8) weight gradients of identical shape in ONE launch: the three 1280x1280 projections of a transformer

@@ -102,3 +102,25 @@ extern "C" int nk_debug_raise_health(void* stream) {
   hipLaunchKernelGGL(nk_raise_health_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d);
   return nk_check_launch("nk_raise_health_kernel");
 }
+
+// ---- the health word across data-parallel ranks: export this rank's word into a caller-owned int32 (the caller reduces it over the ranks with
+// MAX, on the exchange stream), import the result back (OR).  A rank whose stream-K fix-up gave up poisons its gradient tile with NaN and the
+// all-reduce spreads that NaN to every rank: with the word merged, every rank's optimizer kernels skip the update, not only the flagged one's.
+__global__ void nk_health_export_kernel(const unsigned* w, int* dst) { *dst = (int)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void nk_health_import_kernel(unsigned* w, const int* src) {
+  if (*src) __hip_atomic_store(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+extern "C" int nk_health_export(int* dst, void* stream) {
+  unsigned* d = nk_health_word();
+  NK_CHECK_ARG(dst != nullptr);
+  if (!d) { nk_set_error(__FILE__, __LINE__, "health word allocation failed"); return NK_ERR_LAUNCH; }
+  hipLaunchKernelGGL(nk_health_export_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d, dst);
+  return nk_check_launch("nk_health_export_kernel");
+}
+extern "C" int nk_health_import(const int* src, void* stream) {
+  unsigned* d = nk_health_word();
+  NK_CHECK_ARG(src != nullptr);
+  if (!d) { nk_set_error(__FILE__, __LINE__, "health word allocation failed"); return NK_ERR_LAUNCH; }
+  hipLaunchKernelGGL(nk_health_import_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d, src);
+  return nk_check_launch("nk_health_import_kernel");
+}

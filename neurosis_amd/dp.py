@@ -157,6 +157,7 @@ class FlatDataParallel:
         self.rank = self.reducer.rank
         self.sync = True
         self._optimizers = []
+        self._health = None
         if broadcast_params and self.world > 1:
             dist.broadcast(store.master, src=0, group=group)
             store.refresh()
@@ -183,9 +184,31 @@ class FlatDataParallel:
         self.sync = not flag
 
     def finish(self) -> float:
-        """Wait for the exchange; returns the grad_scale (1/world) the optimizer must apply for the mean."""
+        """Wait for the exchange; returns the grad_scale (1/world) the optimizer must apply for the mean.
+        Also merges the device health word over the ranks (MAX), behind the last slice on the exchange stream: a rank whose stream-K fix-up
+        gave up has poisoned its gradient tile with NaN, the reduction has spread it to every rank, and every rank's optimizer kernels must
+        skip that update -- not only the flagged rank's."""
+        self._merge_health()
         self.reducer.finish()
         return 1.0 / self.world
+
+    def _merge_health(self) -> None:
+        if self.world == 1 or not self.store.grad.is_cuda or not self.sync:
+            return
+        from .lib import call
+
+        if self._health is None:
+            self._health = torch.zeros(1, dtype=torch.int32, device=self.store.grad.device)
+        main = torch.cuda.current_stream()
+        ex = self.reducer.stream
+        ex.wait_stream(main)                      # the backward (whose kernels may raise the word) is complete
+        for s in (self.store.state.wgrad_stream,):
+            if s is not None:
+                ex.wait_stream(s)
+        with torch.cuda.stream(ex):
+            call("nk_health_export", self._health.data_ptr(), ex.cuda_stream)
+            dist.all_reduce(self._health, op=dist.ReduceOp.MAX, group=self.group)
+            call("nk_health_import", self._health.data_ptr(), ex.cuda_stream)
 
     # -- rs_ag: the optimizer runs on the owned shard only; shadows are gathered afterwards ------------------------------------------
     @property

@@ -98,6 +98,8 @@ SIGNATURES: dict[str, list] = {
     "nk_ema_flat": [vp, vp, i64, f32, vp],
     "nk_debug_raise_health": [vp],
     "nk_health_clear": [],
+    "nk_health_export": [vp, vp],
+    "nk_health_import": [vp, vp],
     "nk_adafactor_init": [vp, vp],
     "nk_adafactor_chunk": [vp, vp],
 }

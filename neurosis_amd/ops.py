@@ -52,8 +52,9 @@ class EngineState:
         # 203.9 ms/step in round 1, +5.5 ms in round 2: 210 more cross-stream event waits per step delay the weight-gradient GEMMs
         # queued behind them).  Under hipGraph replay those waits are gone -- the parked launches become part of each segment's
         # side-stream graph -- and the main chain sheds ~4 ms of small kernels: 177.2 / 177.1 vs 178.2 / 178.7 ms/step (bench.py,
-        # alternating).  So: on where the chain replays from graphs (the default), off with NK_GRAPH=0.
-        self.norm_params_on_side_stream = os.environ.get("NK_GRAPH", "unet") != "0"
+        # alternating).  So: None = automatic -- on exactly for launches that are being CAPTURED for replay (`deferred` is a list), off for
+        # every eager launch (NK_GRAPH=0, a chain whose capture failed, the frozen towers, bench.py's instrumented eager replays); True / False force it.
+        self.norm_params_on_side_stream: Optional[bool] = None
         # hipGraph capture of a backward chain (neurosis_amd/graphs.py): while `deferred` is a list, on_wgrad_stream() parks the
         # side-stream work there instead of launching it, and the chain reports the end of each top-level block to
         # `segment_hook`, which captures the parked launches as that segment's own graph
@@ -687,7 +688,8 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
             call("nk_layernorm_bwd_params", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                  grad_flat(weight).data_ptr(), grad_flat(bias).data_ptr(), ws.data_ptr(), M, Cc, int(acc), _stream())
 
-        if state_of(weight).norm_params_on_side_stream:
+        st_ = state_of(weight)
+        if st_.norm_params_on_side_stream if st_.norm_params_on_side_stream is not None else st_.deferred is not None:
             on_wgrad_stream(params, dy, x, mean, rstd, ws, owner=weight)
         else:
             params()

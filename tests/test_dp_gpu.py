@@ -270,3 +270,42 @@ def test_streamed_optimizer_equals_the_one_shot_update():
     assert float((finals[0] - finals[1]).norm() / finals[1].norm()) <= 1e-4
     assert float((states[0] - states[1]).norm() / states[1].norm()) <= 1e-3
     assert float((finals[1] - _build(fx, shapes).store.master).norm()) > 0.0
+
+
+def _worker_health(rank, world, port, out):
+    """rank 0's health word is raised during its backward (as a stream-K give-up would); after the exchange BOTH ranks' words are set and BOTH
+    skip the update."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neurosis_amd import lib
+    from neurosis_amd.dp import FlatDataParallel
+
+    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
+    eng = _build(fx, shapes)
+    eng.overlap_optimizer = False
+    eng.configure_adafactor(scale_parameter=True, relative_step=False, warmup_init=False, lr=1e-3)
+    dp = FlatDataParallel(eng.model.diffusion_model, eng.store)
+    before = eng.store.master.clone()
+    _loss(eng, fx, slice(rank, rank + 1)).mean().backward()
+    if rank == 0:
+        lib.call("nk_debug_raise_health", torch.cuda.current_stream().cuda_stream)
+    scale = dp.finish()
+    eng.optimizer_step(grad_scale=scale, dp=dp)
+    eng.join_optimizer()
+    torch.cuda.synchronize()
+    out[rank] = dict(status=int(lib.query("nk_health_status")), unchanged=bool(torch.equal(eng.store.master, before)))
+    lib.call("nk_health_clear")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_health_word_is_merged_over_the_ranks():
+    """(advisor, round 2) the fail-closed word was per process: the healthy rank applied the NaN the all-reduce had brought it"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_health, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r]["status"] == 1 and out[r]["unchanged"], (r, out[r])

@@ -35,7 +35,7 @@ def main():
     if sys.argv[1:]:
         variants = {k: v for k, v in variants.items() if k == "base" or k in sys.argv[1:]}
     def restore():
-        est.wgrad_stream = side; est.batch_wgrads = True; eng.stream_optimizer = False; est.norm_params_on_side_stream = False
+        est.wgrad_stream = side; est.batch_wgrads = True; eng.stream_optimizer = False; est.norm_params_on_side_stream = None
         for k in ("NK_GEMM_G2", "NK_CONV_HALO", "NK_GEMM_SK"): os.environ.pop(k, None)
         for k in extra_env: os.environ.pop(k, None)
     for _ in range(3): step()
