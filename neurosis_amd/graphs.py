@@ -86,6 +86,7 @@ class ChainGraphs:
         self.pool = self.pool_w = self.pool_a = None
         self.stream: Optional[torch.cuda.Stream] = None
         self.replays = 0                # graph launches so far (tests)
+        self.generation = 0             # forward replays / captures so far, over ALL signatures: they share one activation pool
         self.broken = False             # a capture failed: the chain stays eager (still HIP kernels, launched from Python)
 
     def clear(self) -> None:
@@ -93,7 +94,8 @@ class ChainGraphs:
 
     # ------------------------------------------------------------------------------------------------
     def run(self, fwd: Callable, inputs: Sequence[Optional[Tensor]], extra_key=()):
-        key = (extra_key, tuple(_sig(t) for t in inputs), ops.wgrad_mode(self.owner), torch.is_grad_enabled())
+        mode = ops.wgrad_mode(self.owner)
+        key = (extra_key, tuple(_sig(t) for t in inputs), mode, torch.is_grad_enabled())
         pair = self.pairs.get(key)
         if pair is None:
             pair = self.pairs[key] = _Pair()
@@ -121,11 +123,18 @@ class ChainGraphs:
             pair.g_f.replay()
             self.replays += 1
         pair.gen += 1
-        gen = pair.gen
+        self.generation += 1
+        gen, chain_gen = pair.gen, self.generation
 
         def bwd(dout: Tensor):
-            if gen != pair.gen:
+            # (the signatures of a chain share ONE activation pool: a forward of ANY of them since this one has overwritten what this backward reads)
+            if gen != pair.gen or chain_gen != self.generation:
                 raise RuntimeError("neurosis_amd.graphs: backward of a forward that has since been replayed (its activations were overwritten)")
+            # the overwrite / add mode of the weight-gradient kernels is a launch argument baked into the captured backward: it is part of
+            # the signature, taken at forward time -- a caller that flips it between forward and backward would replay the wrong mode for ever
+            if ops.wgrad_mode(self.owner) != mode:
+                raise RuntimeError("neurosis_amd.graphs: the gradient accumulate mode changed between this chain's forward and its backward; "
+                                   "set it (DiffusionEngine.accumulate) BEFORE the forward of the micro-batch")
             if pair.segments is None:
                 self._capture_backward(pair, dout)
             else:

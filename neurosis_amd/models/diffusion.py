@@ -276,7 +276,8 @@ class DiffusionEngine(nn.Module):
 
     def accumulate(self, micro_batch_index: int, dp=None, last: bool = True):
         """Gradient accumulation (Lightning's `accumulate_grad_batches`, configs/sdxl/sdxl.example.yaml): call before the
-        backward of micro-batch `micro_batch_index` of an optimizer step.  The first micro-batch overwrites the gradients,
+        FORWARD of micro-batch `micro_batch_index` of an optimizer step (the overwrite / add mode is part of the replayed chain's signature:
+        changing it between a forward and its backward raises).  The first micro-batch overwrites the gradients,
         later ones add; with a FlatDataParallel `dp`, only the last micro-batch exchanges them (DDP's no_sync)."""
         self.store.state.grad_accumulate = micro_batch_index > 0
         self._last_micro_batch = bool(last)

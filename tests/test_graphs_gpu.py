@@ -165,6 +165,37 @@ def test_accumulate_mode_is_part_of_the_signature():
         os.environ.pop("NK_GRAPH", None)
 
 
+def test_mode_change_or_another_forward_between_forward_and_backward_is_refused():
+    """(advisor, round 2) A replayed backward has its overwrite / add mode baked in, and every signature of a chain shares one activation
+    pool: flipping the mode after the forward, or running another forward (of any signature) before the backward, must raise -- not
+    silently replay the wrong mode or read overwritten activations."""
+    batches = _batches(5)
+    os.environ["NK_GRAPH"] = "1"
+    try:
+        net, store, den, lossfn, wrapped = _setup()
+
+        def fwd(b):
+            return lossfn._forward(wrapped, den, {"crossattn": b["ctx"], "vector": b["y"]}, b["x"], {}, sigmas=b["sigma"], noise=b["noise"]).mean()
+
+        for b in batches[:3]:              # eager, capture, replay
+            store.state.grad_accumulate = False
+            fwd(b).backward()
+        store.state.grad_accumulate = False
+        loss = fwd(batches[3])
+        store.state.grad_accumulate = True
+        with pytest.raises(RuntimeError, match="accumulate mode changed"):
+            loss.backward()
+        store.state.grad_accumulate = False
+        loss = fwd(batches[3])
+        with torch.no_grad():              # another signature (no-grad forward: an evaluation pass) of the same chain, same pool
+            fwd(batches[4]); fwd(batches[4]); fwd(batches[4])
+        with pytest.raises(RuntimeError, match="has since been replayed"):
+            loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("NK_GRAPH", None)
+
+
 def test_split_k_weight_gradient_with_a_multi_megabyte_destination_survives_replay():
     """A 640 x 640 weight gradient over 16 384 rows is a 25-tile grid: split-K with fp32 atomics into a zeroed 1.6 MB destination.
     With `hipMemsetAsync` as the zero-fill, the captured memset node was not ordered before the GEMM on this ROCm and replayed
