@@ -1581,6 +1581,10 @@ static int pick_splitk(int M, int N, int K, int max_split) {
   int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int nk = (K + BK - 1) / BK;
   const int lo = 96, hi = 192;
+  // ... except long reductions into grids that leave half the 512 slots empty (the 128^2- and 64^2-level convolution weight gradients:
+  // 65 536 / 16 384 pixels = 1 024 / 256 k-steps into 135-225 tiles; the 64^2-level Linear ones): the atomics of one extra split are a few
+  // per cent of such a launch and two splits fill the slots -- 65536 x 320 x 5760: 938 -> 587 us, x 8640: 972 -> 617; step -1 ms (round 3)
+  if (tiles >= lo && tiles * 2 <= 512 && nk >= 256 && max_split >= 2) return 2;
   if (tiles >= lo) return 1;
   int s = 1;
   while (s < max_split && tiles * s < hi && nk / (s * 2) >= 8) s *= 2;
