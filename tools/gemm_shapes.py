@@ -16,8 +16,12 @@ timer = bench.GemmTimer()
 orig_flops = timer.flops
 shapes = []
 def flops(name, args):
-    if name in ("nk_linear_fwd_batched", "nk_linear_wgrad_batched"):      # key carries the count: "x3 per launch"
+    if name == "nk_linear_fwd_batched":      # key carries the count: "x3 per launch"
         key = (f"{name[:-8]}[x{args[3]}]", args[4], args[5], args[6])
+    elif name == "nk_linear_wgrad_batched":  # (ptrs, ptrs, ptrs, bias ptrs, count, M, N, K, ...)
+        key = (f"{name[:-8]}[x{args[4]}]", args[5], args[6], args[7])
+    elif name == "nk_linear_wgrad_bias":     # (dy, x, dw, dbias, M, N, K, ...)
+        key = (name, args[4], args[5], args[6])
     elif name == "nk_linear_fwd_geglu":
         key = (name, args[5], 2 * args[6], args[7])
     elif name == "nk_linear_dgrad_geglu":
@@ -43,5 +47,5 @@ tot = sum(a[2] for a in agg.values())
 print(f"total {tot:.1f} ms over {len(timer.records)} launches")
 import json
 json.dump([[list(k), a] for k, a in agg.items()], open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'gemm_shapes.json'), 'w'))
-for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:40]:
+for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:80]:
     print(f"{key[0]:16s} M/N/K={key[1]:>8d} {key[2]:>6d} {key[3]:>6d}  x{a[0]:4d}  {a[2]:7.2f} ms  {a[1]/a[2]/1e9:7.0f} TF/s  ({a[2]/a[0]*1e3:7.1f} us each)")
