@@ -125,6 +125,7 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []
+        self.tag = ""          # appended to the family name of launches made while it is set ("[frozen VAE]": the encoder's convolutions)
 
     @staticmethod
     def flops(name, args):
@@ -161,7 +162,7 @@ class GemmTimer:
             s.record()
             timer._orig(name, *args)
             e.record()
-            timer.records.append((name, timer.flops(name, args), s, e))
+            timer.records.append((name + timer.tag, timer.flops(name, args), s, e))
 
         lib.call = timed_call
         ops.call = timed_call
@@ -202,7 +203,8 @@ class GemmTimer:
             ms = max(s.elapsed_time(e) - self.overhead_ms, 1e-4)
             tot_f += f
             tot_ms += ms
-            a = per.setdefault(self.FAMILY.get(name, name), [0, 0.0, 0.0])
+            base, _, tag = name.partition("[")
+            a = per.setdefault(self.FAMILY.get(base, base) + ("[" + tag if tag else ""), [0, 0.0, 0.0])
             a[0] += 1
             a[1] += f
             a[2] += ms
@@ -494,9 +496,20 @@ def main():
                 est.wgrad_stream = None
             graph_env = os.environ.get("NK_GRAPH")
             os.environ["NK_GRAPH"] = "0"      # the timer wraps the Python-side launches: this step runs the eager chain
+            enc = eng.encode_first_stage
+
+            def tagged_encode(x):      # the frozen VAE encoder's launches are reported apart from the UNet's ("nk_conv2d_fwd[frozen VAE]")
+                timer.tag = "[frozen VAE]"
+                try:
+                    return enc(x)
+                finally:
+                    timer.tag = ""
+
+            eng.encode_first_stage = tagged_encode
             try:
                 step()
             finally:
+                del eng.encode_first_stage      # (the instance attribute shadowing the method)
                 est.wgrad_stream = side
                 timer.uninstall()
                 if graph_env is None:
