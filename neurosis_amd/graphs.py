@@ -2,7 +2,7 @@
 
 The UNet is driven from Python: ~2 700 C-ABI launches per training step, ~28 us of host time each (closure bookkeeping, ctypes
 marshalling, `hipLaunchKernel`), against kernels that take 2-100 us.  A launch sequence whose shapes repeat needs no host at
-all: `tools/micro/graph_cost.py` measures 0.3 us of host and 2.1 us of GPU time per dependent small kernel replayed from a
+all: a round-2 micro-benchmark (`profiles/r02_micro_graph_cost.txt`) measured 0.3 us of host and 2.1 us of GPU time per dependent small kernel replayed from a
 hipGraph on this ROCm, against 8.5 us launched one by one.
 
 `ChainGraphs.run(fwd, inputs)` keeps, per input signature, one forward graph and a SEGMENTED backward over private memory pools:

@@ -138,7 +138,7 @@ class DiffusionEngine(nn.Module):
 
     @property
     def stream_optimizer(self) -> bool:
-        """Apply the fused Adafactor block by block behind backward (NK_OPT_STREAM=1; measured slower, off by default).  It
+        """Apply the fused Adafactor block by block behind backward (`stream_optimizer = True`, `bench.py --stream-optimizer`; measured no faster, off by default).  It
         needs the UNet's gradient-ready hook, and a hook keeps the chain out of hipGraph replay (a FlatDataParallel wrapper
         takes the hook over when N > 1)."""
         return self._stream_optimizer
