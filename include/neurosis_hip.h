@@ -245,6 +245,10 @@ int nk_batchnorm_fwd(const void* x, const float* gamma, const float* beta, void*
                      float* running_var, float* ws, long M, int C, float eps, float momentum, float slope, void* stream);
 int nk_batchnorm_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean, const float* rstd, void* dx,
                      float* dgamma, float* dbeta, float* ws, long M, int C, float slope, int accumulate, void* stream);
+/* BatchNorm2d in evaluation mode (+ LeakyReLU): y = act((x - running_mean) * rsqrt(running_var + eps) * gamma + beta); the discriminator
+ * as log_images / validation see it (nn.BatchNorm2d.eval() inside NLayerDiscriminator, patchgan/model.py:53-83).  ws: C fp32 elements. */
+int nk_batchnorm_eval(const void* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var, void* y,
+                      float* ws, long M, int C, float eps, float slope, void* stream);
 
 /* LPIPS pieces (modules/losses/perceptual.py:64-228 over the AlexNet or VGG16 trunk of extractors.py:11-30).
  * ReLU = nk_leaky_relu_* with slope 0.

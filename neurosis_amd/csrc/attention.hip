@@ -336,6 +336,705 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p
 }
 
 // ================================================================================================
+// head dim 64 (round 4): the SDXL / text-tower shape, rebuilt around VALU issue and LDS-DMA staging.
+// ================================================================================================
+// One LDS image for a [rows][64] bf16 tile (128-byte rows), filled by LDS-DMA and read BOTH by rows (ds_read_b128: the A operand of
+// S^T = K Q^T, dP^T = V dO^T, S = Q K^T, dP = dO V^T) and by columns (ds_read_b64_tr_b16: V^T, K^T, Q^T, dO^T operands): the 16-byte
+// chunk c of row r lives at  r * 128 + ((c ^ a64_swz(r)) << 4),  a64_swz(r) = bit 1 of r -> bit 2, bits 2-3 of r -> bits 0-1.
+//  * row read (lane&31 = row, 16 lanes per LDS pass = rows {0-3,12-15,20-27} / {4-11,16-19,28-31}, one chunk): the 8 even (odd) rows of
+//    a pass carry 8 different swizzles -> 16 different 16-byte bank windows: conflict-free;
+//  * transposed read (a 32-lane half = 4 consecutive rows x 64 bytes): bit 2 of the swizzle differs between rows r and r + 2, so the
+//    four rows land in the four 64-byte windows of the 256-byte bank line: conflict-free.
+// A DMA piece (one wave instruction) deposits 1 KiB = 8 rows linearly; the swizzle is applied on the SOURCE side (lane -> row l >> 3,
+// slot l & 7 <- chunk (l & 7) ^ swz(row)).  Rows past the end of the tensor are clamped to its last row (their scores are masked; a
+// zero page is not needed and stale LDS can never reach an MFMA as NaN).
+typedef __attribute__((address_space(1))) const void* att_gptr;
+typedef __attribute__((address_space(3))) void* att_lptr;
+typedef __attribute__((address_space(3))) const char* lds_c;
+__device__ __forceinline__ int a64_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+// LDS-DMA of [ROWS][64] tiles by a workgroup of NW waves: ROWS / 8 pieces, PPW per wave
+template <int ROWS, int NW>
+struct Dma64 {
+  static constexpr int PPW = ROWS / 8 / NW;
+  static_assert(PPW * 8 * NW == ROWS, "whole pieces per wave");
+  int off[PPW];      // byte offset of this lane's 16 bytes of piece j from the tile's first row
+  __device__ __forceinline__ void init(long stride, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int row = (wave * PPW + j) * 8 + (lane >> 3);
+      off[j] = (int)((row * stride + ((lane & 7) ^ a64_swz(row)) * 8) * 2);
+    }
+  }
+  // tile whose rows all exist: `tile` = address of its first row (wave-uniform)
+  __device__ __forceinline__ void issue_whole(const bf16_t* tile, char* img, int wave) const {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j)
+      __builtin_amdgcn_global_load_lds((att_gptr)((const char*)tile + off[j]), (att_lptr)(img + (wave * PPW + j) * 1024), 16, 0, 0);
+  }
+  // general (first / last tiles only: recomputes what issue_whole keeps in registers): rows row0 + r >= nrows are fetched from row nrows - 1
+  __device__ __forceinline__ void issue(const bf16_t* base, long stride, int row0, int nrows, char* img, int wave, int lane) const {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int row = (wave * PPW + j) * 8 + (lane >> 3);
+      const int r = min(row0 + row, nrows - 1);
+      __builtin_amdgcn_global_load_lds((att_gptr)(base + (long)r * stride + ((lane & 7) ^ a64_swz(row)) * 8), (att_lptr)(img + (wave * PPW + j) * 1024), 16, 0, 0);
+    }
+  }
+};
+// per-lane byte offsets (tile-relative) of the row-read fragments: k-step ks of rows [r0, r0 + 32), r0 a multiple of 32 (immediate)
+__device__ __forceinline__ void a64_row_bases(unsigned (&a)[4], int lane) {
+  const int r = lane & 31, f = a64_swz(r);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) a[ks] = (unsigned)(r * 128 + (((2 * ks + (lane >> 5)) ^ f) << 4));
+}
+// ... and of the transposed-read fragments: [j = low / high 8 rows of a 16-row block][dt = columns 0-31 / 32-63]; the block's first
+// row (a multiple of 16) goes into the immediate
+__device__ __forceinline__ void a64_tr_bases(unsigned (&a)[2][2], int lane) {
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int f = ((q4 >> 1) << 2) | ((h + 2 * j) & 3);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+      a[j][dt] = (unsigned)((4 * h + q4 + 8 * j) * 128 + (((4 * dt + 2 * g1 + (pp >> 1)) ^ f) << 4) + 8 * (pp & 1));
+  }
+}
+#define A64_RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+// an empty asm that "rewrites" x: pure instructions (MFMAs) float freely past asm volatile statements and sched_barriers when the block is
+// linearised, so a chain that must precede the next batch of LDS reads (register budget) is pinned by making those reads' predecessor
+// in the asm chain consume its result
+#define A64_PIN(x) asm volatile("" : "+v"(x))
+#define A64_RDTR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+__device__ __forceinline__ bf16x8_t a64_join(const short4_t& lo, const short4_t& hi) {
+  short8_t r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// ---- forward ----
+// The generic kernel above spends, per 64-key tile and wave, 16 MFMAs (512 matrix-pipe cycles) against ~200 vector issue slots (~930
+// cycles: 32 fmax, 32 fma, 32 v_exp at two slots each, 32 adds, 16 conversions, the alpha path, 4 ds_write_b128 of the staged tile):
+// the loop is VALU-issue-bound (profiles/r02_pmc_attention.txt).  Here the per-element work is  v_exp_f32 + v_add_f32  and half a
+// conversion:
+//  * Q is multiplied by scale * log2(e) ONCE, in its registers (bf16, as the reference's own math path rounds q * scale): scores arrive
+//    in log2 units;
+//  * the running maximum m is SUBTRACTED BY THE MFMA: the first MFMA of a score chain takes a 16-register block holding -m as its C
+//    operand (D != C is free), so  S' = K Q'^T - m  needs no vector instruction;
+//  * no per-tile maximum: p = exp2(S') is computed optimistically and the tile's row sum -- needed anyway -- is the overflow detector.
+//    While every lane's sum stays <= RESCALE_SUM (2^13: any p <= 2^13 is as exact in bf16 as a p <= 1 and far from fp32 overflow) m is
+//    left alone (cdna guide T13, "defer-max", here without even computing the max).  Otherwise (wave-uniform, rare after the first
+//    tile, which always takes it) the scores are recomputed from the K tile still in LDS, the maximum taken, O / l / m rescaled ONCE
+//    and the tile exponentiated against the new m -- the textbook order, so nothing is ever scaled twice or not at all;
+//  * K / V tiles arrive by LDS-DMA two tiles ahead into a ring of three stages (no staging registers, no ds_write, counted vmcnt).
+#define RESCALE_SUM 8192.0f
+template <int NW = 4>
+__global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams p) {
+  constexpr int TILE = 64 * 128, STAGE = 2 * TILE;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [3 stages][K, V][64][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, ql = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  const float c = p.scale * LOG2E;
+
+  const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * 64;
+  const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * 64;
+  const bf16_t* Vb = p.V + (long)b * p.bv + (long)hd * 64;
+  const int nt = (p.Lk + 63) / 64;
+
+  Dma64<64, NW> dk, dv;
+  dk.init(p.sk, wave, lane);
+  dv.init(p.sv, wave, lane);
+  dk.issue(Kb, p.sk, 0, p.Lk, smem, wave, lane);
+  dv.issue(Vb, p.sv, 0, p.Lk, smem + TILE, wave, lane);
+  if (nt > 1) {
+    dk.issue(Kb, p.sk, 64, p.Lk, smem + STAGE, wave, lane);
+    dv.issue(Vb, p.sv, 64, p.Lk, smem + STAGE + TILE, wave, lane);
+  }
+
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4_t z = {0u, 0u, 0u, 0u};
+    if (q0 + ql < p.Lq) z = *(const uint4_t*)(Qb + (long)(q0 + ql) * p.sq + 16 * ks + 8 * h5);
+    float f[8];
+    unpack8(z, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= c;
+    qf[ks] = __builtin_bit_cast(bf16x8_t, pack8(f));
+  }
+  float16_t oacc[2], negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; negm[r] = 0.f; }
+  float m = 0.f, l = 0.f;      // m: the reference point of this lane's query row, log2 units; l: this lane's half of the row sum
+
+  unsigned kab[4], vab[2][2];
+  a64_row_bases(kab, lane);
+  a64_tr_bases(vab, lane);
+  const unsigned smem_a = (unsigned)(size_t)(lds_c)smem;
+
+  // tile 0 has landed for everyone (the Q loads and tile 0 are older than tile 1's four pieces)
+  if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  unsigned so = 0, sn = 2 * STAGE;      // stage of tile t / of tile t + 2
+  // FIRST: tile 0 (defines m).  MASKED: tile t reaches past Lk, or the causal variant.  ISSUE: 2 = tile t + 2 lies wholly inside K / V,
+  // 1 = it may not (or may not exist).  Compile-time flags: as run-time wave-uniform branches hipcc flattens them into the common path.
+  auto iteration = [&](int t, auto first_tag, auto masked_tag, auto issue_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value, MASKED = decltype(masked_tag)::value;
+    constexpr int ISSUE = decltype(issue_tag)::value;
+    const bool more = ISSUE == 2 || t + 2 < nt;
+    if constexpr (ISSUE == 2) {
+      dk.issue_whole(Kb + (long)(t + 2) * 64 * p.sk, smem + sn, wave);
+      dv.issue_whole(Vb + (long)(t + 2) * 64 * p.sv, smem + sn + TILE, wave);
+    } else if (more) {
+      dk.issue(Kb, p.sk, (t + 2) * 64, p.Lk, smem + sn, wave, lane);
+      dv.issue(Vb, p.sv, (t + 2) * 64, p.Lk, smem + sn + TILE, wave, lane);
+    }
+    const unsigned kt = smem_a + so, vt = kt + TILE;
+    float16_t s[2];
+    // S'^T[key][q] = K Q'^T - m: all eight K fragments in one batch, one wait, eight MFMAs; the chains start from the -m block
+    auto scores = [&]() {
+      bf16x8_t kf[2][4];
+      const unsigned k0 = kt + kab[0], k1 = kt + kab[1], k2 = kt + kab[2], k3 = kt + kab[3];
+      A64_RD128(kf[0][0], k0, 0); A64_RD128(kf[0][1], k1, 0); A64_RD128(kf[0][2], k2, 0); A64_RD128(kf[0][3], k3, 0);
+      A64_RD128(kf[1][0], k0, 4096); A64_RD128(kf[1][1], k1, 4096); A64_RD128(kf[1][2], k2, 4096); A64_RD128(kf[1][3], k3, 4096);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[hf][0], qf[0], negm, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[hf][ks], qf[ks], s[hf], 0, 0, 0);
+      }
+      if constexpr (MASKED) {   // keys beyond Lk exist only in the last tile; the causal variant (text towers, L = 77) masks every tile
+        const int last = p.causal ? min(p.Lk - 1, q0 + ql) : p.Lk - 1;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[hf][r] = (t * 64 + hf * 32 + acc_row(r, h5)) <= last ? s[hf][r] : NEG_BIG;
+      }
+    };
+    scores();
+    // the V^T fragments of the first 32 keys are requested NOW: they do not depend on P, and the exponentials below cover their latency;
+    // those of the other 32 keys are requested behind them, in front of the first half's MFMAs (16 registers live at a time, not 32)
+    short4_t vlo[2][2][2], vhi[2][2][2];
+    const unsigned v00 = vt + vab[0][0], v01 = vt + vab[0][1], v10 = vt + vab[1][0], v11 = vt + vab[1][1];
+#define ATT_RDV(hf, s2)                                                                                                  \
+    A64_RDTR(vlo[hf][s2][0], v00, ((hf) * 32 + 16 * (s2)) * 128); A64_RDTR(vlo[hf][s2][1], v01, ((hf) * 32 + 16 * (s2)) * 128); \
+    A64_RDTR(vhi[hf][s2][0], v10, ((hf) * 32 + 16 * (s2)) * 128); A64_RDTR(vhi[hf][s2][1], v11, ((hf) * 32 + 16 * (s2)) * 128)
+#define ATT_WAITV(hf)                                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                    \
+                 : "+v"(vlo[hf][0][0]), "+v"(vlo[hf][0][1]), "+v"(vlo[hf][1][0]), "+v"(vlo[hf][1][1]), "+v"(vhi[hf][0][0]), "+v"(vhi[hf][0][1]), \
+                   "+v"(vhi[hf][1][0]), "+v"(vhi[hf][1][1]))
+    ATT_RDV(0, 0); ATT_RDV(0, 1);
+    float lsum = 0.f;
+    bool redo = FIRST;
+    if constexpr (!FIRST) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[hf][r] = EXP2(s[hf][r]);
+          lsum += s[hf][r];
+        }
+      redo = __any(!(lsum <= RESCALE_SUM));
+      if (redo) scores();      // (the V fragments requested above simply arrive earlier)
+    }
+    if (redo) {
+      float mloc = s[0][0];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[hf][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      // the first tile defines m (its highest score, whatever its sign); later m only rises
+      const float shift = FIRST ? mloc : fmaxf(mloc, 0.f);
+      if constexpr (!FIRST) {
+        const float alpha = EXP2(-shift);
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      }
+      m += shift;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m;
+      lsum = 0.f;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[hf][r] = EXP2(s[hf][r] - shift);
+          lsum += s[hf][r];
+        }
+    }
+    l += lsum;
+    auto pv_half = [&](auto hf_tag) {
+      constexpr int hf = decltype(hf_tag)::value;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t pf = pack_frag(s[hf], s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(vlo[hf][s2][dt], vhi[hf][s2][dt]), pf, oacc[dt], 0, 0, 0);
+      }
+    };
+    ATT_WAITV(0);
+    ATT_RDV(1, 0); ATT_RDV(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    pv_half(std::integral_constant<int, 0>{});
+    ATT_WAITV(1);
+    __builtin_amdgcn_sched_barrier(0);
+    pv_half(std::integral_constant<int, 1>{});
+#undef ATT_WAITV
+#undef ATT_RDV
+    // tile t + 1 (requested an iteration ago) has landed -- this wave's pieces by the counted wait, everyone's by the barrier, which also
+    // releases tile t's stage to the DMA of tile t + 3
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    so += STAGE; if (so == 3 * STAGE) so = 0;
+    sn += STAGE; if (sn == 3 * STAGE) sn = 0;
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    // tiles [0, nwhole) lie wholly inside K / V and need no mask
+    const int nwhole = p.causal ? 0 : p.Lk / 64;
+    if (nwhole > 0) iteration(0, T{}, F{}, I1{}); else iteration(0, T{}, T{}, I1{});
+    int t = 1;
+    for (; t + 2 < nwhole; ++t) iteration(t, F{}, F{}, I2{});
+    for (; t < nwhole; ++t) iteration(t, F{}, F{}, I1{});
+    for (; t < nt; ++t) iteration(t, F{}, T{}, I1{});
+  }
+
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  const int q = q0 + ql;
+  if (q < p.Lq) {
+    bf16_t* Ob = p.O + (long)b * p.bo + (long)q * p.so + (long)hd * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        uint2_t o;
+        o.x = pack2bf(oacc[dt][4 * r4 + 0] * inv, oacc[dt][4 * r4 + 1] * inv);
+        o.y = pack2bf(oacc[dt][4 * r4 + 2] * inv, oacc[dt][4 * r4 + 3] * inv);
+        *(uint2_t*)(Ob + dt * 32 + 8 * r4 + 4 * h5) = o;
+      }
+    if (h5 == 0) p.LSE[((long)b * p.H + hd) * p.Lq + q] = (m + __log2f(l)) * 0.6931471805599453f;
+  }
+}
+
+// ---- backward, dQ (head dim 64) ----
+// Queries on lanes, K / V tiles of 64 keys by LDS-DMA (the forward's ring).  The recomputation costs no vector instruction beyond the
+// exponential and one subtraction: Q' = bf16(Q * scale * log2 e) is rebuilt in registers exactly as the forward built it and -LSE * log2(e)
+// rides in as the C operand of the score chain (a 16-register block, constant for the lane's query), so p = exp2(S') and
+// dS = p * (dP - delta)  (a second block for -delta does not fit the 168 registers of three waves per SIMD).  Also written out for the dK / dV kernel, which runs behind this one: -delta, -LSE * log2(e) (what ITS chains start
+// from, fetched by DMA) and Q' itself as [B][H][Lq][64] (its A operand: both kernels then see bit-identical scores, and so does the
+// forward's LSE).
+struct Attn64Ws {       // layout of the backward workspace (floats) for head dim 64
+  long ndelta, nlse2, qs, part;
+  __host__ __device__ static Attn64Ws make(long B, long H, long Lq) {
+    Attn64Ws w;
+    const long n = (B * H * Lq + 63) & ~63l;
+    w.ndelta = 0; w.nlse2 = n; w.qs = 2 * n; w.part = 2 * n + B * H * Lq * 32;
+    return w;
+  }
+};
+template <int NW = 4>
+__global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dq_kernel(const AttnParams p) {
+  constexpr int TILE = 64 * 128, STAGE = 2 * TILE;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, ql = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  const int q = q0 + ql;
+  const float c = p.scale * LOG2E;
+
+  const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * 64;
+  const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * 64;
+  const bf16_t* Vb = p.V + (long)b * p.bv + (long)hd * 64;
+  const bf16_t* dOb = p.dO + (long)b * p.bdo + (long)hd * 64;
+  const bf16_t* Ocb = p.Oc + (long)b * p.bo + (long)hd * 64;
+  const int nt = (p.Lk + 63) / 64;
+
+  Dma64<64, NW> dk_, dv_;
+  dk_.init(p.sk, wave, lane);
+  dv_.init(p.sv, wave, lane);
+  dk_.issue(Kb, p.sk, 0, p.Lk, smem, wave, lane);
+  dv_.issue(Vb, p.sv, 0, p.Lk, smem + TILE, wave, lane);
+  if (nt > 1) {
+    dk_.issue(Kb, p.sk, 64, p.Lk, smem + STAGE, wave, lane);
+    dv_.issue(Vb, p.sv, 64, p.Lk, smem + STAGE + TILE, wave, lane);
+  }
+
+  const Attn64Ws ws = Attn64Ws::make(p.B, p.H, p.Lq);
+  const long row = ((long)b * p.H + hd) * p.Lq + q;
+  bf16x8_t qf[4], dof[4];
+  float dacc = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4_t zq = {0u, 0u, 0u, 0u}, zd = {0u, 0u, 0u, 0u}, zo = {0u, 0u, 0u, 0u};
+    const int d0 = 16 * ks + 8 * h5;
+    if (q < p.Lq) {
+      zq = *(const uint4_t*)(Qb + (long)q * p.sq + d0);
+      zd = *(const uint4_t*)(dOb + (long)q * p.sdo + d0);
+      zo = *(const uint4_t*)(Ocb + (long)q * p.so + d0);
+    }
+    float fq[8], fo[8], fd[8];
+    unpack8(zq, fq);
+    unpack8(zo, fo);
+    unpack8(zd, fd);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { fq[e] *= c; dacc += fo[e] * fd[e]; }
+    const uint4_t qs = pack8(fq);
+    qf[ks] = __builtin_bit_cast(bf16x8_t, qs);
+    dof[ks] = __builtin_bit_cast(bf16x8_t, zd);
+    if (q < p.Lq) *(uint4_t*)((bf16_t*)(p.delta + ws.qs) + row * 64 + d0) = qs;
+  }
+  const float dlt = dacc + __shfl_xor(dacc, 32, 64);
+  const float lse2 = q < p.Lq ? p.LSE[row] * LOG2E : 1.0e30f;       // rows past Lq: P = 0
+  if (q < p.Lq && h5 == 0) {
+    p.delta[ws.ndelta + row] = -dlt;
+    p.delta[ws.nlse2 + row] = -lse2;
+  }
+  float16_t dq[2], negl;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; negl[r] = -lse2; }
+
+  unsigned kab[4], ktb[2][2];
+  a64_row_bases(kab, lane);
+  a64_tr_bases(ktb, lane);
+  const unsigned smem_a = (unsigned)(size_t)(lds_c)smem;
+  if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  unsigned so = 0, sn = 2 * STAGE;
+  auto iteration = [&](int t, auto masked_tag, auto issue_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr int ISSUE = decltype(issue_tag)::value;
+    const bool more = ISSUE == 2 || t + 2 < nt;
+    if constexpr (ISSUE == 2) {
+      dk_.issue_whole(Kb + (long)(t + 2) * 64 * p.sk, smem + sn, wave);
+      dv_.issue_whole(Vb + (long)(t + 2) * 64 * p.sv, smem + sn + TILE, wave);
+    } else if (more) {
+      dk_.issue(Kb, p.sk, (t + 2) * 64, p.Lk, smem + sn, wave, lane);
+      dv_.issue(Vb, p.sv, (t + 2) * 64, p.Lk, smem + sn + TILE, wave, lane);
+    }
+    const unsigned kt = smem_a + so, vt = kt + TILE;
+    const unsigned k0 = kt + kab[0], k1 = kt + kab[1], k2 = kt + kab[2], k3 = kt + kab[3];
+    const unsigned v0 = vt + kab[0], v1 = vt + kab[1], v2 = vt + kab[2], v3 = vt + kab[3];
+    const unsigned t00 = kt + ktb[0][0], t01 = kt + ktb[0][1], t10 = kt + ktb[1][0], t11 = kt + ktb[1][1];
+    auto half = [&](auto hf_tag) {
+      constexpr int hf = decltype(hf_tag)::value;
+      // register budget (168 at three waves per SIMD): at most 48 transient registers beside Q', dO, -lse2 and dQ -- the K rows die into S
+      // before the V rows are requested, the K^T fragments are requested once S is the only other tile alive
+      bf16x8_t kf[4], vf[4];
+      A64_RD128(kf[0], k0, hf * 4096); A64_RD128(kf[1], k1, hf * 4096); A64_RD128(kf[2], k2, hf * 4096); A64_RD128(kf[3], k3, hf * 4096);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
+      __builtin_amdgcn_sched_barrier(0);
+      float16_t s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negl, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+      A64_PIN(s);
+      __builtin_amdgcn_sched_barrier(0);
+      A64_RD128(vf[0], v0, hf * 4096); A64_RD128(vf[1], v1, hf * 4096); A64_RD128(vf[2], v2, hf * 4096); A64_RD128(vf[3], v3, hf * 4096);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
+      __builtin_amdgcn_sched_barrier(0);
+      float16_t dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof[ks], dp, 0, 0, 0);
+      A64_PIN(dp);
+      __builtin_amdgcn_sched_barrier(0);
+      // the K^T fragments of this half's dQ product: requested now, covered by the exponentials
+      short4_t klo[2][2], khi[2][2];
+      A64_RDTR(klo[0][0], t00, (hf * 32) * 128); A64_RDTR(klo[0][1], t01, (hf * 32) * 128);
+      A64_RDTR(khi[0][0], t10, (hf * 32) * 128); A64_RDTR(khi[0][1], t11, (hf * 32) * 128);
+      A64_RDTR(klo[1][0], t00, (hf * 32 + 16) * 128); A64_RDTR(klo[1][1], t01, (hf * 32 + 16) * 128);
+      A64_RDTR(khi[1][0], t10, (hf * 32 + 16) * 128); A64_RDTR(khi[1][1], t11, (hf * 32 + 16) * 128);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = EXP2(s[r]) * (dp[r] - dlt);             // (the softmax scale multiplies dQ once, after the loop)
+      if constexpr (MASKED) {   // keys beyond Lk exist only in the last tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = (t * 64 + hf * 32 + acc_row(r, h5)) < p.Lk ? dp[r] : 0.f;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(klo[0][0]), "+v"(klo[0][1]), "+v"(khi[0][0]), "+v"(khi[0][1]), "+v"(klo[1][0]), "+v"(klo[1][1]), "+v"(khi[1][0]), "+v"(khi[1][1]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t dsf = pack_frag(dp, s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(klo[s2][dt], khi[s2][dt]), dsf, dq[dt], 0, 0, 0);
+      }
+    };
+    half(std::integral_constant<int, 0>{});
+    half(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    so += STAGE; if (so == 3 * STAGE) so = 0;
+    sn += STAGE; if (sn == 3 * STAGE) sn = 0;
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    const int nwhole = p.Lk / 64;
+    int t = 0;
+    for (; t + 2 < nwhole; ++t) iteration(t, F{}, I2{});
+    for (; t < nwhole; ++t) iteration(t, F{}, I1{});
+    for (; t < nt; ++t) iteration(t, T{}, I1{});
+  }
+
+  if (q < p.Lq) {
+    bf16_t* dQb = p.dQ + (long)b * p.bdq + (long)q * p.sdq + (long)hd * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        uint2_t a;
+        a.x = pack2bf(dq[dt][4 * r4 + 0] * p.scale, dq[dt][4 * r4 + 1] * p.scale);
+        a.y = pack2bf(dq[dt][4 * r4 + 2] * p.scale, dq[dt][4 * r4 + 3] * p.scale);
+        *(uint2_t*)(dQb + dt * 32 + 8 * r4 + 4 * h5) = a;
+      }
+  }
+}
+
+// ---- backward, dK / dV (head dim 64) ----
+// Keys on lanes (K, V fragments of the wave's 32 keys live in registers), 32-query tiles of Q' (the dQ kernel's copy: [B][H][Lq][64], bf16
+// (Q * scale * log2 e)), of dO and of the two row constants by LDS-DMA into a ring of three stages.  S[q][key] and dP[q][key] have the
+// query on the accumulator ROW: -LSE * log2(e) and -delta are read from the stage straight into the accumulator registers the chains
+// then start from (C = D), so again p = exp2(S'), dS = p * dP' and nothing else.  dK = ln 2 * dS^T Q' (= scale * dS^T Q).
+template <int NW = 4>
+__global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dkdv_kernel(const AttnParams p) {
+  constexpr int TILE = 32 * 128, STAGE = 2 * TILE + 256;   // Q' tile, dO tile, [32] -lse2, [32] -delta
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, kl = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int kb = blockIdx.x / p.qsplit, qs = blockIdx.x - kb * p.qsplit;
+  const int k0 = kb * (NW * 32) + wave * 32;
+
+  const Attn64Ws ws = Attn64Ws::make(p.B, p.H, p.Lq);
+  const long head_row = ((long)b * p.H + hd) * p.Lq;
+  const bf16_t* Qs = (const bf16_t*)(p.delta + ws.qs) + head_row * 64;
+  const float* nl2 = p.delta + ws.nlse2 + head_row;
+  const float* ndl = p.delta + ws.ndelta + head_row;
+  const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * 64;
+  const bf16_t* Vb = p.V + (long)b * p.bv + (long)hd * 64;
+  const bf16_t* dOb = p.dO + (long)b * p.bdo + (long)hd * 64;
+  // this workgroup's slice of the query tiles
+  const int nt_all = (p.Lq + 31) / 32;
+  const int per = (nt_all + p.qsplit - 1) / p.qsplit;
+  const int t_lo = qs * per, t_hi = min(nt_all, t_lo + per);
+  const int nt = max(t_hi - t_lo, 0);
+
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4_t zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+    if (k0 + kl < p.Lk) {
+      zk = *(const uint4_t*)(Kb + (long)(k0 + kl) * p.sk + 16 * ks + 8 * h5);
+      zv = *(const uint4_t*)(Vb + (long)(k0 + kl) * p.sv + 16 * ks + 8 * h5);
+    }
+    kf[ks] = __builtin_bit_cast(bf16x8_t, zk);
+    vf[ks] = __builtin_bit_cast(bf16x8_t, zv);
+  }
+  // DMA of query tile `qt` (first row q0) into stage `img`: one piece of Q', one of dO per wave; wave 0 adds the 256 bytes of row constants
+  Dma64<32, NW> dq_, do_;
+  dq_.init(64, wave, lane);
+  do_.init(p.sdo, wave, lane);
+  auto issue_tile = [&](int q0, char* img, bool whole) {
+    if (whole) {
+      dq_.issue_whole(Qs + (long)q0 * 64, img, wave);
+      do_.issue_whole(dOb + (long)q0 * p.sdo, img + TILE, wave);
+    } else {
+      dq_.issue(Qs, 64, q0, p.Lq, img, wave, lane);
+      do_.issue(dOb, p.sdo, q0, p.Lq, img + TILE, wave, lane);
+    }
+    if (wave == 0) {
+      const int qi = min(q0 + (lane & 31), p.Lq - 1);          // (rows past Lq are masked in the loop)
+      const float* src = (lane < 32 ? nl2 : ndl) + qi;
+      __builtin_amdgcn_global_load_lds((att_gptr)src, (att_lptr)(img + 2 * TILE), 4, 0, 0);
+    }
+  };
+  if (nt > 0) issue_tile(t_lo * 32, smem, false);
+  if (nt > 1) issue_tile((t_lo + 1) * 32, smem + STAGE, false);
+
+  float16_t dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+
+  unsigned rab[4], tab[2][2];
+  a64_row_bases(rab, lane);
+  a64_tr_bases(tab, lane);
+  const unsigned smem_a = (unsigned)(size_t)(lds_c)smem;
+  const unsigned stat_a = (unsigned)(2 * TILE + 16 * h5);     // this lane's first row constant: rows 8j + 4 h5 + (0..3), j = 0..3
+  // counted waits: a wave has 2 (wave 0: 3) DMA instructions per tile in flight
+#define DKV_WAIT_ONE_TILE() do { if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } while (0)
+  if (nt > 1) DKV_WAIT_ONE_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  unsigned so = 0, sn = 2 * STAGE;
+  // MASKED: the tile reaches past Lq (the last one).  ISSUE: 2 = tile t + 2 lies wholly inside Q / dO, 1 = it may not (or may not exist)
+  auto iteration = [&](int t, auto masked_tag, auto issue_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr int ISSUE = decltype(issue_tag)::value;
+    const bool more = ISSUE == 2 || t + 2 < nt;
+    if constexpr (ISSUE == 2) issue_tile((t_lo + t + 2) * 32, smem + sn, true);
+    else if (more) issue_tile((t_lo + t + 2) * 32, smem + sn, false);
+    const unsigned qt = smem_a + so, dot = qt + TILE, st = qt + stat_a;
+    // register budget (168 at three waves per SIMD): K, V, dK, dV take 96; at most 48 transient registers at any point
+    float16_t s, dp;
+    {
+      float4_t c0, c1, c2, c3;
+      bf16x8_t qr[4];
+      A64_RD128(c0, st, 0); A64_RD128(c1, st, 32); A64_RD128(c2, st, 64); A64_RD128(c3, st, 96);
+      A64_RD128(qr[0], qt + rab[0], 0); A64_RD128(qr[1], qt + rab[1], 0); A64_RD128(qr[2], qt + rab[2], 0); A64_RD128(qr[3], qt + rab[3], 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      s = __builtin_shufflevector(__builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(c2, c3, 0, 1, 2, 3, 4, 5, 6, 7),
+                                  0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[ks], kf[ks], s, 0, 0, 0);
+      A64_PIN(s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      float4_t e0, e1, e2, e3;
+      bf16x8_t dr[4];
+      A64_RD128(e0, st, 128); A64_RD128(e1, st, 160); A64_RD128(e2, st, 192); A64_RD128(e3, st, 224);
+      A64_RD128(dr[0], dot + rab[0], 0); A64_RD128(dr[1], dot + rab[1], 0); A64_RD128(dr[2], dot + rab[2], 0); A64_RD128(dr[3], dot + rab[3], 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      dp = __builtin_shufflevector(__builtin_shufflevector(e0, e1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(e2, e3, 0, 1, 2, 3, 4, 5, 6, 7),
+                                   0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dr[ks], vf[ks], dp, 0, 0, 0);
+      A64_PIN(dp);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // dO^T fragments of the dV product: requested now, covered by the exponentials
+    short4_t olo[2][2], ohi[2][2];
+    {
+      const unsigned o00 = dot + tab[0][0], o01 = dot + tab[0][1], o10 = dot + tab[1][0], o11 = dot + tab[1][1];
+      A64_RDTR(olo[0][0], o00, 0); A64_RDTR(olo[0][1], o01, 0); A64_RDTR(ohi[0][0], o10, 0); A64_RDTR(ohi[0][1], o11, 0);
+      A64_RDTR(olo[1][0], o00, 2048); A64_RDTR(olo[1][1], o01, 2048); A64_RDTR(ohi[1][0], o10, 2048); A64_RDTR(ohi[1][1], o11, 2048);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = EXP2(s[r]);
+      dp[r] *= s[r];                                  // (the softmax scale multiplies dK once, after the loop)
+    }
+    if constexpr (MASKED) {   // query rows past Lq (clamped copies of the last row) contribute nothing
+      const int q0 = (t_lo + t) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = q0 + acc_row(r, h5) < p.Lq;
+        s[r] = ok ? s[r] : 0.f;
+        dp[r] = ok ? dp[r] : 0.f;
+      }
+    }
+    bf16x8_t pf[2], dsf[2];
+    pf[0] = pack_frag(s, 0); pf[1] = pack_frag(s, 1);
+    dsf[0] = pack_frag(dp, 0); dsf[1] = pack_frag(dp, 1);
+    A64_PIN(pf[0]); A64_PIN(pf[1]); A64_PIN(dsf[0]); A64_PIN(dsf[1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // Q'^T fragments of the dK product: requested in front of the dV MFMAs, which cover them
+    short4_t qlo[2][2], qhi[2][2];
+    {
+      const unsigned q00 = qt + tab[0][0], q01 = qt + tab[0][1], q10 = qt + tab[1][0], q11 = qt + tab[1][1];
+      A64_RDTR(qlo[0][0], q00, 0); A64_RDTR(qlo[0][1], q01, 0); A64_RDTR(qhi[0][0], q10, 0); A64_RDTR(qhi[0][1], q11, 0);
+      A64_RDTR(qlo[1][0], q00, 2048); A64_RDTR(qlo[1][1], q01, 2048); A64_RDTR(qhi[1][0], q10, 2048); A64_RDTR(qhi[1][1], q11, 2048);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(olo[s2][dt], ohi[s2][dt]), pf[s2], dv[dt], 0, 0, 0);
+    A64_PIN(dv[0]); A64_PIN(dv[1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(qlo[s2][dt], qhi[s2][dt]), dsf[s2], dk[dt], 0, 0, 0);
+    A64_PIN(dk[0]); A64_PIN(dk[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) DKV_WAIT_ONE_TILE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    so += STAGE; if (so == 3 * STAGE) so = 0;
+    sn += STAGE; if (sn == 3 * STAGE) sn = 0;
+  };
+#undef DKV_WAIT_ONE_TILE
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    // tiles (t_lo + t) with (t_lo + t + 1) * 32 <= Lq are whole; the prefetched tile t + 2 is whole while (t_lo + t + 3) * 32 <= Lq
+    const int nwhole = min(nt, p.Lq / 32 - t_lo);
+    int t = 0;
+    for (; t + 2 < nwhole; ++t) iteration(t, F{}, I2{});
+    for (; t < nwhole; ++t) iteration(t, F{}, I1{});
+    for (; t < nt; ++t) iteration(t, T{}, I1{});
+  }
+
+  const float ln2 = 0.6931471805599453f;
+  const int key = k0 + kl;
+  if (key < p.Lk) {
+    if (p.qsplit > 1) {
+      // fp32 partials [qs][0=dK,1=dV][b][key][H*D]; summed in a fixed order by attn_dkv_reduce_kernel
+      const long hd_all = (long)p.H * 64;
+      const long plane = (long)p.B * p.Lk * hd_all;
+      float* pk = p.dkv_part + ((long)qs * 2) * plane + ((long)b * p.Lk + key) * hd_all + (long)hd * 64;
+      float* pv = pk + plane;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int d = dt * 32 + 8 * r4 + 4 * h5;
+          *(float4_t*)(pk + d) = (float4_t){dk[dt][4 * r4 + 0] * ln2, dk[dt][4 * r4 + 1] * ln2, dk[dt][4 * r4 + 2] * ln2, dk[dt][4 * r4 + 3] * ln2};
+          *(float4_t*)(pv + d) = (float4_t){dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1], dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]};
+        }
+      return;
+    }
+    bf16_t* dKb = p.dK + (long)b * p.bdk + (long)key * p.sdk + (long)hd * 64;
+    bf16_t* dVb = p.dV + (long)b * p.bdv + (long)key * p.sdv + (long)hd * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = dt * 32 + 8 * r4 + 4 * h5;
+        uint2_t a, v;
+        a.x = pack2bf(dk[dt][4 * r4 + 0] * ln2, dk[dt][4 * r4 + 1] * ln2);
+        a.y = pack2bf(dk[dt][4 * r4 + 2] * ln2, dk[dt][4 * r4 + 3] * ln2);
+        v.x = pack2bf(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
+        v.y = pack2bf(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
+        *(uint2_t*)(dKb + d) = a;
+        *(uint2_t*)(dVb + d) = v;
+      }
+  }
+}
+
+// ================================================================================================
 // backward: dK, dV.  Workgroup = 128 keys (4 waves x 32 keys on lanes), loops over 32-query tiles.
 // ================================================================================================
 template <int DP, int NW = 4>   // NW waves x 32 rows per workgroup (2: twice the workgroups for short sequences)
@@ -695,6 +1394,11 @@ static int attn_dp(int D) { return D <= 64 ? 64 : (D <= 96 ? 96 : 160); }
 // measured SLOWER: forward 72 vs 65 us, backward 200 vs 181 us, twice the K/V tile loads per query row and half the waves sharing a tile.)
 static constexpr int ATTN_NW = 4;
 
+// NK_ATTN64=0: the generic kernels for head dim 64 as well (A/B switch of round 4; read per call)
+static bool attn64_enabled() {
+  const char* e = getenv("NK_ATTN64");
+  return !e || atoi(e) != 0;
+}
 template <typename K>
 static void set_smem(K kern, int bytes) {
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -722,6 +1426,12 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
     set_smem(attn_fwd_kernel<DP_, ATTN_NW>, smem);                                                \
     hipLaunchKernelGGL((attn_fwd_kernel<DP_, ATTN_NW>), grid, dim3(ATTN_NW * 64), smem, stream, p); \
   }
+  if (d->D == 64 && attn64_enabled()) {
+    const int smem64 = 3 * 2 * 64 * 128;
+    set_smem(attn64_fwd_kernel<ATTN_NW>, smem64);
+    hipLaunchKernelGGL((attn64_fwd_kernel<ATTN_NW>), grid, dim3(ATTN_NW * 64), smem64, stream, p);
+    return nk_check_launch("attn64_fwd_kernel");
+  }
   FWD_CASE(64) FWD_CASE(96) FWD_CASE(160)
 #undef FWD_CASE
   return nk_check_launch("attn_fwd_kernel");
@@ -737,9 +1447,10 @@ static int attn_qsplit(const NkAttnDesc* d) {
   return s;
 }
 extern "C" long nk_attention_bwd_ws_floats(const NkAttnDesc* d) {
-  long delta = (long)d->B * d->H * d->Lq;
   int s = attn_qsplit(d);
   long part = s > 1 ? (long)s * 2 * d->B * d->Lk * d->H * d->D : 0;
+  if (d->D == 64) return Attn64Ws::make(d->B, d->H, d->Lq).part + part + 64;     // -delta, -lse2, Q' (whichever kernels run)
+  long delta = (long)d->B * d->H * d->Lq;
   return delta + part + 64;
 }
 
@@ -762,6 +1473,36 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   p.sdq = d->sdq; p.sdk = d->sdk; p.sdv = d->sdv; p.sdo = d->sdo;
   p.bdq = d->bdq; p.bdk = d->bdk; p.bdv = d->bdv; p.bdo = d->bdo;
   p.scale = d->scale;
+  if (d->D == 64 && attn64_enabled()) {
+    // head dim 64: the dQ kernel (which also writes -delta, -lse2 and Q' into the workspace), then dK / dV
+    NK_CHECK_ARG(((uintptr_t)delta_ws & 15) == 0);
+    const Attn64Ws w = Attn64Ws::make(d->B, d->H, d->Lq);
+    constexpr int nw = ATTN_NW;
+    {
+      dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
+      const int smem = 3 * 2 * 64 * 128;
+      set_smem(attn64_bwd_dq_kernel<ATTN_NW>, smem);
+      hipLaunchKernelGGL((attn64_bwd_dq_kernel<ATTN_NW>), grid, dim3(nw * 64), smem, stream, p);
+      if (int e = nk_check_launch("attn64_bwd_dq_kernel")) return e;
+    }
+    p.qsplit = attn_qsplit(d);
+    p.dkv_part = p.qsplit > 1 ? delta_ws + w.part : nullptr;
+    {
+      dim3 grid(((d->Lk + nw * 32 - 1) / (nw * 32)) * p.qsplit, d->H, d->B);
+      const int smem = 3 * (2 * 32 * 128 + 256);
+      set_smem(attn64_bwd_dkdv_kernel<ATTN_NW>, smem);
+      hipLaunchKernelGGL((attn64_bwd_dkdv_kernel<ATTN_NW>), grid, dim3(nw * 64), smem, stream, p);
+      if (int e = nk_check_launch("attn64_bwd_dkdv_kernel")) return e;
+    }
+    if (p.qsplit > 1) {
+      long total = (long)d->B * d->Lk * ((long)d->H * d->D / 4);
+      long blocks = (total + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, p);
+      if (int e = nk_check_launch("attn_dkv_reduce_kernel")) return e;
+    }
+    return NK_OK;
+  }
   // order: dQ kernel first (it also produces delta = rowsum(dO * O) for the dK / dV kernel), then dK / dV
   const int dp = attn_dp(d->D);
   {

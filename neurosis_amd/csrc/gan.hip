@@ -219,6 +219,23 @@ extern "C" int nk_batchnorm_fwd(const void* x, const float* gamma, const float* 
   return nk_check_launch("bn_apply");
 }
 
+// nn.BatchNorm2d in evaluation mode (+ the LeakyReLU behind it): the running statistics as a per-channel affine map.
+// ws: C fp32 elements (rstd of the running variance).
+__global__ void bn_eval_rstd_kernel(const float* __restrict__ running_var, float eps, float* __restrict__ rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) rstd[c] = rsqrtf(running_var[c] + eps);
+}
+extern "C" int nk_batchnorm_eval(const void* x, const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, void* y, float* ws, long M, int C, float eps, float slope, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NK_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && ws && M > 0 && C > 0 && (C & 7) == 0 && slope > 0.f);
+  hipLaunchKernelGGL(bn_eval_rstd_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, running_var, eps, ws, C);
+  if (int e = nk_check_launch("bn_eval_rstd")) return e;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, stream, (const bf16_t*)x, running_mean, ws, gamma, beta,
+                     (bf16_t*)y, M, C, slope);
+  return nk_check_launch("bn_apply (eval)");
+}
+
 extern "C" int nk_batchnorm_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, float* dgamma, float* dbeta, float* ws, long M, int C, float slope,
                                 int accumulate, void* stream_) {

@@ -1648,7 +1648,11 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
     return out_f32 ? launch_g2<OP_MC, OP_MC, 1>(p, stream) : launch_g2<OP_MC, OP_MC, 0>(p, stream);
   }
 
-  if (use_sk(p, out_f32)) {
+  // (a launch that carries a fused bias gradient never goes to stream-K, whatever NK_GEMM_SK says: that kernel has no ones-MFMA row sum,
+  // and the gradient would silently stay unwritten)
+  bool has_dbias = p.dbias != nullptr;
+  for (int z = 0; z < p.nbatch && z < NK_MAX_BATCH; ++z) has_dbias = has_dbias || p.dbias_b[z] != nullptr;
+  if (!has_dbias && use_sk(p, out_f32)) {
     const long ntm_ = (p.M + BM - 1) / BM, ntn_ = (p.N + BN - 1) / BN, nk_ = (p.K + BK - 1) / BK;
     if (ntm_ * ntn_ * (p.nbatch ? p.nbatch : 1) * nk_ < (1l << 22)) {   // share arithmetic is 32-bit: W * grid < 2^31
       if (p.accumulate == 2) p.accumulate = 0;     // "destination known zero" only matters to the atomic split-K path

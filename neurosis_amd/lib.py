@@ -77,6 +77,7 @@ SIGNATURES: dict[str, list] = {
     "nk_lpips_layer_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "nk_batchnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, f32, vp],
     "nk_batchnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
+    "nk_batchnorm_eval": [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
     "nk_silu_bwd": [vp, vp, vp, i64, vp],
     "nk_add": [vp, vp, vp, i64, vp],
     "nk_cat_channels": [vp, vp, vp, i64, i32, i32, vp],

@@ -71,10 +71,9 @@ class NLayerDiscriminator(nn.Module):
                     nxt.num_batches_tracked += 1
                     t, b_bn = ops.batchnorm_fwd(h.t, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var, nxt.eps, nxt.momentum, SLOPE)
                 else:
-                    # evaluation (logging): the running statistics as a per-channel affine map -- a handful of [M, C] torch ops, no
-                    # gradients (nothing trains through an eval-mode discriminator)
-                    scale = nxt.weight.detach() * torch.rsqrt(nxt.running_var + nxt.eps)
-                    t = torch.nn.functional.leaky_relu(h.t.float() * scale + (nxt.bias.detach() - nxt.running_mean * scale), SLOPE).to(h.t.dtype)
+                    # evaluation (logging): the running statistics as a per-channel affine map, one HIP launch; no gradients (nothing
+                    # trains through an eval-mode discriminator)
+                    t = ops.batchnorm_eval(h.t, nxt.weight.detach(), nxt.bias.detach(), nxt.running_mean, nxt.running_var, nxt.eps, SLOPE)
                     b_bn = _no_backward
                 h = Img(t, h.N, h.H, h.W)
                 tape.append(b_bn)

@@ -801,6 +801,18 @@ def batchnorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Optiona
     return y, bwd
 
 
+def batchnorm_eval(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Tensor, running_var: Tensor, eps: float = 1e-5, slope: float = 1.0) -> Tensor:
+    """nn.BatchNorm2d in evaluation mode on a token matrix [M, C] (running statistics), with the following LeakyReLU fused in."""
+    _check2d(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("batchnorm: x must be dense")
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    call("nk_batchnorm_eval", x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), y.data_ptr(),
+         _ws(Cc + 64, x.device).data_ptr(), M, Cc, float(eps), float(slope), _stream())
+    return y
+
+
 def silu_fwd(x: Tensor):
     y = torch.empty_like(x)
     call("nk_silu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), _stream())

@@ -93,6 +93,22 @@ def test_linear_wgrad_with_fused_bias_gradient(ops, M, N, K):
     assert_close(dw, 2 * (dy.t() @ x), TOL_F32, "wgrad accumulate")
 
 
+@pytest.mark.parametrize("sk_mode", ["1", "2", "3"])
+def test_fused_bias_gradient_survives_the_stream_k_switch(ops, sk_mode, monkeypatch):
+    """NK_GEMM_SK=1|2|3 routes fp32-output weight gradients to the stream-K kernel, which has no bias row sum: a launch that carries a
+    fused bias gradient must stay on a kernel that writes it (round-3 advisor finding: the gradient was silently left unwritten)."""
+    M, N, K = 4096, 1280, 640
+    dy, x = rnd(M, N), rnd(M, K)
+    monkeypatch.setenv("NK_GEMM_SK", sk_mode)        # read per call by nk_gemm_dispatch
+    dw, db = torch.full((N, K), 7.0, device="cuda"), torch.full((N,), -3.0, device="cuda")
+    ops.gemm_tn_f32(dev(dy), dev(x), dw, False, dbias=db)
+    assert_close(dw, dy.t() @ x, TOL_F32, "wgrad under NK_GEMM_SK")
+    assert_close(db, dy.sum(0), TOL_F32, "fused bias gradient under NK_GEMM_SK")
+    ref = torch.zeros(N, device="cuda")
+    ops.colsum(dev(dy), ref, False)
+    assert_close(db, ref.cpu(), TOL_F32, "fused bias gradient vs colsum")
+
+
 @pytest.mark.parametrize("M,N,K,count", [(1024, 256, 384, 3), (64, 128, 128, 8), (4096, 1280, 1280, 3)])
 def test_linear_wgrad_batched(ops, M, N, K, count, monkeypatch):
     """`count` same-shape weight gradients in one launch (blockIdx.z) == the launches one by one; also through the queue."""
@@ -341,6 +357,53 @@ def test_attention_fused_qkv_slices_and_spike(ops):
     g = dev(qkv)
     o, _ = ops.attention_fwd(g[:, :H * D], g[:, H * D:2 * H * D], g[:, 2 * H * D:], B, H, D)
     assert_close(o, ref, TOL_BF16, "attn fused-slices")
+
+
+def _rescale_path_inputs(w_jump, w_keys):
+    """Scores that force the data-dependent paths of the head-dim-64 forward: a first tile far BELOW what follows for the u-rows (m must
+    rise), u-rows (0, 4, ... of every 32-row wave block) whose scores jump by ~4, ~9 and ~17 log2 units at tiles 2, 4 and 7, w-rows
+    (2, 10, ...) that jump by `w_jump` natural units on the keys `w_keys`, and rows that never jump -- all inside one wave block, so a
+    wave-uniform decision covers rows that need it and rows that do not."""
+    B, H, L, D = 1, 2, 512, 64
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B * L, H, D, generator=g) * 0.5
+    k = torch.randn(B * L, H, D, generator=g) * 0.5
+    v = torch.randn(B * L, H * D, generator=g)
+    # the score of (query, key) rises by  q[3] * k[3] / 8  natural units: the QUERIES carry 32 along dim 3 / 17 and the keys a quarter of the
+    # jump (gradients through a large key component against a bf16 dS are dominated by cancellation in any bf16 kernel: with the roles
+    # swapped -- queries 8, keys up to 12 -- the generic kernels are 0.2 of the largest dq off)
+    q[:, :, 3] = 0.0; q[:, :, 17] = 0.0
+    k[:, :, 3] = 0.0; k[:, :, 17] = 0.0
+    q[0::4, :, 3] = 32.0
+    q[2::8, :, 17] = 32.0
+    k[:64, :, 3] = -1.5                    # first tile 6 natural units below for the u-rows
+    k[130:134, :, 3] = 0.7                 # ~ +4 log2 units over the running reference at tile 2: deferred, p up to ~2^11
+    k[260:262, :, 3] = 1.55                # ~ +9 log2 units at tile 4
+    k[w_keys, :, 17] = w_jump / 4
+    k[470, :, 3] = 3.0                     # a late jump (+12 natural units) for the u-rows in the last whole tile
+    return B, H, L, D, bf16_round(q.reshape(B * L, H * D)), bf16_round(k.reshape(B * L, H * D)), bf16_round(v)
+
+
+def test_attention_d64_deferred_rescale_paths(ops):
+    """The head-dim-64 forward leaves its reference point m alone while a tile's row sums stay under 2^13 and otherwise recomputes the tile
+    against a new maximum (csrc/attention.hip, attn64_fwd_kernel).  Both paths are data-dependent and rare on random data, so the inputs
+    force them (see _rescale_path_inputs).  Part 1: 32 keys ~9 log2 units up (their SUM crosses the threshold although no single p does),
+    forward and backward against fp32 -- the backward consumes the forward's log-sum-exp, so a wrong m / l pairing shows in every gradient.
+    Part 2: three keys 28 natural units (40 log2 units) up -- exp2 overflows to +inf in the optimistic pass and the tile must be recomputed."""
+    for w_jump, w_keys, tol_dq, tol_dk in ((6.2, slice(384, 416), 7e-2, 5e-2), (28.0, slice(400, 403), 3e-2, TOL_BF16)):
+        # (gradient tolerances of the first input: a bf16 dS against |q| = 32 -- the generic kernels measure 4.9e-2 / 2.6e-2 on it, the
+        # head-dim-64 ones 4.9e-2 / 3.3e-2: tools/debug_attn.py)
+        B, H, L, D, q, k, v = _rescale_path_inputs(w_jump, w_keys)
+        qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+        ref = _attn_ref(qr, kr, vr, B, H, D)
+        do = rnd(B * L, H * D, seed=9)
+        ref.backward(do)
+        o, bwd = ops.attention_fwd(dev(q), dev(k), dev(v), B, H, D)
+        assert_close(o, ref, TOL_BF16, f"attn64 rescale paths fwd ({w_jump})")
+        dq, dk, dv = bwd(dev(do))
+        assert_close(dq, qr.grad, tol_dq, f"attn64 rescale paths dq ({w_jump})")
+        assert_close(dk, kr.grad, tol_dk, f"attn64 rescale paths dk ({w_jump})")
+        assert_close(dv, vr.grad, TOL_BF16, f"attn64 rescale paths dv ({w_jump})")
 
 
 def test_attention_unfused_d512(ops):
