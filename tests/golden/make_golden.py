@@ -930,6 +930,79 @@ def engine_case(nd, nmodel):
     print(f"engine: latents {tuple(latents.shape)} loss_mean={float(loss_mean):.6f} logged={ {k: float(v) for k, v in logged.items()} } state_dict keys={len(sd_keys)}")
 
 
+# Single blocks at REAL SDXL / SD-VAE widths and small spatial size ("single-op vectors at real channel counts"): the tiny
+# networks above run every HIP kernel at model_channels = 32 / head dim 16; these pin head dim 64, the 160-wide GEMM tiles, the halo
+# convolution's 64-channel slabs, 640 / 1280-wide LayerNorm + GEGLU and the 512-channel VAE attention to the reference's own classes.
+BLOCK_CASES = {
+    # name: (kind, constructor kwargs, input shapes)
+    "resblock_320_640": ("resblock", dict(channels=320, emb_channels=1280, dropout=0.0, out_channels=640, use_checkpoint=False), dict(x=(1, 320, 16, 16), emb=(1, 1280))),
+    "tblock_640": ("tblock", dict(dim=640, n_heads=10, d_head=64, context_dim=2048, gated_ff=True, checkpoint=False, attn_mode="torch-sdp"),
+                   dict(x=(1, 256, 640), context=(1, 77, 2048))),
+    "tblock_1280": ("tblock", dict(dim=1280, n_heads=20, d_head=64, context_dim=2048, gated_ff=True, checkpoint=False, attn_mode="torch-sdp"),
+                    dict(x=(1, 64, 1280), context=(1, 77, 2048))),
+    "spatial_640_depth2": ("spatial", dict(in_channels=640, n_heads=10, d_head=64, depth=2, context_dim=2048, use_linear=True, attn_type="torch-sdp", use_checkpoint=False),
+                           dict(x=(1, 640, 16, 16), context=(1, 77, 2048))),
+    "vae_resnet_128_256": ("vae_resnet", dict(in_channels=128, out_channels=256, temb_channels=0, dropout=0.0), dict(x=(1, 128, 16, 16))),
+    "vae_attn_512": ("vae_attn", dict(in_channels=512), dict(x=(1, 512, 16, 16))),
+}
+BLOCK_SAMPLE_ROWS = 8       # rows of every >= 2-D weight gradient that are stored (the rest is pinned through its norm)
+
+
+def block_inputs(name: str, shapes: dict) -> dict:
+    """bf16-exact inputs, a pure function of (case name, tensor name, shape): the tests rebuild them instead of storing them"""
+    out = {}
+    for k, shp in shapes.items():
+        g = torch.Generator().manual_seed(zlib.crc32(f"{name}/{k}".encode()) & 0x7FFFFFFF)
+        out[k] = torch.randn(*shp, generator=g).to(torch.bfloat16).to(torch.float32)
+    return out
+
+
+def block_upstream(name: str, shape) -> torch.Tensor:
+    g = torch.Generator().manual_seed(zlib.crc32(f"{name}/dy".encode()) & 0x7FFFFFFF)
+    return torch.randn(*shape, generator=g).to(torch.bfloat16).to(torch.float32)
+
+
+def blocks_case(nmodel):
+    """outputs, input gradients, every parameter's gradient norm and the first rows of every weight gradient of the reference's ResBlock
+    (openaimodel.py:200-342), BasicTransformerBlock / SpatialTransformer (attention.py:420-511, 567-667), VAE ResnetBlock and AttnBlock
+    (model.py:85-134, 144-173) at SDXL widths; written as .safetensors (no pickle)."""
+    from safetensors.torch import save_file
+
+    from neurosis.modules.attention import BasicTransformerBlock, SpatialTransformer
+    from neurosis.modules.diffusion.openaimodel import ResBlock
+
+    ctor = {"resblock": ResBlock, "tblock": BasicTransformerBlock, "spatial": SpatialTransformer, "vae_resnet": nmodel.ResnetBlock, "vae_attn": nmodel.AttnBlock}
+    tensors, key_shapes = {}, {}
+    for name, (kind, kw, in_shapes) in BLOCK_CASES.items():
+        blk = ctor[kind](**kw).eval()
+        shapes = {k: list(v.shape) for k, v in blk.state_dict().items()}
+        blk.load_state_dict(synth_state_dict(shapes))
+        ins = {k: v.clone().requires_grad_(True) for k, v in block_inputs(name, in_shapes).items()}
+        if kind == "resblock":
+            out = blk(ins["x"], ins["emb"])
+        elif kind in ("tblock", "spatial"):
+            out = blk(ins["x"], context=ins["context"])
+        elif kind == "vae_resnet":
+            out = blk(ins["x"], None)
+        else:
+            out = blk(ins["x"])
+        dy = block_upstream(name, out.shape)
+        out.backward(dy)
+        tensors[f"{name}/out"] = out.detach().contiguous()
+        for k, v in ins.items():
+            tensors[f"{name}/d_{k}"] = v.grad.detach().contiguous()
+        names = [k for k, _ in blk.named_parameters()]
+        tensors[f"{name}/grad_norms"] = torch.tensor([float(p.grad.norm()) for _, p in blk.named_parameters()])
+        for k, p in blk.named_parameters():
+            g = p.grad.detach()
+            tensors[f"{name}/g/{k}"] = (g[:BLOCK_SAMPLE_ROWS] if g.dim() >= 2 else g).contiguous()
+        key_shapes[name] = dict(shapes=shapes, params=names)
+        print(f"block {name}: out {tuple(out.shape)} |out| {float(out.abs().mean()):.4f} params {sum(p.numel() for p in blk.parameters())}")
+    save_file(tensors, str(HERE / "blocks_real_width.safetensors"))
+    (HERE / "blocks_real_width_keys.json").write_text(json.dumps(key_shapes, indent=0))
+    print("blocks fixture bytes:", (HERE / "blocks_real_width.safetensors").stat().st_size)
+
+
 def config_case():
     """The `model:` tree of the reference's example configs as DATA: for every node that names a class, where it sits, its
     class_path, the names of its init_args (and their values when they are plain scalars / lists of scalars), and whether that
@@ -979,7 +1052,7 @@ def config_case():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes", "lpips", "loss_class", "engine", "config"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes", "lpips", "loss_class", "engine", "config", "blocks"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -1014,3 +1087,5 @@ if __name__ == "__main__":
         engine_case(nd, nmodel)
     if "config" in which:
         config_case()
+    if "blocks" in which:
+        blocks_case(nmodel)

@@ -13,7 +13,7 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters
 
 def rb(*shape): return torch.randn(*shape, device="cuda").to(torch.bfloat16)
-shapes = [(4, 20, 1024, 1024), (8, 20, 1024, 1024), (16, 20, 1024, 1024), (4, 10, 4096, 4096), (2, 10, 4096, 4096), (1, 10, 4096, 4096)]
+shapes = [(4, 20, 1024, 77), (4, 10, 4096, 77), (4, 20, 1024, 1024), (8, 20, 1024, 1024), (16, 20, 1024, 1024), (4, 10, 4096, 4096), (2, 10, 4096, 4096), (1, 10, 4096, 4096)]
 for (B, Hh, Lq, Lk) in shapes:
     D = 64
     q, k, v = rb(B * Lq, Hh * D), rb(B * Lk, Hh * D), rb(B * Lk, Hh * D)
