@@ -310,7 +310,8 @@ int nk_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, lo
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor Adafactor on the flat buffers.  Replaces Adafactor.step,
  * reference optimizers/adafactor.py:162-255 (_get_lr :133-147, _rms :150-151, _approx_sq_grad :154-159): the per-tensor
- * Python loop becomes five launches per chunk of consecutive tensors.  `tensors` / `items` are device tables built by the
+ * Python loop becomes three launches per chunk of consecutive tensors (statistics, update RMS of the matrices, apply; the per-strip and
+ * per-tensor finalisations ride in the last block of each pass to finish).  `tensors` / `items` are device tables built by the
  * host (layout: neurosis_amd/csrc/optim.hip NkAfTensor / NkAfItem; nk_adafactor_tensor_bytes() guards the mirror).
  * nk_adafactor_init fills the per-item partial sums of p^2 once; nk_adafactor_chunk performs one step for tensors
  * [tensor_lo, tensor_hi) = items [item_lo, item_hi).  beta2t = 1 - step^decay_rate and rel_step are host scalars. */
@@ -321,7 +322,9 @@ typedef struct NkAdafactorArgs {
   int item_lo, item_hi, tensor_lo, tensor_hi;
   float beta2t, eps1, eps2, clip_threshold, rel_step, weight_decay, grad_scale;
   int scale_parameter;
-  const void* fin_items; int fin_lo, fin_hi;   /* finalize work list of the chunk's matrices (empty range: none) */
+  unsigned* counters;   /* "blocks done" counters, one range per tensor (NkAfTensor.cnt0); all zero before a step, all zero after it */
+  int has_matrix;       /* the chunk holds at least one 2-D tensor (the update-RMS pass of the matrices is launched) */
+  int reserved;
 } NkAdafactorArgs;
 long nk_adafactor_tensor_bytes(void);
 int nk_adafactor_init(const NkAdafactorArgs* args, void* stream);

@@ -19,7 +19,7 @@ int nk_check_launch(const char* what) {
 }
 
 extern "C" const char* nk_last_error(void) { return g_err; }
-extern "C" int nk_abi_version(void) { return 2; }
+extern "C" int nk_abi_version(void) { return 3; }
 
 // ---- backward-health word ---------------------------------------------------------------------------------------------
 #include <mutex>

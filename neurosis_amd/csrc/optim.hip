@@ -28,9 +28,11 @@ struct NkAfTensor {      // mirrored by neurosis_amd/optim.py (AF_TENSOR_DTYPE);
   int d0, d1;
   int kh, kw;
   int item0, nitems;     // this tensor's range in the item table
-  int mr0;               // matrix: first slot of its row-EMA partial sums (one per 1024 rows) in `mean_row`
+  int mr0;               // matrix: first slot of its row-EMA partial sums (one per 256-row strip) in `mean_row`
+  int cnt0;              // first of this tensor's "blocks done" counters: [0] the tensor's, matrices: [1 + tr] row strips, [1 + ntr + tc] column strips
+  int pad;
 };
-static_assert(sizeof(NkAfTensor) == 72, "mirrored by neurosis_amd/optim.py");
+static_assert(sizeof(NkAfTensor) == 80, "mirrored by neurosis_amd/optim.py");
 
 struct NkAfItem { int tensor, tr, tc, pad; };
 
@@ -39,9 +41,8 @@ struct NkAfArgs {
   const NkAfTensor* tensors; const NkAfItem* items;
   float* u2_part;      // [nitems] partial sums of u^2
   float* p2_part;      // [nitems] partial sums of p^2 after the update (read by the NEXT step's F2)
-  float* mean_row;     // per matrix: ceil(d0/1024) partial sums of the row EMA (slots mr0...)
-  const NkAfItem* fin_items;   // finalize work list: (tensor, slice of 1024 lines, 0 = rows / 1 = cols)
-  int fin_lo, fin_hi;
+  float* mean_row;     // per matrix: one partial sum of the row EMA per 256-row strip (slots mr0...)
+  unsigned* counters;  // "blocks done" counters (zero before the step; every one is back at zero when its last block has passed)
   float* scale;        // [ntensors] lr / max(1, rms(u)/clip)
   float* lr_t;         // [ntensors]
   int item_lo, item_hi, tensor_lo, tensor_hi;
@@ -175,10 +176,51 @@ __device__ __forceinline__ float af_conv_apply(const NkAfArgs& a, const NkAfTens
   return acc;
 }
 
+// "last block done": count this block in; true (for every thread of the block) in the block that completes `total`.
+// No fences: an agent-scope release / acquire writes back and invalidates the XCD's WHOLE L2 -- with every block of a 1 000-block launch
+// doing that beside the next step's VAE encoder the step went from 165 to 238 ms (round 4, first version).  Instead every handed-off
+// value is STORED with an agent-scope atomic store (sc1: written through to the coherence point) and drained (vmcnt(0)) before the
+// block is counted, and the finishing block LOADS them with agent-scope atomic loads (sc1: past its own non-coherent L2 lines) --
+// the second valid form of MI355X_MICROARCH.md "Correctness boundaries".
+#define AF_PUBLISH(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define AF_FETCH(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+__device__ __forceinline__ bool af_last_block(unsigned* counter, unsigned total, int tid, unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's published values have been acknowledged
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = atomicAdd(counter, 1u);
+    *flag = old + 1u == total;
+    if (old + 1u == total) AF_PUBLISH(counter, 0u);   // back to zero for the next step (nobody else touches it any more)
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+
+// one tensor's step size from its items' partial sums (RMS(u) -> clip denominator, RMS(p) -> relative step size)
+__device__ __forceinline__ void af_tensor_scale(const NkAfArgs& a, const NkAfTensor& t, int ti, int tid, float* red) {
+  float su = 0.f, sp = 0.f;
+  for (int i = tid; i < t.nitems; i += 256) {
+    su += AF_FETCH(a.u2_part + t.item0 + i);       // (this launch's blocks)
+    sp += a.p2_part[t.item0 + i];                  // (an earlier launch: the previous step's apply pass)
+  }
+  su = block_sum_256(su, red);
+  sp = block_sum_256(sp, red);
+  if (tid == 0) {
+    const float numel = t.kind == 0 ? (float)t.d0 : (float)t.d0 * (float)t.d1 * (float)(t.kind == 2 ? t.kh * t.kw : 1);
+    const float rms_u = sqrtf(su / numel);
+    const float denom = fmaxf(1.0f, rms_u / a.clip);
+    const float rms_p = sqrtf(sp) / sqrtf(numel);
+    const float lr = (a.scale_parameter ? fmaxf(a.eps2, rms_p) : 1.0f) * a.rel_step;
+    a.lr_t[ti] = lr;
+    a.scale[ti] = lr / denom;
+  }
+}
+
 __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
   AF_HEALTH_GATE(a);
   __shared__ float red[4];
   __shared__ float colsh[16][AF_TC + 4];
+  __shared__ unsigned flag[2];
   const NkAfItem it = a.items[a.item_lo + blockIdx.x];
   const NkAfTensor t = a.tensors[it.tensor];
   const int tid = threadIdx.x;
@@ -187,6 +229,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
     const int ry = tid >> 4, cx = tid & 15;
     const int col = it.tc * AF_TC + cx * 4;
     const bool cok = col < t.d1;
+    const int ntc = (t.d1 + AF_TC - 1) / AF_TC, ntr = (t.d0 + AF_TR - 1) / AF_TR;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     float* rowpart = a.ws + t.ws_row + (long)it.tc * t.d0;
 #pragma unroll 1
@@ -210,7 +253,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
         }
         // sum over the 16 column lanes of this row (lanes cx = 0..15 are adjacent within the wave)
         rs += __shfl_xor(rs, 8); rs += __shfl_xor(rs, 4); rs += __shfl_xor(rs, 2); rs += __shfl_xor(rs, 1);
-        if (cx == 0 && r < t.d0) rowpart[r] = rs;
+        if (cx == 0 && r < t.d0) AF_PUBLISH(rowpart + r, rs);
       }
     }
 #pragma unroll
@@ -222,19 +265,45 @@ __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += colsh[r][tid];
-        a.ws[t.ws_col + (long)it.tr * t.d1 + c] = s;
+        AF_PUBLISH(a.ws + t.ws_col + (long)it.tr * t.d1 + c, s);
       }
     }
-  } else if (t.kind == 2) {
-    float acc;
+    // the last tile of this 256-row strip: row EMAs of the strip and the sum of them (mean of the row EMA = sum of the slots / d0)
+    if (af_last_block(a.counters + t.cnt0 + 1 + it.tr, (unsigned)ntc, tid, &flag[0])) {
+      const int r = it.tr * AF_TR + tid;
+      float v = 0.f;
+      if (r < t.d0) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < ntc; ++c) s += AF_FETCH(a.ws + t.ws_row + (long)c * t.d0 + r);   // (independent loads: keep 8 in flight)
+        float* st = a.state + t.row_off + r;
+        v = *st * a.beta2t + (s / (float)t.d1) * (1.0f - a.beta2t);
+        *st = v;
+      }
+      v = block_sum_256(v, red);
+      if (tid == 0) a.mean_row[t.mr0 + it.tr] = v;
+    }
+    // ... and of this 64-column strip: its column EMAs
+    if (af_last_block(a.counters + t.cnt0 + 1 + ntr + it.tc, (unsigned)ntr, tid, &flag[1])) {
+      const int c = it.tc * AF_TC + tid;
+      if (tid < AF_TC && c < t.d1) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < ntr; ++r) s += AF_FETCH(a.ws + t.ws_col + (long)r * t.d1 + c);
+        float* st = a.state + t.col_off + c;
+        *st = *st * a.beta2t + (s / (float)t.d0) * (1.0f - a.beta2t);
+      }
+    }
+    return;
+  }
+  float acc;
+  if (t.kind == 2) {
     if (t.kh == 3 && t.kw == 3) acc = af_conv_stats<3, 3>(a, t, it.tr, tid, gs);
     else if (t.kh == 1 && t.kw == 1) acc = af_conv_stats<1, 1>(a, t, it.tr, tid, gs);
     else acc = af_conv_stats<0, 0>(a, t, it.tr, tid, gs);
-    acc = block_sum_256(acc, red);
-    if (tid == 0) a.u2_part[a.item_lo + blockIdx.x] = acc;
   } else {
     const long n = (long)t.d0;
-    float acc = 0.f;
+    acc = 0.f;
     for (int q = 0; q < AF_VEC / 256; ++q) {
       const long e = (long)it.tr * AF_VEC + q * 256 + tid;
       if (e < n) {
@@ -246,54 +315,16 @@ __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
         acc += u * u;
       }
     }
-    acc = block_sum_256(acc, red);
-    if (tid == 0) a.u2_part[a.item_lo + blockIdx.x] = acc;
   }
-}
-
-// matrices: row / column EMAs from the tile partials.  One block per 1024 rows (or columns) of one tensor; row blocks
-// also leave the sum of their rows' EMAs behind (mean of the row EMA = sum of those slots / d0, summed by the consumers).
-#define AF_FIN 1024
-__global__ __launch_bounds__(256) void af_finalize_stats_kernel(const NkAfArgs a) {
-  AF_HEALTH_GATE(a);
-  __shared__ float red[4];
-  const NkAfItem it = a.fin_items[a.fin_lo + blockIdx.x];
-  const NkAfTensor t = a.tensors[it.tensor];
-  const int tid = threadIdx.x;
-  const int ntc = (t.d1 + AF_TC - 1) / AF_TC, ntr = (t.d0 + AF_TR - 1) / AF_TR;
-  if (it.tc == 0) {
-    float msum = 0.f;
-    for (int q = 0; q < AF_FIN / 256; ++q) {
-      const int r = it.tr * AF_FIN + q * 256 + tid;
-      if (r < t.d0) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < ntc; ++c) s += a.ws[t.ws_row + (long)c * t.d0 + r];   // (independent loads: keep 8 in flight)
-        float* st = a.state + t.row_off + r;
-        const float v = *st * a.beta2t + (s / (float)t.d1) * (1.0f - a.beta2t);
-        *st = v;
-        msum += v;
-      }
-    }
-    msum = block_sum_256(msum, red);
-    if (tid == 0) a.mean_row[t.mr0 + it.tr] = msum;
-  } else {
-    for (int q = 0; q < AF_FIN / 256; ++q) {
-      const int c = it.tr * AF_FIN + q * 256 + tid;
-      if (c < t.d1) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < ntr; ++r) s += a.ws[t.ws_col + (long)r * t.d1 + c];
-        float* st = a.state + t.col_off + c;
-        *st = *st * a.beta2t + (s / (float)t.d0) * (1.0f - a.beta2t);
-      }
-    }
-  }
+  acc = block_sum_256(acc, red);
+  if (tid == 0) AF_PUBLISH(a.u2_part + a.item_lo + blockIdx.x, acc);
+  // convolutions and vectors have their update's RMS now: the last block of the tensor turns it into the step size
+  if (af_last_block(a.counters + t.cnt0, (unsigned)t.nitems, tid, &flag[0])) af_tensor_scale(a, t, it.tensor, tid, red);
 }
 
 __device__ __forceinline__ float af_mean_row(const NkAfArgs& a, const NkAfTensor& t) {
   float s = 0.f;
-  const int n = (t.d0 + AF_FIN - 1) / AF_FIN;
+  const int n = (t.d0 + AF_TR - 1) / AF_TR;
   for (int i = 0; i < n; ++i) s += a.mean_row[t.mr0 + i];
   return s / (float)t.d0;
 }
@@ -302,6 +333,7 @@ __device__ __forceinline__ float af_mean_row(const NkAfArgs& a, const NkAfTensor
 __global__ __launch_bounds__(256) void af_u2_kernel(const NkAfArgs a) {
   AF_HEALTH_GATE(a);
   __shared__ float red[4];
+  __shared__ unsigned flag;
   const NkAfItem it = a.items[a.item_lo + blockIdx.x];
   const NkAfTensor t = a.tensors[it.tensor];
   if (t.kind != 1) return;
@@ -338,32 +370,8 @@ __global__ __launch_bounds__(256) void af_u2_kernel(const NkAfArgs a) {
       }
   }
   acc = block_sum_256(acc, red);
-  if (tid == 0) a.u2_part[a.item_lo + blockIdx.x] = acc;
-}
-
-// one block per tensor: RMS(u) -> clip, RMS(p) -> step size
-__global__ __launch_bounds__(256) void af_finalize_scale_kernel(const NkAfArgs a) {
-  AF_HEALTH_GATE(a);
-  __shared__ float red[4];
-  const int ti = a.tensor_lo + blockIdx.x;
-  const NkAfTensor t = a.tensors[ti];
-  const int tid = threadIdx.x;
-  float su = 0.f, sp = 0.f;
-  for (int i = tid; i < t.nitems; i += 256) {
-    su += a.u2_part[t.item0 + i];
-    sp += a.p2_part[t.item0 + i];
-  }
-  su = block_sum_256(su, red);
-  sp = block_sum_256(sp, red);
-  if (tid == 0) {
-    const float numel = t.kind == 0 ? (float)t.d0 : (float)t.d0 * (float)t.d1 * (float)(t.kind == 2 ? t.kh * t.kw : 1);
-    const float rms_u = sqrtf(su / numel);
-    const float denom = fmaxf(1.0f, rms_u / a.clip);
-    const float rms_p = sqrtf(sp) / sqrtf(numel);
-    const float lr = (a.scale_parameter ? fmaxf(a.eps2, rms_p) : 1.0f) * a.rel_step;
-    a.lr_t[ti] = lr;
-    a.scale[ti] = lr / denom;
-  }
+  if (tid == 0) AF_PUBLISH(a.u2_part + a.item_lo + blockIdx.x, acc);
+  if (af_last_block(a.counters + t.cnt0, (unsigned)t.nitems, tid, &flag)) af_tensor_scale(a, t, it.tensor, tid, red);
 }
 
 __global__ __launch_bounds__(256) void af_apply_kernel(const NkAfArgs a) {
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(256) void af_init_p2_kernel(const NkAfArgs a) {
 
 static int af_check(const NkAdafactorArgs* h) {
   NK_CHECK_ARG(h && h->master && h->grad && h->shadow && h->state && h->ws && h->tensors && h->items);
-  NK_CHECK_ARG(h->u2_part && h->p2_part && h->mean_row && h->scale && h->lr_t);
+  NK_CHECK_ARG(h->u2_part && h->p2_part && h->mean_row && h->scale && h->lr_t && h->counters);
   NK_CHECK_ARG(h->item_hi > h->item_lo && h->tensor_hi > h->tensor_lo);
   return NK_OK;
 }
@@ -494,7 +502,7 @@ static NkAfArgs af_args(const NkAdafactorArgs* h) {
   a.master = h->master; a.grad = h->grad; a.shadow = (bf16_t*)h->shadow; a.state = h->state; a.ws = h->ws;
   a.tensors = (const NkAfTensor*)h->tensors; a.items = (const NkAfItem*)h->items;
   a.u2_part = h->u2_part; a.p2_part = h->p2_part; a.mean_row = h->mean_row; a.scale = h->scale; a.lr_t = h->lr_t;
-  a.fin_items = (const NkAfItem*)h->fin_items; a.fin_lo = h->fin_lo; a.fin_hi = h->fin_hi;
+  a.counters = h->counters;
   a.item_lo = h->item_lo; a.item_hi = h->item_hi; a.tensor_lo = h->tensor_lo; a.tensor_hi = h->tensor_hi;
   a.beta2t = h->beta2t; a.eps1 = h->eps1; a.eps2 = h->eps2; a.clip = h->clip_threshold; a.rel_step = h->rel_step;
   a.weight_decay = h->weight_decay; a.grad_scale = h->grad_scale; a.scale_parameter = h->scale_parameter;
@@ -519,17 +527,13 @@ extern "C" int nk_adafactor_chunk(const NkAdafactorArgs* h, void* stream_) {
   NkAfArgs a = af_args(h);
   if (!a.health) { nk_set_error(__FILE__, __LINE__, "health word allocation failed"); return NK_ERR_LAUNCH; }
   const int nitems = a.item_hi - a.item_lo, ntens = a.tensor_hi - a.tensor_lo;
+  (void)ntens;
   hipLaunchKernelGGL(af_stats_kernel, dim3(nitems), dim3(256), 0, stream, a);
   if (int e = nk_check_launch("af_stats_kernel")) return e;
-  if (h->fin_hi > h->fin_lo) {
-    NK_CHECK_ARG(h->fin_items != nullptr);
-    hipLaunchKernelGGL(af_finalize_stats_kernel, dim3(h->fin_hi - h->fin_lo), dim3(256), 0, stream, a);
-    if (int e = nk_check_launch("af_finalize_stats_kernel")) return e;
+  if (h->has_matrix) {
     hipLaunchKernelGGL(af_u2_kernel, dim3(nitems), dim3(256), 0, stream, a);
     if (int e = nk_check_launch("af_u2_kernel")) return e;
   }
-  hipLaunchKernelGGL(af_finalize_scale_kernel, dim3(ntens), dim3(256), 0, stream, a);
-  if (int e = nk_check_launch("af_finalize_scale_kernel")) return e;
   hipLaunchKernelGGL(af_apply_kernel, dim3(nitems), dim3(256), 0, stream, a);
   if (int e = nk_check_launch("af_apply_kernel")) return e;
   nk_health_snapshot(stream);                    // what the backward in front of this update left in the word

@@ -27,9 +27,9 @@ from .lib import call, query
 
 AF_TENSOR_DTYPE = np.dtype([("off", "<i8"), ("row_off", "<i8"), ("col_off", "<i8"), ("ws_row", "<i8"), ("ws_col", "<i8"),
                             ("kind", "<i4"), ("d0", "<i4"), ("d1", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("item0", "<i4"),
-                            ("nitems", "<i4"), ("mr0", "<i4")])
+                            ("nitems", "<i4"), ("mr0", "<i4"), ("cnt0", "<i4"), ("pad", "<i4")])
 AF_ITEM_DTYPE = np.dtype([("tensor", "<i4"), ("tr", "<i4"), ("tc", "<i4"), ("pad", "<i4")])
-AF_TR, AF_TC, AF_CONV_PAIRS, AF_VEC, AF_FIN = 256, 64, 1024, 1024, 1024
+AF_TR, AF_TC, AF_CONV_PAIRS, AF_VEC = 256, 64, 1024, 1024
 
 
 class _Args(C.Structure):
@@ -39,7 +39,7 @@ class _Args(C.Structure):
                 ("item_lo", C.c_int), ("item_hi", C.c_int), ("tensor_lo", C.c_int), ("tensor_hi", C.c_int),
                 ("beta2t", C.c_float), ("eps1", C.c_float), ("eps2", C.c_float), ("clip_threshold", C.c_float),
                 ("rel_step", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float),
-                ("scale_parameter", C.c_int), ("fin_items", C.c_void_p), ("fin_lo", C.c_int), ("fin_hi", C.c_int)]
+                ("scale_parameter", C.c_int), ("counters", C.c_void_p), ("has_matrix", C.c_int), ("reserved", C.c_int)]
 
 
 def _align(n: int, a: int = 64) -> int:
@@ -61,12 +61,12 @@ class FlatAdafactor:
         if query("nk_adafactor_tensor_bytes") != AF_TENSOR_DTYPE.itemsize:
             raise RuntimeError("FlatAdafactor: tensor table layout differs from the HIP library's")
         if chunk_bytes is None:
-            # gradient bytes per chunk of tensors (five launches each).  64 MB: a chunk's gradients are re-read (second-moment pass, update-RMS
-            # pass, apply pass) out of the 256 MB Infinity Cache instead of HBM -- 14 instead of 22 HBM bytes per parameter.  Round 1, with the
-            # update IN LINE behind backward, measured the opposite (128 MB chunks 19.2 images/s, 1-4 GB chunks 19.9-20.0: the ~800 dependent
-            # small launches cost more than the re-reads); since the update runs on its own stream beside the next step's VAE encoder, what
-            # counts is the HBM bandwidth it takes from that encoder: steady-state step 172.2 / 172.8 / 173.8 / 174.8 ms at 64 / 128 / 256 /
-            # 2048 MB (one box, bench.py, round 3).
+            # gradient bytes per chunk of tensors (three launches each).  A chunk's gradients are re-read (second-moment pass, update-RMS
+            # pass, apply pass) out of the 256 MB Infinity Cache instead of HBM while the chunk fits it -- 14 instead of 22 HBM bytes per
+            # parameter.  The update runs on its own stream beside the next step's VAE encoder, so what counts is the HBM bandwidth it takes
+            # from that encoder: round 3 (five launches per chunk) measured a steady-state step of 172.2 / 172.8 / 173.8 / 174.8 ms at
+            # 64 / 128 / 256 / 2048 MB; round 4 (three launches per chunk): step-time p50 164.3 / 165.2 / 165.5 ms at 64 / 128 / 256 MB
+            # (one box, back to back) -- the cache-sized chunk still wins although it costs twice the launches.
             import os
 
             chunk_bytes = int(os.environ.get("NK_AF_CHUNK_MB", "64")) << 20
@@ -80,24 +80,24 @@ class FlatAdafactor:
         dev = store.master.device
 
         tens = np.zeros(len(store.params), dtype=AF_TENSOR_DTYPE)
-        items, fin = [], []
-        self.chunks = []   # (tensor_lo, tensor_hi, item_lo, item_hi, fin_lo, fin_hi)
+        items = []
+        self.chunks = []   # (tensor_lo, tensor_hi, item_lo, item_hi)
         state_off = 0
         ws_max = 0
         mr_slots = 0
-        c_t0, c_i0, c_f0, c_bytes, c_ws = 0, 0, 0, 0, 0
-        self._fin_start = []     # index into `fin` at which each tensor's entries begin (restrict() cuts chunks at tensor boundaries)
+        n_counters = 0
+        c_t0, c_i0, c_bytes, c_ws = 0, 0, 0, 0
         for ti, (p, off) in enumerate(zip(store.params, store.offsets)):
             t = tens[ti]
             t["off"] = off
-            self._fin_start.append(len(fin))
+            t["cnt0"] = n_counters
             if p.dim() >= 2 and p.dim() not in (2, 4):
                 raise NotImplementedError(f"FlatAdafactor: {p.dim()}-d parameters are not supported")
             nbytes = p.numel() * 4
             if c_bytes and (c_bytes + nbytes > chunk_bytes or ti in bounds):   # close the current chunk before this tensor
-                self.chunks.append((c_t0, ti, c_i0, len(items), c_f0, len(fin)))
+                self.chunks.append((c_t0, ti, c_i0, len(items)))
                 ws_max = max(ws_max, c_ws)
-                c_t0, c_i0, c_f0, c_bytes, c_ws = ti, len(items), len(fin), 0, 0
+                c_t0, c_i0, c_bytes, c_ws = ti, len(items), 0, 0
             t["item0"] = len(items)
             if p.dim() == 2:
                 d0, d1 = p.shape
@@ -111,8 +111,8 @@ class FlatAdafactor:
                 c_ws += _align(ntc * d0 + ntr * d1)
                 items += [(ti, r, c, 0) for r in range(ntr) for c in range(ntc)]
                 t["mr0"] = mr_slots
-                mr_slots += -(-d0 // AF_FIN)
-                fin += [(ti, r, 0, 0) for r in range(-(-d0 // AF_FIN))] + [(ti, c, 1, 0) for c in range(-(-d1 // AF_FIN))]
+                mr_slots += ntr
+                n_counters += ntr + ntc
             elif p.dim() == 4:
                 O, I, KH, KW = p.shape
                 if KH > 3 or KW > 3:
@@ -128,16 +128,18 @@ class FlatAdafactor:
                 state_off += _align(n)
                 items += [(ti, r, 0, 0) for r in range(-(-n // AF_VEC))]
             t["nitems"] = len(items) - int(t["item0"])
+            n_counters += 1
             c_bytes += nbytes
-        self.chunks.append((c_t0, len(store.params), c_i0, len(items), c_f0, len(fin)))
+        self.chunks.append((c_t0, len(store.params), c_i0, len(items)))
         ws_max = max(ws_max, c_ws)
 
         items_np = np.array(items, dtype=np.int32).view(AF_ITEM_DTYPE).reshape(-1)
         self._tens_np = tens
         self.tensors = torch.from_numpy(tens.view(np.uint8).copy()).to(dev)
         self.items = torch.from_numpy(items_np.view(np.uint8).copy()).to(dev)
-        fin_np = np.array(fin if fin else [(0, 0, 0, 0)], dtype=np.int32).view(AF_ITEM_DTYPE).reshape(-1)
-        self.fin_items = torch.from_numpy(fin_np.view(np.uint8).copy()).to(dev)
+        # "blocks done" counters of the last-block-done finalisations (optim.hip): zeroed before every step (begin_step) although every pass
+        # leaves them at zero -- a step abandoned half way by the health gate must not poison the next one
+        self.counters = torch.zeros(n_counters, dtype=torch.int32, device=dev)
         self.nitems, self.ntensors = len(items), len(store.params)
         self.state = torch.zeros(max(state_off, 1), dtype=torch.float32, device=dev)
         self.ws = torch.empty(max(ws_max, 1), dtype=torch.float32, device=dev)
@@ -155,14 +157,12 @@ class FlatAdafactor:
         of the flat buffers; the others' updated shadows arrive by broadcast).  Chunks are cut at the two boundaries; per-tensor state
         never crosses a tensor, so cutting changes no arithmetic."""
         cut = []
-        for (t0, t1, i0, i1, f0, f1) in self.chunks:
+        for (t0, t1, i0, i1) in self.chunks:
             marks = sorted({t0, t1} | {b for b in (tensor_lo, tensor_hi) if t0 < b < t1})
             for a, b in zip(marks[:-1], marks[1:]):
                 ia = i0 if a == t0 else int(self._tens_np[a]["item0"])
                 ib = i1 if b == t1 else int(self._tens_np[b]["item0"])
-                fa = f0 if a == t0 else self._fin_start[a]
-                fb = f1 if b == t1 else self._fin_start[b]
-                cut.append((a, b, ia, ib, fa, fb))
+                cut.append((a, b, ia, ib))
         self.chunks = cut
         self.owned = (tensor_lo, tensor_hi)
 
@@ -183,13 +183,14 @@ class FlatAdafactor:
 
     # -- the update -------------------------------------------------------------------------------
     def _args(self, chunk, beta2t: float, rel_step: float, grad_scale: float) -> _Args:
-        t0, t1, i0, i1, f0, f1 = chunk
+        t0, t1, i0, i1 = chunk
         s = self.store
+        has_matrix = int((self._tens_np["kind"][t0:t1] == 1).any())
         return _Args(s.master.data_ptr(), s.grad.data_ptr(), s.shadow.data_ptr(), self.state.data_ptr(), self.ws.data_ptr(),
                      self.tensors.data_ptr(), self.items.data_ptr(), self.u2_part.data_ptr(), self.p2_part.data_ptr(),
                      self.mean_row.data_ptr(), self.scale.data_ptr(), self.lr_t.data_ptr(), i0, i1, t0, t1,
                      beta2t, self.eps[0], self.eps[1], self.clip_threshold, rel_step, self.weight_decay, grad_scale,
-                     int(self.scale_parameter), self.fin_items.data_ptr(), f0, f1)
+                     int(self.scale_parameter), self.counters.data_ptr(), has_matrix, 0)
 
     def rel_step(self, step: int) -> float:
         """adafactor.py:133-139"""
@@ -200,7 +201,7 @@ class FlatAdafactor:
 
     def refresh_param_norms(self) -> None:
         """Recompute the per-tile sums of p^2 (needed once, and again whenever the masters are changed from outside)."""
-        a = self._args((0, self.ntensors, 0, self.nitems, 0, 0), 0.0, 0.0, 1.0)
+        a = self._args((0, self.ntensors, 0, self.nitems), 0.0, 0.0, 1.0)
         call("nk_adafactor_init", C.byref(a), ops._stream())
         self._p2_valid = True
 
@@ -217,6 +218,7 @@ class FlatAdafactor:
     def begin_step(self) -> None:
         if not self._p2_valid:
             self.refresh_param_norms()
+        self.counters.zero_()
         self.step_count += 1
         self._beta2t = 1.0 - math.pow(self.step_count, self.decay_rate)
         self._rel = self.rel_step(self.step_count)
