@@ -332,7 +332,7 @@ def main():
                          "instead of the whole update after backward")
     ap.add_argument("--dp-mode", choices=["allreduce", "rs_ag"], default=os.environ.get("NK_DP_MODE", "allreduce"),
                     help="N > 1: allreduce = flat all-reduce of every gradient slice, the whole optimizer on every rank (default, what Lightning DDP does); "
-                         "rs_ag = slices reduced to tensor-aligned owner shards, optimizer on the owned shard, bf16 shadows gathered (neurosis_amd/dp.py)")
+                         "rs_ag = every slice reduce-scattered into tensor-aligned parts, optimizer on the owned parts, bf16 shadows all-gathered (neurosis_amd/dp.py)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
@@ -461,13 +461,19 @@ def main():
             rccl = None
         devices = [None] * world
         dist.all_gather_object(devices, f"{torch.cuda.get_device_name(device)} #{torch.cuda.current_device()} pid {os.getpid()}")
+        sent = int(wire / nsteps_counted)
+        span_s = (sum(span) / len(span) * 1e-3) if span else None
         comm = {"world_size": world, "backend": dist.get_backend(), "rccl_version": rccl, "devices": devices, "mode": dp.mode,
                 "wire_dtype": args.wire_dtype, "collectives_per_step": round(ncoll / nsteps_counted, 1),
-                "bytes_sent_per_rank_per_step": int(wire / nsteps_counted),
-                "allreduce_bytes_per_step": nbytes, "exposed_ms_mean": round(sum(exposed) / len(exposed), 2),
+                "bytes_sent_per_rank_per_step": sent,
+                "gradient_bytes": nbytes, "exposed_ms_mean": round(sum(exposed) / len(exposed), 2),
                 "first_to_last_collective_ms_mean": round(sum(span) / max(len(span), 1), 2) if span else None,
-                "busbw_GBps_over_span": round(nbytes * 2 * (world - 1) / world / (sum(span) / len(span) * 1e-3) / 1e9, 1) if span else None,
-                "note": "exposed = compute stream stalled between end of backward and end of the flat all-reduce; span includes the backward the exchange overlaps"}
+                # bus bandwidth from the bytes the collectives actually moved (all-reduce: 2 (N-1)/N x payload; rs_ag: (N-1)/N x the padded
+                # staging rows of the reduce-scatters -- the all-gathers run behind the update, outside this span)
+                "busbw_GBps_over_span": round(sent / span_s / 1e9, 1) if span_s else None,
+                "max_chunk_elements": dp.reducer.max_chunk,
+                "nccl_env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_NCHANNELS_PER_NET_PEER", "RCCL_MSCCL_ENABLE") if k in os.environ},
+                "note": "exposed = compute stream stalled between end of backward and end of the gradient exchange; span = first to last collective of the gradient exchange (includes the backward it overlaps); rs_ag counts its all-gathers in bytes_sent but they run on the optimizer stream"}
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

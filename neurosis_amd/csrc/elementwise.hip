@@ -602,10 +602,65 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ 
     __syncthreads();
   }
 }
+// The same for rows of up to 16 384 elements (the SD VAE's 128 x 128 mid block at 1024^2, and everything smaller): a row is held in the
+// block's registers between its one read and its one write -- 2 bytes in, 2 out per element where the general kernel reads the row three
+// times (1.59 GB fetched per 0.54 GB score matrix: profiles/r03_pmc_summary.csv).
+template <int NPT>     // 16-byte pieces per thread: L <= NPT * 2048
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(bf16_t* __restrict__ s, long M, int L) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (long row = blockIdx.x; row < M; row += gridDim.x) {
+    bf16_t* p = s + row * L;
+    uint4_t v[NPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int i = (j * 256 + tid) * 8;
+      v[j] = (uint4_t){0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};     // -inf: exp -> 0 past the end of the row
+      if (i < L) v[j] = *(const uint4_t*)(p + i);
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      float f[8];
+      unpack8(v[j], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f[e]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      float f[8];
+      unpack8(v[j], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += __expf(f[e] - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int i = (j * 256 + tid) * 8;
+      float f[8];
+      unpack8(v[j], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = __expf(f[e] - mx) * inv;
+      if (i < L) *(uint4_t*)(p + i) = pack8(f);
+    }
+    __syncthreads();
+  }
+}
 extern "C" int nk_softmax_rows(void* s, long M, int L, void* stream) {
   NK_CHECK_ARG(s && M > 0 && L > 0 && (L & 7) == 0);
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((int)(M < 4096 ? M : 4096)), dim3(256), 0, (hipStream_t)stream,
-                     (bf16_t*)s, M, L);
+  const dim3 grid((int)(M < 8192 ? M : 8192));
+  if (L <= 4096) hipLaunchKernelGGL(softmax_rows_reg_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)s, M, L);
+  else if (L <= 8192) hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)s, M, L);
+  else if (L <= 16384) hipLaunchKernelGGL(softmax_rows_reg_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)s, M, L);
+  else hipLaunchKernelGGL(softmax_rows_kernel, dim3((int)(M < 4096 ? M : 4096)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)s, M, L);
   return nk_check_launch("softmax_rows");
 }
 

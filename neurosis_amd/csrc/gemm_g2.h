@@ -31,6 +31,17 @@
 #pragma once
 
 #define G2_BM 128
+// Diagnostic build only (make EXTRA=-DNK_G2_STAMPS; tools/g2_stamps.py): wave 0 of every workgroup stamps s_memtime at entry, after the
+// prologue, after the k loop and after the epilogue, plus s_memrealtime around the loop (the clock the chip holds: cdna guide section 7).
+// In the shipped library none of this exists.
+#ifdef NK_G2_STAMPS
+__device__ unsigned long long nk_g2_stamp_buf[8 * 4096];
+#define G2_STAMP(slot) do { if (tid == 0 && blockIdx.x < 4096 && blockIdx.z == 0) nk_g2_stamp_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G2_STAMP_RT(slot) do { if (tid == 0 && blockIdx.x < 4096 && blockIdx.z == 0) nk_g2_stamp_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define G2_STAMP(slot)
+#define G2_STAMP_RT(slot)
+#endif
 #define G2_STAGE_BYTES 36864                     // A image 16 KiB + B image up to 20 KiB
 #define G2_NS 4
 #define G2_SMEM_BYTES (G2_NS * G2_STAGE_BYTES)   // 147456
@@ -281,6 +292,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HN = BN_ / 2, NJ = HN / 16;          // columns per group; 16-column blocks per wave: 4 or 5
   const int tid = threadIdx.x, lane = tid & 63;
+  G2_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wq = wave & 3;
 
@@ -350,6 +362,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
   G2_BAR();
   if (grp == 1) { G2_BAR(); }                                       // the second group runs one barrier behind
 
+  G2_STAMP(1); G2_STAMP_RT(4);
   unsigned so = 0, sn = 2 * G2_STAGE_BYTES;                         // stage of slab t / of slab t + 2
   for (int t = 0; t < nk; ++t) {
     // ---- R: fragment reads of slab t, DMA of slab t + 2, wait for slab t + 1 ----
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    ob.fire(sb, smem + sn + 16384, wave);
+    ob.fire(sb, smem + sn + 16384, wave);      // (all five pieces in the R phase instead: 1237 vs 1117 cycles per k-step, tools/g2_stamps.py, round 4)
     oa.next_sources(p.K, sa);
     ob.next_sources(p.K, sb);
 #pragma unroll
@@ -387,6 +400,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
   }
   if (grp == 0) { G2_BAR(); }                                       // ... and the first group waits for it here
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the past-the-end zero-page pieces must land before the LDS is given up
+  G2_STAMP(2); G2_STAMP_RT(5);
 #undef G2_BAR
 #undef G2_WAIT_ONE_SLAB
 
@@ -408,7 +422,16 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
     float4_t last[2] = {acc[0][NJ - 1], acc[1][NJ - 1]};
     reg_epilogue_col16<OUT_F32, 2>(p, Cp, last, mb, nb + (NJ - 1) * 16, lane);
   }
+#ifdef NK_G2_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G2_STAMP(3);
+#endif
 }
+#ifdef NK_G2_STAMPS
+extern "C" int nk_debug_g2_stamps(unsigned long long* host_out, int nwg) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nk_g2_stamp_buf), (size_t)nwg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // NK_GEMM_G2: 0 = never; 1 (default) = by shape; 2 = every eligible launch (A/B runs)
 static int g2_mode() {

@@ -366,7 +366,13 @@ class DiffusionEngine(nn.Module):
             self._optimizer_in_flight = False
 
     def state_dict(self, *args, **kwargs):
+        """Parameters as the reference's keys name them.  Under the sharded data-parallel exchange (dp.FlatDataParallel, mode rs_ag) the
+        fp32 masters of the other ranks' parts are stale between checkpoints: they (and the optimizer statistics) are gathered HERE, before
+        the tensors are collected -- a collective, so every rank must call state_dict() together (Lightning's dump_checkpoint does)."""
         self.join_optimizer()
+        dp = getattr(getattr(self, "store", None), "dp", None)
+        if dp is not None and dp.sharded:
+            dp.sync_masters()
         return super().state_dict(*args, **kwargs)
 
     # -- sampling (SURVEY 8(f) N4) -------------------------------------------------------------------

@@ -149,22 +149,27 @@ class FlatAdafactor:
         self.scale = torch.zeros(self.ntensors, dtype=torch.float32, device=dev)
         self.lr_t = torch.zeros(self.ntensors, dtype=torch.float32, device=dev)
         self._p2_valid = False
-        self.owned = None          # restrict(): (tensor_lo, tensor_hi) this process updates; None = everything
+        self.owned = None          # restrict_ranges(): [(tensor_lo, tensor_hi), ...] this process updates; None = everything
         store.add_listener(self)
 
     def restrict(self, tensor_lo: int, tensor_hi: int) -> None:
-        """Update only tensors [tensor_lo, tensor_hi) from now on (data-parallel rs_ag mode: a rank owns a contiguous, tensor-aligned shard
-        of the flat buffers; the others' updated shadows arrive by broadcast).  Chunks are cut at the two boundaries; per-tensor state
-        never crosses a tensor, so cutting changes no arithmetic."""
+        self.restrict_ranges([(tensor_lo, tensor_hi)])
+
+    def restrict_ranges(self, ranges) -> None:
+        """Update only the tensors inside `ranges` = [(tensor_lo, tensor_hi), ...] from now on (data-parallel rs_ag mode: a rank owns one
+        tensor-aligned part of every slice of the flat buffers; the others' updated shadows arrive by all-gather).  Chunks are cut at every
+        boundary; per-tensor state never crosses a tensor, so cutting changes no arithmetic."""
+        ranges = sorted((int(a), int(b)) for a, b in ranges if b > a)
+        bounds = sorted({x for ab in ranges for x in ab})
         cut = []
         for (t0, t1, i0, i1) in self.chunks:
-            marks = sorted({t0, t1} | {b for b in (tensor_lo, tensor_hi) if t0 < b < t1})
+            marks = sorted({t0, t1} | {b for b in bounds if t0 < b < t1})
             for a, b in zip(marks[:-1], marks[1:]):
                 ia = i0 if a == t0 else int(self._tens_np[a]["item0"])
                 ib = i1 if b == t1 else int(self._tens_np[b]["item0"])
                 cut.append((a, b, ia, ib))
         self.chunks = cut
-        self.owned = (tensor_lo, tensor_hi)
+        self.owned = ranges
 
     def state_span(self, tensor_lo: int, tensor_hi: int) -> tuple[int, int]:
         """[lo, hi) of `self.state` (fp32 second-moment statistics) belonging to tensors [tensor_lo, tensor_hi): state is laid out in
@@ -174,7 +179,7 @@ class FlatAdafactor:
         return lo, hi
 
     def _mine(self, ci: int) -> bool:
-        return self.owned is None or (self.chunks[ci][0] >= self.owned[0] and self.chunks[ci][1] <= self.owned[1])
+        return self.owned is None or any(self.chunks[ci][0] >= a and self.chunks[ci][1] <= b for a, b in self.owned)
 
     def masters_changed(self) -> None:
         """FlatParamStore hook: the fp32 masters were rewritten from outside (checkpoint load, broadcast, EMA swap): the

@@ -132,8 +132,8 @@ class DiffusionEngineMI355X(_Base):
     # -- checkpoints: the reference's state_dict keys live under `engine.`; optimizer state rides along ------------------
     def on_save_checkpoint(self, checkpoint: dict) -> None:
         self.engine.join_optimizer()
-        if self.dp is not None:
-            self.dp.sync_masters()        # rs_ag: every rank's masters and optimizer statistics become whole again (a collective: all ranks call)
+        # (rs_ag: DiffusionEngine.state_dict() has already made every rank's masters and optimizer statistics whole -- Lightning builds the
+        # module's state_dict before this hook runs -- so what is saved below is complete whether or not the tensors alias the flat buffers)
         opt = self.engine._torch_optimizer
         if opt is not None:
             checkpoint["nk_optimizer"] = opt.state_dict()

@@ -101,70 +101,126 @@ def test_mean_of_rank_gradients_equals_full_batch_gradient():
 
 
 def _worker_sharded(rank, world, port, out):
-    """The sharded exchange (mode rs_ag) against the all-reduce one, with gloo on CPU: gradient slices arrive back to front as the UNet's
-    backward finalises them; each mode then applies the same update rule -- p -= lr * mean gradient -- (all-reduce: everywhere; rs_ag: the
-    owner on its shard, then shadows broadcast, masters gathered on demand).  Masters and shadows must agree exactly."""
+    """The sharded exchange (mode rs_ag: reduce_scatter_tensor of every slice into tensor-aligned parts, optimizer on the owned parts,
+    all_gather_into_tensor of the shadows and of the directly-read fp32 masters) against the all-reduce one, with gloo on CPU: gradient slices
+    arrive back to front as the UNet's backward finalises them; each mode then applies the same update rule -- p -= lr * mean gradient --
+    (all-reduce: everywhere; rs_ag: the owner on its parts; masters gathered on demand).  Masters and shadows must agree exactly."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from types import SimpleNamespace
 
-    from neurosis_amd.dp import FlatDataParallel, shard_bounds
+    from neurosis_amd.dp import FlatDataParallel, SlicePlan
 
     torch.manual_seed(0)
-    sizes = [1000, 37, 4096, 512, 2048, 64, 3000, 800]
+    sizes = [1000, 37, 4096, 512, 2048, 64, 3000, 800, 640, 640, 640]
     offsets, total = [], 0
     for n in sizes:
         offsets.append(total)
         total += (n + 63) // 64 * 64
+    ends = offsets + [total]
+    blocks = [(offsets[8], total), (offsets[5], offsets[8]), (offsets[2], offsets[5]), (0, offsets[2])]       # four "blocks", back to front
+    vectors = (1, 5)
 
     def make_store():
         master = torch.linspace(-1, 1, total)
-        store = SimpleNamespace(params=[torch.empty(n) if n in (37, 64) else torch.empty(n // 8, 8) for n in sizes], offsets=offsets, numel=total, master=master.clone(), shadow=master.to(torch.bfloat16),
-                                grad=torch.zeros(total), listeners=[], state=SimpleNamespace(wgrad_stream=None, aux_stream=None))
+        store = SimpleNamespace(params=[torch.empty(n) if i in vectors else torch.empty(n // 8, 8) for i, n in enumerate(sizes)], offsets=offsets, numel=total,
+                                master=master.clone(), shadow=master.to(torch.bfloat16), grad=torch.zeros(total), listeners=[],
+                                state=SimpleNamespace(wgrad_stream=None, aux_stream=None))
         store._mark_fresh = lambda: None
         store.refresh = lambda: store.shadow.copy_(store.master.to(torch.bfloat16))
         return store
 
-    tb, eb = shard_bounds(make_store(), world)
-    ok_bounds = tb[0] == 0 and tb[-1] == len(sizes) and eb[0] == 0 and eb[-1] == total and all(eb[i] == (offsets + [total])[tb[i]] for i in range(world + 1))
+    # the plan of one slice: tensor-aligned cuts, every element owned exactly once, parts of about equal size
+    pl = SlicePlan(make_store(), offsets[2], offsets[5], world)
+    ok_plan = (pl.cuts[0] == offsets[2] and pl.cuts[-1] == offsets[5] and all(c in ends for c in pl.cuts) and sorted(pl.cuts) == pl.cuts
+               and all(pl.cuts[r] == ends[pl.tcuts[r]] for r in range(world + 1)) and pl.row % 64 == 0 and pl.row >= max(pl.sizes))
+    # the last block is three equal tensors: at world 3 its parts are equal and aligned -> no staging copies (the slice is its own staging layout)
+    pl_eq = SlicePlan(make_store(), offsets[8], total, world)
+    ok_plan = ok_plan and (world != 3 or all(sz == pl_eq.row for sz in pl_eq.sizes))
     results = {}
     for mode in ("allreduce", "rs_ag"):
         store = make_store()
         unet = SimpleNamespace(grad_ready_hook=None)
-        dp = FlatDataParallel(unet, store, mode=mode, broadcast_params=False)
-        ends = offsets + [total]
+        dp = FlatDataParallel(unet, store, mode=mode, broadcast_params=False, slices=blocks)
         # a stand-in for the fused optimizer's statistics: one fp32 value per element, laid out in tensor order like FlatAdafactor.state
-        opt = SimpleNamespace(state=torch.zeros(total), restrict=lambda lo, hi: None, state_span=lambda lo, hi: (ends[lo], ends[hi]))
+        opt = SimpleNamespace(state=torch.zeros(total), restrict_ranges=lambda r: None, state_span=lambda lo, hi: (ends[lo], ends[hi]))
         dp.attach_optimizer(opt)
+        owned = dp.owned_ranges()
         g = torch.Generator().manual_seed(100 + rank)
         for step in range(3):
             store.grad.copy_(torch.randn(total, generator=g))
-            for lo, hi in [(offsets[5], total), (offsets[2], offsets[5]), (0, offsets[2])]:        # three "blocks", back to front
-                dp.reducer.reduce_range(lo, hi)
+            for lo, hi in blocks:
+                dp.exchange_range(lo, hi)
             scale = dp.finish()
-            lo_t, hi_t = dp.owned_tensors()
-            a, b = (offsets + [total])[lo_t], (offsets + [total])[hi_t]
-            store.master[a:b] -= 0.1 * scale * store.grad[a:b]                                      # the "optimizer", on the owned range
-            store.shadow[a:b] = store.master[a:b].to(torch.bfloat16)
-            opt.state[a:b] += (scale * store.grad[a:b]) ** 2
+            for lo_t, hi_t in owned:                                                                # the "optimizer", on the owned parts
+                a, b = ends[lo_t], ends[hi_t]
+                store.master[a:b] -= 0.1 * scale * store.grad[a:b]
+                store.shadow[a:b] = store.master[a:b].to(torch.bfloat16)
+                opt.state[a:b] += (scale * store.grad[a:b]) ** 2
             dp.after_optimizer_step()
         shadows_before_sync = store.shadow.clone()
-        # the 1-D parameters (here tensors 1 and 5), which kernels read as fp32 masters, must be current on every rank BEFORE any sync_masters()
-        vec_before_sync = torch.cat([store.master[offsets[t]:offsets[t] + sizes[t]] for t in (1, 5)]).clone()
+        # the 1-D parameters, which kernels read as fp32 masters, must be current on every rank BEFORE any sync_masters()
+        vec_before_sync = torch.cat([store.master[offsets[t]:offsets[t] + sizes[t]] for t in vectors]).clone()
         dp.sync_masters()
-        results[mode] = (store.master.clone(), shadows_before_sync, dp.sharded, dp.reducer.take_counts(), opt.state.clone(), vec_before_sync)
-    same_master = torch.equal(results["allreduce"][0], results["rs_ag"][0]) and torch.equal(results["allreduce"][4], results["rs_ag"][4])
-    same_shadow = torch.equal(results["allreduce"][1], results["rs_ag"][1]) and torch.equal(results["allreduce"][5], results["rs_ag"][5])
-    fewer_bytes = results["rs_ag"][3][1] <= 0.77 * results["allreduce"][3][1]      # fp32 in + bf16 out vs fp32 both ways: 6/8 of the bytes per link
-    out[rank] = (ok_bounds, same_master, same_shadow, results["rs_ag"][2], not results["allreduce"][2], fewer_bytes)
+        results[mode] = (store.master.clone(), shadows_before_sync, dp.sharded, dp.reducer.take_counts(), opt.state.clone(), vec_before_sync, owned)
+    # (two ranks: a + b has one order -> bit-equal; three: the ring all-reduce and the reduce-scatter add in different orders -> fp32 rounding)
+    same = torch.equal if world == 2 else (lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-6))
+    same_master = same(results["allreduce"][0], results["rs_ag"][0]) and same(results["allreduce"][4], results["rs_ag"][4])
+    same_shadow = (same(results["allreduce"][1].float(), results["rs_ag"][1].float()) if world == 2 else
+                   torch.allclose(results["allreduce"][1].float(), results["rs_ag"][1].float(), rtol=1e-2, atol=1e-3)) and same(results["allreduce"][5], results["rs_ag"][5])
+    # every tensor has exactly one owner across the ranks
+    gathered = [None] * world
+    dist.all_gather_object(gathered, results["rs_ag"][6])
+    owners = [sum(any(a <= t < b for a, b in rr) for rr in gathered) for t in range(len(sizes))]
+    one_owner = all(o == 1 for o in owners)
+    # (bytes per rank: the padded staging rows of this toy set -- tensors of very unequal size -- hide the 6/8; checked on equal parts below
+    # and on the real UNet's parameter list in test_host_logic.py)
+    out[rank] = (ok_plan, same_master, same_shadow, results["rs_ag"][2], not results["allreduce"][2], one_owner)
     dist.destroy_process_group()
 
 
-def test_sharded_exchange_equals_allreduce_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_exchange_equals_allreduce(world):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker_sharded, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
-        assert out[r] == (True, True, True, True, True, True), out[r]
+        assert out[r] == (True,) * 6, out[r]
+
+
+def _worker_bytes(rank, world, port, out):
+    """equal, aligned parts: rs_ag moves exactly 6/8 of the all-reduce's bytes per rank (fp32 reduce-scatter + bf16 all-gather vs fp32 both ways)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+
+    from neurosis_amd.dp import FlatDataParallel
+
+    n, k = 1024, 2 * world
+    offsets, total = [i * n for i in range(k)], k * n
+    counts = {}
+    for mode in ("allreduce", "rs_ag"):
+        store = SimpleNamespace(params=[torch.empty(n // 8, 8) for _ in range(k)], offsets=offsets, numel=total, master=torch.zeros(total), shadow=torch.zeros(total, dtype=torch.bfloat16),
+                                grad=torch.ones(total), listeners=[], state=SimpleNamespace(wgrad_stream=None, aux_stream=None))
+        store._mark_fresh = lambda: None
+        dp = FlatDataParallel(SimpleNamespace(grad_ready_hook=None), store, mode=mode, broadcast_params=False, slices=[(0, total)])
+        dp.exchange_range(0, total)
+        dp.finish()
+        dp.after_optimizer_step()
+        counts[mode] = dp.reducer.take_counts()
+        ok_sum = bool((store.grad[dp.plans[(0, total)].cuts[rank]:dp.plans[(0, total)].cuts[rank + 1]] == world).all()) if dp.sharded else bool((store.grad == world).all())
+        counts[mode + "_ok"] = ok_sum
+    out[rank] = (counts["rs_ag"][1] / counts["allreduce"][1], counts["rs_ag"][0], counts["allreduce_ok"], counts["rs_ag_ok"])
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_moves_three_quarters_of_the_bytes():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_bytes, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        ratio, ncoll, ok_a, ok_s = out[r]
+        assert abs(ratio - 0.75) < 1e-6 and ncoll == 2 and ok_a and ok_s, out[r]      # (no 1-D parameters here: one reduce-scatter, one all-gather)

@@ -111,7 +111,7 @@ def test_flat_data_parallel_rccl_one_gpu_per_rank():
 def _worker_modes(rank, world, port, out):
     """Three configurations of the exchange in one process pair (two ranks on cuda:0 over gloo), each from the same initial weights, three
     training steps with the fused Adafactor: all-reduce / fp32 wire (the default), all-reduce / bf16 wire (bench.py --wire-dtype bf16), and
-    the sharded rs_ag mode (reduce to owner, optimizer on the owned shard, shadows gathered; masters gathered at the end)."""
+    the sharded rs_ag mode (every slice reduce-scattered into tensor-aligned parts, optimizer on the owned parts, shadows all-gathered; masters gathered at the end)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -137,7 +137,7 @@ def _worker_modes(rank, world, port, out):
         stale = eng.store.master.cpu().clone()
         dp.sync_masters()
         torch.cuda.synchronize()
-        res[tag] = (eng.store.master.cpu(), shadow, stale, dp.sharded, dp.owned_tensors(), len(eng.store.params))
+        res[tag] = (eng.store.master.cpu(), shadow, stale, dp.sharded, dp.owned_ranges(), len(eng.store.params))
         eng.model.diffusion_model.grad_ready_hook = None
         del eng, dp, af
         torch.cuda.empty_cache()
@@ -147,18 +147,19 @@ def _worker_modes(rank, world, port, out):
     gathered = [None] * world
     dist.all_gather_object(gathered, {k: v[0] for k, v in res.items()})
     same_across_ranks = all(torch.equal(gathered[0][k], gathered[r][k]) for k in res for r in range(world))
-    lo, hi = res["rsag"][4]
+    owned = res["rsag"][4]
+    n_owned = sum(b - a for a, b in owned)
     store0 = _build(fx, shapes).store
 
     def worst(tag):      # the three tensors that differ most from the default run: (index, dims, owner is this rank, relative difference)
         rows = []
         for t, (p, off) in enumerate(zip(store0.params, store0.offsets)):
             a, b = res[tag][0][off:off + p.numel()], ref[off:off + p.numel()]
-            rows.append((float((a - b).norm() / (b.norm() + 1e-12)), t, p.dim(), lo <= t < hi))
+            rows.append((float((a - b).norm() / (b.norm() + 1e-12)), t, p.dim(), any(lo <= t < hi for lo, hi in owned)))
         return sorted(rows, reverse=True)[:3]
     out[rank] = dict(same_across_ranks=same_across_ranks, rsag_vs_ar=rel(res["rsag"][0], ref), ar16_vs_ar=rel(res["ar16"][0], ref), noise=rel(res["again"][0], ref),
                      shadow_rsag_vs_ar=rel(res["rsag"][1], res["ar32"][1]), sharded=res["rsag"][3] and not res["ar32"][3],
-                     owns_part=0 <= lo < hi <= res["rsag"][5] and (hi - lo) < res["rsag"][5],
+                     owns_part=0 < n_owned < res["rsag"][5] and all(0 <= a < b <= res["rsag"][5] for a, b in owned),
                      stale_before_sync=rel(res["rsag"][2], ref) > rel(res["rsag"][0], ref),
                      moved=rel(ref, store0.master.cpu()), worst_rsag=worst("rsag"), worst_ar16=worst("ar16"))
     dist.barrier()
