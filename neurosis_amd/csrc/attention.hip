@@ -1447,7 +1447,7 @@ static bool attn64_enabled() {
 }
 template <typename K>
 static void set_smem(K kern, int bytes) {
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  nk_optin_lds((const void*)kern, bytes);
 }
 
 extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, void* o, float* lse,

@@ -430,11 +430,14 @@ static bool halo_shape_ok(const NkGemmParams& p) {
   if ((p.N & 7) || (p.ldc & 7) || (p.residual && (p.ldr & 7))) return false;
   return true;
 }
+// column-tile width of the halo-tile launch for N output channels: THE rule (tile planner, launcher and the statistics-epilogue query
+// nk_conv2d_stats_tiles all ask here: the epilogue's partial layout depends on it)
+static int halo_bn(int N) { return N % 160 == 0 ? 160 : 128; }
 // tile height for this problem: 8-row tiles where they still give about one workgroup per CU, else 4-row tiles; 0 = the patches
 // would cover the image with too much waste (ragged small images keep the gather kernels)
 static int halo_tile_rows(const NkGemmParams& p) {
   const NkGather& g = p.ga;
-  const int bn = p.N % 160 == 0 ? 160 : 128;
+  const int bn = halo_bn(p.N);
   const long txn = (g.W + CH_TW - 1) / CH_TW;
   for (int th = 8; th >= 4; th -= 4) {
     const long tyn = (g.H + th - 1) / th;
@@ -454,12 +457,8 @@ static bool use_halo(const NkGemmParams& p, int amode, int bmode, int out_f32) {
 
 template <int BN_, int MI, int STATS>
 static int launch_halo_as(const NkGemmParams& p, hipStream_t stream) {
-  static bool attr_set = false;
   auto kern = nk_conv3x3_halo_kernel<BN_, MI, STATS>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<MI>::SMEM);
-    attr_set = true;
-  }
+  nk_optin_lds((const void*)kern, HaloGeom<MI>::SMEM);
   const NkGather& g = p.ga;
   const long tiles = (long)p.halo_nb * ((g.W + CH_TW - 1) / CH_TW) * ((g.H + HaloGeom<MI>::TH - 1) / HaloGeom<MI>::TH) * (p.N / BN_);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), HaloGeom<MI>::SMEM, stream, p);
@@ -468,7 +467,7 @@ static int launch_halo_as(const NkGemmParams& p, hipStream_t stream) {
 template <int STATS>
 static int launch_halo_s(const NkGemmParams& p, hipStream_t stream) {
   const int th = halo_tile_rows(p);
-  const bool wide = p.N % 160 == 0;
+  const bool wide = halo_bn(p.N) == 160;
   if (th == 8) return wide ? launch_halo_as<160, 4, STATS>(p, stream) : launch_halo_as<128, 4, STATS>(p, stream);
   return wide ? launch_halo_as<160, 2, STATS>(p, stream) : launch_halo_as<128, 2, STATS>(p, stream);
 }

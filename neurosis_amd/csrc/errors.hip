@@ -124,3 +124,16 @@ extern "C" int nk_health_import(const int* src, void* stream) {
   hipLaunchKernelGGL(nk_health_import_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d, src);
   return nk_check_launch("nk_health_import_kernel");
 }
+
+// ---- dynamic-LDS opt-in, once per (kernel, device) ----------------------------------------------------------------------------------------
+#include <mutex>
+#include <set>
+#include <utility>
+void nk_optin_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.insert({kernel, dev}).second) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}

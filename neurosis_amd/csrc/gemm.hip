@@ -1393,12 +1393,8 @@ static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int
 }
 template <int AMODE, int WM, int WN>
 static int launch_xl_as(const NkGemmParams& p, hipStream_t stream) {
-  static bool attr_set = false;
   auto kern = nk_gemm_xl_kernel<AMODE, WM, WN>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES);
-    attr_set = true;
-  }
+  nk_optin_lds((const void*)kern, XL_SMEM_BYTES);
   dim3 grid(((p.M + XL_BM - 1) / XL_BM) * ((p.N + XL_BN - 1) / XL_BN), 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3((XL_BM / WM) * (XL_BN / WN) * 64), XL_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_xl_kernel");
@@ -1432,14 +1428,10 @@ template <int AMODE, int BMODE, int OUT_F32>
 static int launch(const NkGemmParams& p_in, int splitk, hipStream_t stream) {
   NkGemmParams p2 = p_in;
   const NkGemmParams& p = p2;
-  static bool attr_set = false;
   auto kern8 = nk_gemm_dma_kernel<AMODE, BMODE, OUT_F32, 8>;      // 8 waves per 128 x 128 tile: +4..14 % over 4 waves on every SDXL shape
   auto kernr = nk_gemm_ring_kernel<AMODE, BMODE, OUT_F32>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
-    (void)hipFuncSetAttribute((const void*)kernr, hipFuncAttributeMaxDynamicSharedMemorySize, RING_SMEM_BYTES);
-    attr_set = true;
-  }
+  nk_optin_lds((const void*)kern8, V2_SMEM_BYTES);
+  nk_optin_lds((const void*)kernr, RING_SMEM_BYTES);
   int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, splitk, p.nbatch ? p.nbatch : 1);
   {  // patch height: with T tiles over 8 XCDs an XCD runs ~T/8 tiles at a time; a gm x (T/8/gm) patch touches gm + T/8/gm operand
@@ -1545,12 +1537,8 @@ extern "C" int nk_gemm_sk_status(void) {
 
 template <int AMODE, int BMODE, int OUT_F32>
 static int launch_sk(NkGemmParams& p, hipStream_t stream) {
-  static bool attr_set = false;
   auto kern = nk_gemm_sk_kernel<AMODE, BMODE, OUT_F32>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SK_SMEM_BYTES);
-    attr_set = true;
-  }
+  nk_optin_lds((const void*)kern, SK_SMEM_BYTES);
   const long ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nk = (p.K + BK - 1) / BK;
   const long T = ntm * ntn * (p.nbatch ? p.nbatch : 1), W = T * nk;
   // persistent grid: two workgroups per CU, at least ~4 k-steps each
@@ -1712,6 +1700,7 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
 
 // pixel tiles per image of the halo-tile launch this convolution would get (= rows per image of the statistics epilogue's partials);
 // 0 when it is not eligible (shape, NK_CONV_HALO=0)
+int nk_halo_bn(int N) { return halo_bn(N); }
 int nk_halo_tiles_per_image(const NkGemmParams& p) {
   if (!use_halo(p, OP_KCG, OP_KC, 0)) return 0;
   return halo_tiles_per_image(p);

@@ -479,12 +479,8 @@ static bool use_g2(const NkGemmParams& p, int amode, int bmode, int out_f32, int
 
 template <int AMODE, int BMODE, int OUT_F32, int BN_>
 static int launch_g2_as(const NkGemmParams& p, hipStream_t stream) {
-  static bool attr_set = false;
   auto kern = nk_gemm_g2_kernel<AMODE, BMODE, OUT_F32, BN_>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G2_SMEM_BYTES);
-    attr_set = true;
-  }
+  nk_optin_lds((const void*)kern, G2_SMEM_BYTES);
   dim3 grid(((p.M + G2_BM - 1) / G2_BM) * ((p.N + BN_ - 1) / BN_), 1, p.nbatch ? p.nbatch : 1);
   hipLaunchKernelGGL(kern, grid, dim3(512), G2_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_g2_kernel");

@@ -27,6 +27,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int uint2_t;
 
 void nk_set_error(const char* file, int line, const char* what);
 int nk_check_launch(const char* what);
+// Opt a kernel in to `bytes` of dynamic LDS ON THE CURRENT DEVICE, once per (kernel, device): the attribute is per device, so a process-wide
+// "done" flag would leave a second GPU of the same process launching 100+ KiB kernels without it (round-3 advisor finding).  Thread-safe.
+void nk_optin_lds(const void* kernel, int bytes);
 // Backward-health word (errors.hip): ONE device word per process.  A kernel that cannot deliver a correct result (a
 // stream-K fix-up that gave up waiting) raises it and poisons its output; the fused optimizer kernels read it first and
 // leave every buffer untouched while it is set; the optimizer entry points report it on the host without synchronising.

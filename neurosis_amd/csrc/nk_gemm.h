@@ -80,4 +80,5 @@ enum { NK_OP_KC = 0, NK_OP_KCG = 1, NK_OP_MC = 2, NK_OP_MCT = 3, NK_OP_MCG = 4 }
 
 int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int allow_splitk, hipStream_t stream);
 int nk_halo_tiles_per_image(const NkGemmParams& p);
+int nk_halo_bn(int N);        // column-tile width of the halo-tile launch (conv_halo.h: halo_bn)
 int nk_geglu_fwd_fusable(const NkGemmParams& p);

@@ -206,7 +206,7 @@ extern "C" long nk_conv2d_stats_tiles(const NkConvDesc* d, int stats_groups) {
   if (stats_groups < 0 || stats_groups > 32) return 0;
   if (stats_groups) {
     if (d->Cout % stats_groups) return 0;
-    const int bn = d->Cout % 160 == 0 ? 160 : 128, cpg = d->Cout / stats_groups;
+    const int bn = nk_halo_bn(d->Cout), cpg = d->Cout / stats_groups;
     if (bn % cpg) return 0;               // a column tile must hold whole groups
   }
   NkGemmParams p = conv_fwd_params(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);

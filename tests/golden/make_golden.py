@@ -3,7 +3,7 @@
 /root/reference) on the CPU in the authoring container.  The reference never travels to the GPU box; only
 the small fixtures written here do.
 
-    python tests/golden/make_golden.py        # rewrites tests/golden/*.pt / *.json
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.safetensors / *.json (no pickle: fixture_io.py)
 
 Third-party packages the reference imports but this image lacks (lightning, torchvision, open_clip, ...) are
 replaced by empty stand-in modules at import time only; xformers is left genuinely
@@ -26,6 +26,9 @@ from unittest import mock
 
 import numpy as np
 import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from tests.golden.fixture_io import load_fixture, save_fixture  # noqa: E402
 
 HERE = Path(__file__).resolve().parent
 REF_SRC = Path("/root/reference/src")
@@ -185,7 +188,7 @@ def unet_case(nd, cfg: dict, name: str, B: int, HW: int, with_y: bool):
     gnorm = {k: float(p.grad.norm()) for k, p in net.named_parameters()}
     fixture = dict(cfg=cfg, x=x, noise=noise, context=ctx, y=y, sigma=sigma, sigma_table=table, c_noise_idx=idx, z_t=z_t.detach(), F_out=f_out,
                    D_out=d_out.detach(), loss=loss.detach(), grads=grads, grad_norms=gnorm)
-    torch.save(fixture, HERE / f"{name}.pt")
+    save_fixture(fixture, f"{name}")
     (HERE / f"{name}_keys.json").write_text(json.dumps(shapes, indent=0))
     print(f"{name}: loss={loss.tolist()} params={sum(int(torch.tensor(s).prod()) for s in shapes.values())}")
 
@@ -199,7 +202,7 @@ def vae_case(nmodel):
     with torch.no_grad():
         z = enc(img, regularize=True)
         moments = enc(img, regularize=False)
-    torch.save(dict(cfg=VAE_TINY, image=img, z=z, moments=moments), HERE / "vae_encoder_tiny.pt")
+    save_fixture(dict(cfg=VAE_TINY, image=img, z=z, moments=moments), "vae_encoder_tiny")
     (HERE / "vae_encoder_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
     print("vae: z", tuple(z.shape), float(z.abs().mean()))
 
@@ -212,7 +215,7 @@ def op_cases(nd):
     emb = timestep_embedding(t, 320)
     disc = nd.LegacyDDPMDiscretization()
     table = disc(1000, do_append_zero=False, flip=False).detach()
-    torch.save(dict(t=t, emb320=emb, ddpm_table=table), HERE / "glue_vectors.pt")
+    save_fixture(dict(t=t, emb320=emb, ddpm_table=table), "glue_vectors")
     print("glue: table", table.shape, float(table[0]), float(table[-2]), float(table[-1]))
 
 
@@ -244,7 +247,7 @@ def adafactor_case():
             states.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()})
         out[tag] = dict(kwargs=kw, shapes=shapes, init=init, grads=grads, after=after, states=states)
         print("adafactor", tag, "lr of p0 after 3 steps:", opt._get_lr(opt.param_groups[0], opt.state[params[0]]))
-    torch.save(out, HERE / "adafactor_steps.pt")
+    save_fixture(out, "adafactor_steps")
 
 
 def conditioner_case():
@@ -276,7 +279,7 @@ def conditioner_case():
     ])
     out = cond(batch)
     zero = cond(batch, force_zero_embeddings=["pooled_g", "crop_coords_top_left"])
-    torch.save(dict(batch=batch, out=out, zero=zero), HERE / "conditioner_sdxl.pt")
+    save_fixture(dict(batch=batch, out=out, zero=zero), "conditioner_sdxl")
     print("conditioner:", {k: tuple(v.shape) for k, v in out.items()})
 
 
@@ -289,7 +292,7 @@ def decoder_case(nmodel):
     z = torch.randn(2, 4, 8, 8, generator=g)
     with torch.no_grad():
         image = dec(z)
-    torch.save(dict(cfg=VAE_TINY, z=z, image=image), HERE / "vae_decoder_tiny.pt")
+    save_fixture(dict(cfg=VAE_TINY, z=z, image=image), "vae_decoder_tiny")
     (HERE / "vae_decoder_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
     print("decoder: image", tuple(image.shape), float(image.abs().mean()))
 
@@ -337,7 +340,7 @@ def vae_train_case(nmodel):
                                  grad_norms={k: float(p.grad.norm()) for k, p in named.items()})
         assert torch.allclose(z.detach(), moments[:, :4].detach() + torch.exp(0.5 * moments[:, 4:].detach().clamp(-30, 20)) * noise, atol=1e-6)
         print(f"vae train {tag}: loss={float(loss):.5f} kl={float(log['kl_loss']):.3f}")
-    torch.save(out, HERE / "vae_train_tiny.pt")
+    save_fixture(out, "vae_train_tiny")
     (HERE / "vae_train_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
 
 
@@ -392,7 +395,7 @@ def discriminator_case():
     g_loss = -disc(img).mean()
     g_loss.backward()
     out["generator"] = dict(g_loss=g_loss.detach(), d_image=img.grad.clone())
-    torch.save(out, HERE / "patchgan_tiny.pt")
+    save_fixture(out, "patchgan_tiny")
     (HERE / "patchgan_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
 
 
@@ -444,7 +447,7 @@ def glue_class_cases(nd):
     net = nd.UNetModel(**UNET_TINY).eval()
     shapes = json.loads((HERE / "unet_sdxl_tiny_keys.json").read_text())
     net.load_state_dict(synth_state_dict(shapes))
-    fx = torch.load(HERE / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     sigma = torch.tensor([0.35, 0.8])
     denoiser = nd.Denoiser(preconditioning=npre.RectifiedFlowComfyPreconditioning())
     weighting = nw.RectifiedFlowComfyWeighting()
@@ -457,7 +460,7 @@ def glue_class_cases(nd):
     out["rf"] = dict(sigma=sigma, z_t=z_t.detach(), F_out=eps_out.detach(), loss=loss.detach(),
                      grads={k: p.grad.detach().clone() for k, p in net.named_parameters() if k in GRAD_KEYS[:6]},
                      grad_norms={k: float(p.grad.norm()) for k, p in net.named_parameters()})
-    torch.save(out, HERE / "glue_classes.pt")
+    save_fixture(out, "glue_classes")
     print("glue classes:", {k: len(v) for k, v in out.items()}, "rf loss", loss.tolist())
 
 
@@ -536,7 +539,7 @@ def lpips_case():
         dist = lp(x, y)
         (dist.reshape(-1) * torch.tensor([1.0, 0.5])).sum().backward()
         lin = {k: v.clone() for k, v in lp.state_dict().items() if k.startswith("lin") and not k.startswith("lins")}
-        torch.save(dict(x=x, y=y.detach(), distance=dist.detach(), upstream=torch.tensor([1.0, 0.5]), d_y=y.grad.clone(), lin=lin), HERE / f"lpips_{kind}_tiny.pt")
+        save_fixture(dict(x=x, y=y.detach(), distance=dist.detach(), upstream=torch.tensor([1.0, 0.5]), d_y=y.grad.clone(), lin=lin), f"lpips_{kind}_tiny")
         (HERE / f"lpips_{kind}_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
         print(f"lpips[{kind}]:", dist.reshape(-1).tolist(), "grad norm", float(y.grad.norm()))
 
@@ -598,7 +601,7 @@ def sampler_cases(nd):
         with torch.no_grad():
             out[name] = sampler(analytic_denoiser, x0.clone(), cond, uc=uc)
         print(f"sampler {name}: |x|={float(out[name].abs().mean()):.5f}")
-    torch.save(out, HERE / "sampler_analytic.pt")
+    save_fixture(out, "sampler_analytic")
 
     torch.manual_seed(0)
     net = nd.UNetModel(**UNET_TINY).eval()
@@ -631,7 +634,7 @@ def sampler_cases(nd):
             final = sampler(denoiser_cb, noise.clone(), cond, uc=uc)
         fixture["runs"][name] = dict(cls=cls, steps=steps, scale=scale, trajectory=trajectory, final=final)
         print(f"unet sampler {name}: |x|={float(final.abs().mean()):.5f} steps={len(trajectory)}")
-    torch.save(fixture, HERE / "sampler_unet_tiny.pt")
+    save_fixture(fixture, "sampler_unet_tiny")
 
 
 HF_CLIP_TINY = dict(vocab_size=1000, hidden_size=64, intermediate_size=256, num_hidden_layers=4, num_attention_heads=4, max_position_embeddings=77,
@@ -737,7 +740,7 @@ def text_encoder_cases():
         with torch.no_grad():
             res = emb(prompts)
         out["openclip"][tag] = dict(layer=layer, return_pooled=pooled, legacy=legacy, result=res)
-    torch.save(out, HERE / "text_encoders_tiny.pt")
+    save_fixture(out, "text_encoders_tiny")
     (HERE / "text_encoders_tiny_keys.json").write_text(json.dumps({"hf": hf_shapes, "openclip": oc_shapes}, indent=0))
     print("text encoders: hf", tuple(full.last_hidden_state.shape), "openclip pooled", tuple(out["openclip"]["penultimate_pooled"]["result"][1].shape))
 
@@ -800,7 +803,7 @@ def dataset_cases():
                 epochs.append(list(sampler))
             per_rank.append(epochs)
         out["sampler"][(world, drop_last, shuffle)] = per_rank
-    torch.save(out, HERE / "dataset_aspect.pt")
+    save_fixture(out, "dataset_aspect")
     print("dataset: lists", {k: len(v) for k, v in out["lists"].items()}, "batches", {k: len(v) for k, v in out["schedule"].items()})
 
 
@@ -871,7 +874,7 @@ def loss_class_case(nd):
                                  grad_norms=gnorm, offset_seed=SEED + 1, offset_out=offset_out, weighting=type(weighting).__name__,
                                  denoiser="rf" if kw["objective_type"] == "rf" else "discrete_eps")
         print(f"loss_class {tag}: loss={loss.tolist()}")
-    torch.save(out, HERE / "loss_class_tiny.pt")
+    save_fixture(out, "loss_class_tiny")
 
 
 def engine_case(nd, nmodel):
@@ -923,9 +926,8 @@ def engine_case(nd, nmodel):
     loss_mean.backward()
     grads = {k: p_.grad.detach().clone() for k, p_ in net.named_parameters() if k in GRAD_KEYS}
     sd_keys = sorted(k for k in eng.state_dict().keys())
-    torch.save(dict(unet_cfg=UNET_TINY, vae_cfg=VAE_TINY, image=image, crossattn=batch["crossattn"], vector=batch["vector"], sigma=sig, noise=noise,
-                    latents=latents, loss_mean=loss_mean.detach(), logged=logged, grads=grads, scale_factor=0.13025, vae_batch_size=2, seed=SEED),
-               HERE / "engine_tiny.pt")
+    save_fixture(dict(unet_cfg=UNET_TINY, vae_cfg=VAE_TINY, image=image, crossattn=batch["crossattn"], vector=batch["vector"], sigma=sig, noise=noise,
+                    latents=latents, loss_mean=loss_mean.detach(), logged=logged, grads=grads, scale_factor=0.13025, vae_batch_size=2, seed=SEED), "engine_tiny")
     (HERE / "engine_tiny_keys.json").write_text(json.dumps({"unet": ushapes, "vae": vshapes, "engine_state_dict_keys": sd_keys}, indent=0))
     print(f"engine: latents {tuple(latents.shape)} loss_mean={float(loss_mean):.6f} logged={ {k: float(v) for k, v in logged.items()} } state_dict keys={len(sd_keys)}")
 

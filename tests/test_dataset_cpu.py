@@ -9,8 +9,9 @@ import torch
 
 from neurosis_amd.dataset import AspectBucketList, AspectDistributedSampler, SDXLBucketList, bucket_batch_schedule, collate_bucket_batch
 from tests.golden.make_golden import BUCKET_LIST_CASES, BUCKET_RATIOS, bucket_assignment
+from tests.golden.fixture_io import load_fixture
 
-G = torch.load(Path(__file__).resolve().parent / "golden" / "dataset_aspect.pt", weights_only=False)
+G = load_fixture("dataset_aspect")
 
 
 def _build(name):

@@ -15,6 +15,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from tests.golden.fixture_io import load_fixture
 
 G = Path(__file__).resolve().parent / "golden"
 
@@ -67,7 +68,7 @@ def _worker_oracle(rank, world, port, out):
     from oracle import sdxl_oracle as O
     from tests.golden.make_golden import synth_state_dict
 
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     names = list(shapes)
     table = O.legacy_ddpm_sigmas()

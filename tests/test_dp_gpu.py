@@ -10,6 +10,7 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -52,7 +53,7 @@ def _worker(rank, world, port, out, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from neurosis_amd.dp import FlatDataParallel
 
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     eng = _build(fx, shapes)
     dp = FlatDataParallel(eng.model.diffusion_model, eng.store)
@@ -117,7 +118,7 @@ def _worker_modes(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from neurosis_amd.dp import FlatDataParallel
 
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     res = {}
     # ("again" repeats the default configuration: the run-to-run noise floor -- 0.0 on this fixture, none of whose launches splits K)
@@ -190,7 +191,7 @@ def test_engine_accumulate_helper_overwrites_then_adds():
     ones add; optimizer_step() resets the mode."""
     from neurosis_amd import ops
 
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     eng = _build(fx, shapes)
     sel = slice(0, 2)
@@ -215,7 +216,7 @@ def test_optimizer_on_its_own_stream_equals_in_line(optimizer):
     """optimizer_step() runs on a second stream and is joined where the next UNet forward starts: three training steps give
     the parameters the in-line order gives (same kernels on the same data; tolerance covers the fp32 atomics of split-K weight
     gradients, which differ run to run either way), and nothing reads the weights before the join."""
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     finals, losses = [], []
     for overlap in (True, False):
@@ -245,7 +246,7 @@ def test_streamed_optimizer_equals_the_one_shot_update():
     """DiffusionEngine streams the fused Adafactor update of each top-level block behind that block's backward (its own stream,
     _grads_ready): three steps must give the parameters, optimizer state and losses of the one-shot update after backward
     (same kernels on the same data; tolerance covers the fp32 atomics of the split-K weight gradients)."""
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     finals, states, losses = [], [], []
     for streamed in (True, False):
@@ -282,7 +283,7 @@ def _worker_health(rank, world, port, out):
     from neurosis_amd import lib
     from neurosis_amd.dp import FlatDataParallel
 
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     eng = _build(fx, shapes)
     eng.overlap_optimizer = False

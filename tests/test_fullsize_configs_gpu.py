@@ -17,6 +17,7 @@ import pytest
 import torch
 
 from tests.util import cosine, rel_err
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -88,7 +89,7 @@ def test_config5_autoencoder_training_256_batch_4_with_lpips_and_patchgan():
     from oracle import patchgan_oracle as PO
     from tests.test_lpips_cpu import trunk_weights
 
-    lfx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "lpips_vgg_tiny.pt"), weights_only=False)
+    lfx = load_fixture("lpips_vgg_tiny")
     loss = GeneralLPIPSWithDiscriminator(disc_start=0, disc_factor=0.5, disc_weight=0.8, perceptual_weight=0.6, logvar_init=0.1, rec_weight=1.2,
                                          lpips_kwargs=dict(pnet_type="vgg", lin_weights=lfx["lin"]))
     loss.perceptual_loss.load_state_dict(trunk_weights(), strict=False)          # synthetic trunk (the ImageNet weights are a download)

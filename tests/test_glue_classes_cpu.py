@@ -9,8 +9,9 @@ import torch
 import neurosis_amd.modules.diffusion as D
 from tests.golden.make_golden import GLUE_CLASSES, GLUE_SIGMAS, GLUE_T
 from tests.util import rel_err
+from tests.golden.fixture_io import load_fixture
 
-FX = torch.load(Path(__file__).resolve().parent / "golden" / "glue_classes.pt", weights_only=False)
+FX = load_fixture("glue_classes")
 SIG = torch.tensor(GLUE_SIGMAS)
 COMFY = torch.tensor([0.001, 0.1, 0.37, 0.5, 0.93, 0.999])
 T = torch.tensor(GLUE_T, dtype=torch.float64)

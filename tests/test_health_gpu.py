@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from tests.golden.make_golden import UNET_TINY, synth_state_dict
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -44,7 +45,7 @@ def test_flagged_backward_is_not_applied_and_is_reported(opt):
     from neurosis_amd import lib, ops
     from neurosis_amd.optimizers import Adafactor, AdamW
 
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     eng = _engine(partial(Adafactor, scale_parameter=True, relative_step=True, warmup_init=True) if opt == "adafactor" else partial(AdamW, lr=1e-3))
     batch = {"crossattn": fx["context"].cuda(), "vector": fx["y"].cuda()}
 

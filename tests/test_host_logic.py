@@ -8,6 +8,7 @@ import torch
 
 import neurosis_amd.modules.diffusion as D
 from tests.golden.make_golden import UNET_SD15_TINY, UNET_TINY, VAE_TINY, synth_state_dict
+from tests.golden.fixture_io import load_fixture
 
 G = Path(__file__).resolve().parent / "golden"
 
@@ -36,7 +37,7 @@ def test_full_size_sdxl_topology_on_meta():
 
 
 def test_sigma_table_and_denoiser_coefficients():
-    fx = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)
+    fx = load_fixture("unet_sdxl_tiny")
     den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization())
     assert torch.equal(den.sigmas, fx["sigma_table"])  # 1001 entries, trailing 0.0 (quirk Q1)
     assert not den.sigmas.requires_grad  # detached (quirk Q5)

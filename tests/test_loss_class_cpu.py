@@ -10,6 +10,7 @@ import torch
 
 from oracle import sdxl_oracle as O
 from tests.golden.make_golden import LOSS_CLASS_CASES, UNET_TINY, VAE_TINY, synth_state_dict
+from tests.golden.fixture_io import load_fixture
 
 G = Path(__file__).parent / "golden"
 TOL = 1e-5
@@ -21,7 +22,7 @@ def rel(a, b):
 
 @pytest.fixture(scope="module")
 def fx():
-    return torch.load(G / "loss_class_tiny.pt", weights_only=False)
+    return load_fixture("loss_class_tiny")
 
 
 @pytest.fixture(scope="module")
@@ -66,7 +67,7 @@ def test_apply_noise_offset_matches_reference_under_the_same_seed(fx):
 
 def test_oracle_training_step_matches_reference_engine():
     """DiffusionEngine.encode_first_stage (chunked by vae_batch_size) and training_step of the reference itself"""
-    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    e = load_fixture("engine_tiny")
     keys = json.loads((G / "engine_tiny_keys.json").read_text())
     usd = synth_state_dict(keys["unet"])
     vsd_all = synth_state_dict(keys["vae"])

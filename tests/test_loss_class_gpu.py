@@ -12,6 +12,7 @@ import torch
 
 from tests.golden.make_golden import LOSS_CLASS_CASES, UNET_TINY, VAE_TINY, synth_state_dict
 from tests.util import check_grad_cosines, cosine, rel_err
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -31,7 +32,7 @@ def _unet(store=True):
 def test_hip_loss_class_matches_the_reference_class(tag):
     import neurosis_amd.modules.diffusion as D
 
-    fx = torch.load(G / "loss_class_tiny.pt", weights_only=False)
+    fx = load_fixture("loss_class_tiny")
     case = fx["cases"][tag]
     kw = case["kwargs"]
     net, st = _unet()
@@ -80,7 +81,7 @@ def _engine(**kw):
 
 
 def test_engine_methods_match_the_reference_engine():
-    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    e = load_fixture("engine_tiny")
     eng = _engine()
     batch = {"image": e["image"].cuda(), "crossattn": e["crossattn"].cuda(), "vector": e["vector"].cuda()}
     latents = eng.encode_first_stage(eng.get_input(batch))          # 3 images in chunks of vae_batch_size = 2
@@ -103,7 +104,7 @@ def test_optimizer_and_ema_state_survive_a_checkpoint_round_trip():
     optimizer state and EMA.  The EMA entries carry LitEma's names (modules/ema.py:23-29)."""
     from neurosis_amd.optimizers import Adafactor, AdafactorScheduler
 
-    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    e = load_fixture("engine_tiny")
     mk = lambda: _engine(optimizer=partial(Adafactor, scale_parameter=True, relative_step=True, warmup_init=True),
                          scheduler=partial(AdafactorScheduler, initial_lr=4e-7), use_ema=True, ema_decay_rate=0.99)
     batch = lambda: {"image": e["image"].cuda(), "crossattn": e["crossattn"].cuda(), "vector": e["vector"].cuda()}
@@ -180,7 +181,7 @@ def test_lightning_adapter_step_logic_with_a_stand_in_trainer():
     from neurosis_amd.optimizers import Adafactor
     from neurosis_amd.trainer import DiffusionEngineMI355X
 
-    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    e = load_fixture("engine_tiny")
     keys = json.loads((G / "engine_tiny_keys.json").read_text())
     net = D.UNetModel(**UNET_TINY)
     net.load_state_dict(synth_state_dict(keys["unet"]))
@@ -221,7 +222,7 @@ def test_lightning_adapter_applies_a_checkpoint_that_arrives_before_fit_start():
     from neurosis_amd.optimizers import Adafactor
     from neurosis_amd.trainer import DiffusionEngineMI355X
 
-    e = torch.load(G / "engine_tiny.pt", weights_only=False)
+    e = load_fixture("engine_tiny")
     keys = json.loads((G / "engine_tiny_keys.json").read_text())
 
     def mk():

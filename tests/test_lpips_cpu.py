@@ -8,6 +8,7 @@ import torch
 from oracle import lpips_oracle as LO
 from tests.golden.make_golden import synth_state_dict
 from tests.util import rel_err
+from tests.golden.fixture_io import load_fixture
 
 G = Path(__file__).resolve().parent / "golden"
 
@@ -19,7 +20,7 @@ def trunk_weights(kind="vgg"):
 
 @pytest.mark.parametrize("kind", ["vgg", "alex"])
 def test_lpips_oracle_distance_and_gradient(kind):
-    fx = torch.load(G / f"lpips_{kind}_tiny.pt", weights_only=False)
+    fx = load_fixture(f"lpips_{kind}_tiny")
     y = fx["y"].clone().requires_grad_(True)
     dist = LO.lpips(trunk_weights(kind), fx["lin"], fx["x"], y, trunk=kind)
     assert dist.shape == fx["distance"].shape and rel_err(dist, fx["distance"]) < 1e-5

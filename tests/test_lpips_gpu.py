@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from tests.golden.make_golden import synth_state_dict
 from tests.util import cosine, rel_err
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -73,7 +74,7 @@ def test_lpips_layer_kernel(C, HW):
 def _lpips(kind="vgg"):
     from neurosis_amd.modules.losses import LPIPS
 
-    fx = torch.load(G / f"lpips_{kind}_tiny.pt", weights_only=False)
+    fx = load_fixture(f"lpips_{kind}_tiny")
     shapes = json.loads((G / f"lpips_{kind}_tiny_keys.json").read_text())
     lp = LPIPS(pnet_type=kind, lin_weights=fx["lin"])
     lp.load_state_dict({k: v * 1.6 for k, v in synth_state_dict(shapes).items()}, strict=False)

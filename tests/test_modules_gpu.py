@@ -14,6 +14,7 @@ import torch
 
 from tests.golden.make_golden import synth_state_dict
 from tests.util import bf16_round, check_grad_cosines, cosine, rel_err
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -23,7 +24,7 @@ def _build_unet(name, store, **override):
     import neurosis_amd.modules.diffusion as D
     from neurosis_amd.nn import FlatParamStore
 
-    fx = torch.load(G / f"{name}.pt", weights_only=False)
+    fx = load_fixture(f"{name}")
     shapes = json.loads((G / f"{name}_keys.json").read_text())
     cfg = dict(fx["cfg"])
     cfg.update(override)
@@ -124,7 +125,7 @@ def test_gradient_accumulation_and_adamw():
 def test_vae_encoder_against_reference_golden():
     import neurosis_amd.modules.diffusion as D
 
-    fx = torch.load(G / "vae_encoder_tiny.pt", weights_only=False)
+    fx = load_fixture("vae_encoder_tiny")
     shapes = json.loads((G / "vae_encoder_tiny_keys.json").read_text())
     enc = D.Encoder(**fx["cfg"])
     enc.load_state_dict(synth_state_dict(shapes))
@@ -218,7 +219,7 @@ def test_general_conditioner_against_reference_golden():
     force_zero_embeddings, against the reference's GeneralConditioner (fixture from make_golden.py::conditioner_case)."""
     from neurosis_amd.modules.encoders import ConcatTimestepEmbedderND, GeneralConditioner, PrecomputedEmbedder
 
-    fx = torch.load(G / "conditioner_sdxl.pt", weights_only=False)
+    fx = load_fixture("conditioner_sdxl")
     batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in fx["batch"].items()}
     cond = GeneralConditioner([
         PrecomputedEmbedder(input_key="tokens_l"), PrecomputedEmbedder(input_key="tokens_g"), PrecomputedEmbedder(input_key="pooled_g"),
@@ -242,7 +243,7 @@ def test_rectified_flow_objective_fused_against_reference():
     import neurosis_amd.modules.diffusion as D
 
     fx, net, st = _build_unet("unet_sdxl_tiny", True)
-    rf = torch.load(G / "glue_classes.pt", weights_only=False)["rf"]
+    rf = load_fixture("glue_classes")["rf"]
     den = D.Denoiser(preconditioning=D.RectifiedFlowComfyPreconditioning())
     lossfn = D.StandardDiffusionLoss(sigma_generator=D.RectifiedFlowComfySigmaGenerator(), loss_weighting=D.RectifiedFlowComfyWeighting(), objective_type="rf")
     cond = {"crossattn": fx["context"].cuda(), "vector": fx["y"].cuda()}

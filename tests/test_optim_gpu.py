@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from tests.util import rel_err
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).parent / "golden"
@@ -29,7 +30,7 @@ def set_grads(params, grads, scale=1.0):
 def test_flat_adafactor_matches_reference_steps(tag):
     from neurosis_amd.optim import FlatAdafactor
 
-    c = torch.load(GOLD / "adafactor_steps.pt", weights_only=False)[tag]
+    c = load_fixture("adafactor_steps")[tag]
     store, params = make_store(c["init"])
     opt = FlatAdafactor(store, chunk_bytes=8 << 10, **c["kwargs"])   # tiny chunks: several chunks even for this small set
     assert len(opt.chunks) > 2

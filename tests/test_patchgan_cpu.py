@@ -9,9 +9,10 @@ import torch
 from oracle import patchgan_oracle as PO
 from tests.golden.make_golden import disc_state_dict
 from tests.util import rel_err
+from tests.golden.fixture_io import load_fixture
 
 G = Path(__file__).resolve().parent / "golden"
-FX = torch.load(G / "patchgan_tiny.pt", weights_only=False)
+FX = load_fixture("patchgan_tiny")
 SHAPES = json.loads((G / "patchgan_tiny_keys.json").read_text())
 
 

@@ -18,6 +18,7 @@ import torch
 
 from tests.golden.make_golden import disc_state_dict
 from tests.util import cosine, rel_err
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -63,7 +64,7 @@ def test_leaky_relu_kernels():
 def _disc():
     from neurosis_amd.modules.losses import NLayerDiscriminator
 
-    fx = torch.load(G / "patchgan_tiny.pt", weights_only=False)
+    fx = load_fixture("patchgan_tiny")
     shapes = json.loads((G / "patchgan_tiny_keys.json").read_text())
     disc = NLayerDiscriminator(**fx["cfg"])
     disc.load_state_dict(disc_state_dict(shapes), strict=False)

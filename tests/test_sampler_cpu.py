@@ -11,6 +11,7 @@ from oracle import sampler_oracle as SO
 from oracle import sdxl_oracle as O
 from tests.golden.make_golden import SAMPLER_CASES, analytic_denoiser, sampler_inputs, seeded_noise_sampler, synth_state_dict
 from tests.util import rel_err
+from tests.golden.fixture_io import load_fixture
 
 G = Path(__file__).resolve().parent / "golden"
 TOL = 2e-6
@@ -39,7 +40,7 @@ def _oracle_run(name):
 
 @pytest.mark.parametrize("name", sorted(SAMPLER_CASES))
 def test_oracle_samplers_match_reference(name):
-    want = torch.load(G / "sampler_analytic.pt", weights_only=False)[name]
+    want = load_fixture("sampler_analytic")[name]
     assert rel_err(_oracle_run(name), want) < TOL
 
 
@@ -58,7 +59,7 @@ def product_sampler(name, device="cpu"):
 
 @pytest.mark.parametrize("name", sorted(SAMPLER_CASES))
 def test_product_samplers_match_reference_on_cpu(name):
-    want = torch.load(G / "sampler_analytic.pt", weights_only=False)[name]
+    want = load_fixture("sampler_analytic")[name]
     x0, cond, uc = sampler_inputs()
     torch.manual_seed(4321)
     with torch.no_grad():
@@ -76,10 +77,10 @@ def test_sampling_sigma_table_matches_product_discretization():
 def test_oracle_unet_sampling_trajectories():
     """Euler+CFG, Heun+CFG and plain Euler through the oracle UNet and the oracle eps-denoiser against the reference's
     trajectories (tiny SDXL-style UNet, 16x16 latents)."""
-    fx = torch.load(G / "sampler_unet_tiny.pt", weights_only=False)
+    fx = load_fixture("sampler_unet_tiny")
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
     sd = synth_state_dict(shapes)
-    cfg = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)["cfg"]
+    cfg = load_fixture("unet_sdxl_tiny")["cfg"]
     table = O.legacy_ddpm_sigmas()
 
     def denoiser(x, sigma, c):
@@ -97,6 +98,6 @@ def test_oracle_unet_sampling_trajectories():
 
 
 def test_oracle_vae_decoder():
-    fx = torch.load(G / "vae_decoder_tiny.pt", weights_only=False)
+    fx = load_fixture("vae_decoder_tiny")
     sd = synth_state_dict(json.loads((G / "vae_decoder_tiny_keys.json").read_text()))
     assert rel_err(O.vae_decode(sd, fx["cfg"], fx["z"]), fx["image"]) < 1e-5

@@ -15,6 +15,7 @@ import torch
 from tests.golden.make_golden import SAMPLER_CASES, analytic_denoiser, sampler_inputs, synth_state_dict
 from tests.test_sampler_cpu import product_sampler
 from tests.util import cosine, rel_err
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -82,7 +83,7 @@ def test_sample_kernels_reject_bad_shapes():
 @pytest.mark.parametrize("name", sorted(n for n in SAMPLER_CASES if "churn" not in n))
 def test_sampler_classes_on_device_match_reference(name):
     """(the churn case draws torch.randn_like from the device generator and is pinned on the CPU only)"""
-    want = torch.load(G / "sampler_analytic.pt", weights_only=False)[name]
+    want = load_fixture("sampler_analytic")[name]
     x0, cond, uc = sampler_inputs()
     cond, uc = ({k: v.cuda() for k, v in d.items()} for d in (cond, uc))
     with torch.no_grad():
@@ -95,7 +96,7 @@ def _tiny_engine(sampler):
     from neurosis_amd.models.diffusion import DiffusionEngine
 
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
-    cfg = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)["cfg"]
+    cfg = load_fixture("unet_sdxl_tiny")["cfg"]
     net = D.UNetModel(**cfg)
     net.load_state_dict(synth_state_dict(shapes))
     den = D.DiscreteDenoiser(preconditioning=D.EpsPreconditioning(), num_idx=1000, discretization=D.LegacyDDPMDiscretization())
@@ -108,7 +109,7 @@ def test_fused_unet_sampling_against_reference_trajectory(run):
     import neurosis_amd.modules.diffusion.sampling as S
     from neurosis_amd.modules.guidance import VanillaCFG
 
-    fx = torch.load(G / "sampler_unet_tiny.pt", weights_only=False)
+    fx = load_fixture("sampler_unet_tiny")
     ref = fx["runs"][run]
     sampler = getattr(S, ref["cls"])(discretization=D.LegacyDDPMDiscretization(), guider=None if ref["scale"] is None else VanillaCFG(ref["scale"]),
                                      num_steps=ref["steps"])
@@ -150,7 +151,7 @@ def test_fused_route_equals_generic_route_on_the_same_network():
     import neurosis_amd.modules.diffusion.sampling as S
     from neurosis_amd.modules.guidance import VanillaCFG
 
-    fx = torch.load(G / "sampler_unet_tiny.pt", weights_only=False)
+    fx = load_fixture("sampler_unet_tiny")
     sampler = S.EulerEDMSampler(discretization=D.LegacyDDPMDiscretization(), guider=VanillaCFG(5.0), num_steps=4)
     engine = _tiny_engine(sampler)
     cond, uc = ({k: v.cuda() for k, v in d.items()} for d in (fx["cond"], fx["uc"]))
@@ -173,7 +174,7 @@ def test_captured_step_equals_eager_step_and_survives_weight_updates():
     from neurosis_amd import ops
     from neurosis_amd.modules.guidance import VanillaCFG
 
-    fx = torch.load(G / "sampler_unet_tiny.pt", weights_only=False)
+    fx = load_fixture("sampler_unet_tiny")
     sampler = S.EulerEDMSampler(discretization=D.LegacyDDPMDiscretization(), guider=VanillaCFG(5.0), num_steps=4)
     engine = _tiny_engine(sampler)
     cond, uc = ({k: v.cuda() for k, v in d.items()} for d in (fx["cond"], fx["uc"]))
@@ -208,7 +209,7 @@ def test_captured_step_sees_a_store_refresh_of_the_channel_padded_convs():
     from neurosis_amd.modules.guidance import VanillaCFG
     from neurosis_amd.nn import FlatParamStore
 
-    fx = torch.load(G / "sampler_unet_tiny.pt", weights_only=False)
+    fx = load_fixture("sampler_unet_tiny")
     sampler = S.EulerEDMSampler(discretization=D.LegacyDDPMDiscretization(), guider=VanillaCFG(5.0), num_steps=3)
     engine = _tiny_engine(sampler)
     store = FlatParamStore(engine.model.parameters())
@@ -229,7 +230,7 @@ def test_captured_step_sees_a_store_refresh_of_the_channel_padded_convs():
 def test_vae_decoder_against_reference_golden():
     import neurosis_amd.modules.diffusion as D
 
-    fx = torch.load(G / "vae_decoder_tiny.pt", weights_only=False)
+    fx = load_fixture("vae_decoder_tiny")
     dec = D.Decoder(**fx["cfg"])
     dec.load_state_dict(synth_state_dict(json.loads((G / "vae_decoder_tiny_keys.json").read_text())))
     dec = dec.cuda()
@@ -253,10 +254,10 @@ def test_engine_decode_and_log_images_round_trip():
     from neurosis_amd.modules.guidance import VanillaCFG
 
     shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
-    cfg = torch.load(G / "unet_sdxl_tiny.pt", weights_only=False)["cfg"]
+    cfg = load_fixture("unet_sdxl_tiny")["cfg"]
     net = D.UNetModel(**cfg)
     net.load_state_dict(synth_state_dict(shapes))
-    dd = dict(torch.load(G / "vae_decoder_tiny.pt", weights_only=False)["cfg"])
+    dd = dict(load_fixture("vae_decoder_tiny")["cfg"])
     dd.pop("embed_dim")
     vae = AutoencoderKL(embed_dim=4, ddconfig=dd)
     enc_sd = synth_state_dict(json.loads((G / "vae_encoder_tiny_keys.json").read_text()))
@@ -273,7 +274,7 @@ def test_engine_decode_and_log_images_round_trip():
     batch = {"image": (torch.rand(2, 3, 128, 128, generator=g) * 2 - 1).cuda(), "crossattn": torch.randn(2, 7, cfg["context_dim"], generator=g).cuda(),
              "vector": torch.randn(2, cfg["adm_in_channels"], generator=g).cuda()}
     z = engine.encode_first_stage(batch["image"])
-    fx_dec = torch.load(G / "vae_decoder_tiny.pt", weights_only=False)
+    fx_dec = load_fixture("vae_decoder_tiny")
     direct = engine.vae_decoder(fx_dec["z"].cuda())
     assert rel_err(engine.decode_first_stage(fx_dec["z"].cuda() * 0.13025), direct) <= 1e-6
     out = engine.log_images(batch, num_img=2)

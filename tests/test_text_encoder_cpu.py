@@ -9,13 +9,14 @@ import torch
 from oracle import clip_oracle as CO
 from tests.golden.make_golden import synth_state_dict
 from tests.util import rel_err
+from tests.golden.fixture_io import load_fixture
 
 G = Path(__file__).resolve().parent / "golden"
 TOL = 1e-5
 
 
 def _fx():
-    fx = torch.load(G / "text_encoders_tiny.pt", weights_only=False)
+    fx = load_fixture("text_encoders_tiny")
     shapes = json.loads((G / "text_encoders_tiny_keys.json").read_text())
     return fx, synth_state_dict(shapes["hf"]), synth_state_dict(shapes["openclip"])
 

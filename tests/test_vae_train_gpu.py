@@ -14,6 +14,7 @@ import torch
 
 from tests.golden.make_golden import synth_state_dict
 from tests.util import check_grad_cosines, cosine, rel_err
+from tests.golden.fixture_io import load_fixture
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
@@ -23,7 +24,7 @@ def _engine(loss="l2", **kw):
     from neurosis_amd.models.autoencoder import AutoencodingEngine, DiagonalGaussianRegularizer
     from neurosis_amd.modules.diffusion.model import Decoder, Encoder
 
-    fx = torch.load(G / "vae_train_tiny.pt", weights_only=False)
+    fx = load_fixture("vae_train_tiny")
     sd = synth_state_dict(json.loads((G / "vae_train_tiny_keys.json").read_text()))
     eng = AutoencodingEngine(encoder=Encoder(**fx["cfg"]), decoder=Decoder(**fx["cfg"]), loss=loss, regularizer=DiagonalGaussianRegularizer(sample=True), **kw)
     eng.load_state_dict({**eng.state_dict(), **sd})
@@ -63,7 +64,7 @@ def test_unfused_attention_backward_vs_autograd():
 
 @pytest.mark.parametrize("tag", ["rec_only", "rec_kl"])
 def test_reconstruction_step_against_reference(tag):
-    fx0 = torch.load(G / "vae_train_tiny.pt", weights_only=False)
+    fx0 = load_fixture("vae_train_tiny")
     case = fx0["cases"][tag]
     fx, eng = _engine(regularization_weights={"kl_loss": case["kl_weight"]} if case["kl_weight"] else None)
     loss, z, xrec, reg_log = eng.loss_and_backward(fx["x"].cuda(), noise=case["noise"].cuda())
@@ -114,9 +115,9 @@ def _gan_engine(**kw):
     from neurosis_amd.modules.losses import NLayerDiscriminator
     from tests.golden.make_golden import disc_state_dict
 
-    fx = torch.load(G / "vae_train_tiny.pt", weights_only=False)
+    fx = load_fixture("vae_train_tiny")
     sd = synth_state_dict(json.loads((G / "vae_train_tiny_keys.json").read_text()))
-    dfx = torch.load(G / "patchgan_tiny.pt", weights_only=False)
+    dfx = load_fixture("patchgan_tiny")
     dsd = disc_state_dict(json.loads((G / "patchgan_tiny_keys.json").read_text()))
     disc = NLayerDiscriminator(**dfx["cfg"])
     disc.load_state_dict(dsd, strict=False)
@@ -186,7 +187,7 @@ def test_perceptual_term_in_the_generator_step_vs_oracle():
     from oracle import patchgan_oracle as PO
     from tests.test_lpips_cpu import trunk_weights
 
-    lfx = torch.load(G / "lpips_vgg_tiny.pt", weights_only=False)
+    lfx = load_fixture("lpips_vgg_tiny")
     lp = LPIPS(pnet_type="vgg", lin_weights=lfx["lin"])
     lp.load_state_dict(trunk_weights(), strict=False)
     fx, sd, dsd, eng = _gan_engine(disc_factor=0.5, perceptual_loss=lp.cuda(), perceptual_weight=0.8, logvar_init=0.1)
