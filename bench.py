@@ -100,14 +100,28 @@ def synthetic_batch(device, batch, hw, gen, precomputed_te=True):
     length = torch.randint(5, 76, (batch, 1), device=device, generator=gen)
     ids = torch.where(torch.arange(77, device=device)[None] >= length, torch.full_like(ids, 49407), ids)
     ids[:, 0] = 49406
-    size = torch.tensor([[float(H), float(W)]] * batch, device=device)
+    size = _size_tensor(device, batch, H, W)
     return {"image": image, "caption_ids": ids, "original_size_as_tuple": size, "crop_coords_top_left": torch.zeros_like(size), "target_size_as_tuple": size}
 
 
-def draw_sigmas(batch, gen_cpu, device):
-    """sigma = exp(-1.2 + 1.2 n), clipped to the LegacyDDPM table range (the denoiser snaps it)."""
-    n = torch.randn(batch, generator=gen_cpu)
-    return (-1.2 + 1.2 * n).exp().clamp(0.0292, 14.61).to(device)
+_SIZE_CACHE = {}
+
+
+def _size_tensor(device, batch, H, W):
+    """[batch, 2] fp32 (H, W) on the device, built once per bucket: a fresh torch.tensor(list, device=...) is a pageable host-to-device copy,
+    which makes the HOST wait for everything queued on the stream -- once per step that cost the launching thread its whole lead over the
+    GPU (tools/sync_debug.py; round 4)."""
+    key = (str(device), batch, H, W)
+    if key not in _SIZE_CACHE:
+        _SIZE_CACHE[key] = torch.tensor([[float(H), float(W)]] * batch, device=device)
+    return _SIZE_CACHE[key]
+
+
+def draw_sigmas(batch, gen, device):
+    """sigma = exp(-1.2 + 1.2 n), clipped to the LegacyDDPM table range (the denoiser snaps it).  Drawn ON the device: a CPU
+    draw copied over is a synchronising host-to-device copy (see _size_tensor)."""
+    n = torch.randn(batch, device=device, generator=gen)
+    return (-1.2 + 1.2 * n).exp().clamp(0.0292, 14.61)
 
 
 class GemmTimer:
@@ -390,7 +404,7 @@ def main():
             if force_hw is not None:
                 hw = force_hw
             batch = synthetic_batch(device, args.batch, hw, gen, args.precomputed_te)
-            sig = draw_sigmas(args.batch, gen_cpu, device)
+            sig = draw_sigmas(args.batch, gen, device)
             eng.accumulate(mb, dp, last=mb == args.accumulate - 1)
             loss = eng.training_step(batch, 0, sigmas=sig)
             (loss / args.accumulate).backward()
@@ -434,11 +448,14 @@ def main():
         dp.reducer.record_timing = True
         dp.reducer.take_counts()       # count the timed steps' collectives only
     barrier()
+    if os.environ.get("NK_SYNC_DEBUG_AFTER_WARMUP") == "1":      # tools/sync_debug.py: report every host-synchronising call of the timed steps
+        torch.cuda.set_sync_debug_mode("warn")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step(mark=True)
     end_mark = torch.cuda.Event(enable_timing=True)
     end_mark.record()
+    torch.cuda.set_sync_debug_mode("default")
     barrier()
     dt = time.perf_counter() - t0
     if dp is not None:

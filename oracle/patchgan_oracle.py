@@ -46,9 +46,11 @@ def disc_loss(kind: str, real: Tensor, fake: Tensor) -> Tensor:
 def generator_adversarial_loss(enc_sd: dict, dec_sd: dict, disc_sd: dict, dd: dict, x: Tensor, noise: Tensor, rec_weight: float = 1.0, logvar: float = 0.0,
                                disc_factor: float = 1.0, disc_weight: float = 1.0, n_layers: int = 3, lpips=None, perceptual_weight: float = 1.0):
     """The autoencoder's side of GeneralLPIPSWithDiscriminator with perceptual_weight = 0 (discriminator_loss.py:205-233,
-    247-286), as its terms spell it out -- NOTE: the reference's own forward raises for this branch (`weights > 0` with
-    weights = None at :298, and the loss it builds at :276 is an un-reduced tensor), so this half is NOT pinned by reference
-    fixtures; it follows the taming-transformers / generative-models formula the reference was reworked from:
+    247-286), as its terms spell it out -- NOTE: as its engine calls it (weights = None) the reference's own forward raises in this
+    branch (`if weights > 0` at :300) and the loss it builds at :281 is an un-reduced [B, C, H, W] tensor that manual_backward cannot
+    take.  Given a tensor `weights` the forward does run: its nll_loss, g_loss and adaptive weight are captured in
+    tests/golden/gan_generator_tiny (make_golden.py::gan_generator_case) and this function is checked against them
+    (tests/test_patchgan_cpu.py).  The TOTAL follows the taming-transformers / generative-models formula the reference was reworked from:
         nll = sum(rec_weight * (x - xrec)^2 / exp(logvar) + logvar) / B ;  g = -mean(D(xrec))
         d_w = clamp(||grad_W nll|| / (||grad_W g|| + 1e-4), 0, 1e4) * disc_weight,  W = decoder.conv_out.weight
         loss = nll + disc_factor * d_w * g

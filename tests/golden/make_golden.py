@@ -399,6 +399,48 @@ def discriminator_case():
     (HERE / "patchgan_tiny_keys.json").write_text(json.dumps(shapes, indent=0))
 
 
+def gan_generator_case(nmodel):
+    """The generator (autoencoder) branch of the reference's GeneralLPIPSWithDiscriminator.forward (discriminator_loss.py:229-303), run by
+    the reference itself on the tiny autoencoder + PatchGAN of the cases above.  As the reference's engine calls it -- weights=None -- the
+    branch raises at :300 (`if weights > 0` with None) and the value it returns at :281 is an UN-REDUCED tensor (p_rec_loss is [B,C,H,W]), on
+    which manual_backward cannot be called; with a tensor `weights = 1` the forward does run, and its pieces are what the fixture pins:
+    nll_loss (:263), g_loss (:270) and the adaptive weight (:272, calculate_adaptive_weight :196-208) on the decoder's last layer.  The
+    object is built without __init__ (which downloads LPIPS weights); perceptual_weight = 0 keeps LPIPS out of the branch."""
+    import neurosis.modules.autoencoding.losses.discriminator_loss as ndl
+    from neurosis.modules.losses.patchgan.model import NLayerDiscriminator
+    from neurosis.modules.regularizers import DiagonalGaussianRegularizer
+
+    hp = dict(disc_factor=0.7, disc_weight=0.9, rec_weight=0.02, logvar_init=2.5)       # (small nll gradients: the adaptive weight stays under its 1e4 clamp)
+    enc, dec = nmodel.Encoder(**VAE_TINY).train(), nmodel.Decoder(**VAE_TINY).train()
+    shapes = {f"encoder.{k}": list(v.shape) for k, v in enc.state_dict().items()}
+    shapes.update({f"decoder.{k}": list(v.shape) for k, v in dec.state_dict().items()})
+    sd = synth_state_dict(shapes)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")})
+    disc = NLayerDiscriminator(**DISC_TINY).train()
+    dshapes = {k: list(v.shape) for k, v in disc.state_dict().items()}
+    disc.load_state_dict(disc_state_dict(dshapes), strict=False)
+    loss = ndl.GeneralLPIPSWithDiscriminator.__new__(ndl.GeneralLPIPSWithDiscriminator)
+    torch.nn.Module.__init__(loss)
+    loss.dims, loss.scale_input_to_tgt_size, loss.perceptual_weight, loss.learn_logvar = 2, False, 0.0, False
+    loss.logvar = torch.nn.Parameter(torch.ones(size=()) * hp["logvar_init"])
+    loss.discriminator, loss.disc_start, loss.disc_factor, loss.discriminator_weight = disc, 0, hp["disc_factor"], hp["disc_weight"]
+    loss.rec_weight, loss.rec_loss_type, loss.regularization_weights, loss.additional_log_keys = hp["rec_weight"], "l2", {}, set()
+    loss.train()
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1                 # (the image of vae_train_case)
+    torch.manual_seed(2718)
+    noise = torch.randn(2, 4, 8, 8)
+    torch.manual_seed(2718)
+    z, _ = DiagonalGaussianRegularizer(sample=True)(enc(x))
+    xrec = dec(z)
+    total, log = loss(x, xrec, global_step=1, optimizer_idx=0, last_layer=dec.get_last_layer(), weights=torch.tensor(1.0))
+    out = dict(hp=hp, x=x, noise=noise, xrec=xrec.detach(), nll=log["train/loss/nll"], g_loss=log["train/loss/g"], d_weight=log["train/scalars/d_weight"],
+               total_shape=list(total.shape), total_mean=log["train/loss/total"])
+    save_fixture(out, "gan_generator_tiny")
+    print(f"gan generator branch: nll={float(out['nll']):.4f} g={float(out['g_loss']):.5f} d_weight={float(out['d_weight']):.4f} total is {tuple(total.shape)}")
+
+
 GLUE_SIGMAS = [0.002, 0.0292, 0.35, 0.9, 1.0, 2.7, 14.6, 80.0]
 GLUE_T = [0.0, 0.0004, 0.1, 0.37, 0.5, 0.93, 0.9995]
 GLUE_CLASSES = {
@@ -1054,7 +1096,7 @@ def config_case():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes", "lpips", "loss_class", "engine", "config", "blocks"}
+    which = set(sys.argv[1:]) or {"unet", "vae", "glue", "adafactor", "conditioner", "decoder", "sampler", "text", "dataset", "vae_train", "disc", "glue_classes", "lpips", "loss_class", "engine", "config", "blocks", "gan_generator"}
     nd, nmodel = import_reference()
     if "unet" in which:
         unet_case(nd, UNET_TINY, "unet_sdxl_tiny", B=2, HW=16, with_y=True)
@@ -1091,3 +1133,5 @@ if __name__ == "__main__":
         config_case()
     if "blocks" in which:
         blocks_case(nmodel)
+    if "gan_generator" in which:
+        gan_generator_case(nmodel)

@@ -54,3 +54,24 @@ def test_product_disc_losses_and_their_gradients(kind):
     assert rel_err(d_real, real.grad) < 1e-6 and rel_err(d_fake, fake.grad) < 1e-6
     late = get_discr_loss_fn(kind, start_step=100)
     assert float(late(case["logits_real"], case["logits_fake"], global_step=5)) == 0.0
+
+
+def test_generator_adversarial_pieces_oracle_vs_reference():
+    """oracle/patchgan_oracle.generator_adversarial_loss against what the reference's own GeneralLPIPSWithDiscriminator.forward computes for
+    the generator branch when it is given a tensor `weights` (tests/golden/make_golden.py::gan_generator_case): nll, g, adaptive weight."""
+    from tests.golden.make_golden import synth_state_dict
+
+    gfx = load_fixture("gan_generator_tiny")
+    G = Path(__file__).resolve().parent / "golden"
+    vfx = load_fixture("vae_train_tiny")
+    sd = synth_state_dict(json.loads((G / "vae_train_tiny_keys.json").read_text()))
+    dsd = disc_state_dict(json.loads((G / "patchgan_tiny_keys.json").read_text()))
+    enc = {k[len("encoder."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    dec = {k[len("decoder."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    hp = gfx["hp"]
+    loss, nll, g, dw, xrec = PO.generator_adversarial_loss(enc, dec, dsd, vfx["cfg"], gfx["x"], gfx["noise"], rec_weight=hp["rec_weight"], logvar=hp["logvar_init"],
+                                                           disc_factor=hp["disc_factor"], disc_weight=hp["disc_weight"])
+    assert rel_err(xrec, gfx["xrec"]) <= 1e-5
+    assert abs(float(nll) - float(gfx["nll"])) <= 1e-5 * abs(float(gfx["nll"]))
+    assert abs(float(g) - float(gfx["g_loss"])) <= 1e-4 * abs(float(gfx["g_loss"])) + 1e-7
+    assert abs(float(dw) - float(gfx["d_weight"])) <= 1e-3 * float(gfx["d_weight"])

@@ -131,7 +131,8 @@ def _gan_engine(**kw):
 
 def test_adversarial_generator_step_vs_oracle():
     """nll + adaptive-weight adversarial term of the autoencoder's update against the CPU oracle's autograd (this branch of
-    the reference's loss does not run as written: see oracle/patchgan_oracle.py; pinned by construction, not by fixtures)."""
+    the reference's loss does not run as written: see oracle/patchgan_oracle.py; its pieces ARE pinned by the reference, see
+    test_adversarial_generator_pieces_match_the_reference below and tests/test_patchgan_cpu.py)."""
     from oracle import patchgan_oracle as PO
 
     fx, sd, dsd, eng = _gan_engine(disc_factor=0.7, disc_weight=0.9, rec_weight=1.3, logvar_init=0.2)
@@ -158,6 +159,20 @@ def test_adversarial_generator_step_vs_oracle():
     fx, sd, dsd, eng = _gan_engine(disc_start=10)
     loss, _, _, log = eng.loss_and_backward(fx["x"].cuda(), noise=case["noise"].cuda())
     assert float(log["d_weight"]) == 0.0 and abs(float(loss) - float(log["nll_loss"])) <= 1e-6 * abs(float(loss))
+
+
+def test_adversarial_generator_pieces_match_the_reference():
+    """What the reference CAN run of this branch (GeneralLPIPSWithDiscriminator.forward with a tensor `weights`: make_golden.py::
+    gan_generator_case says which two lines stop it as shipped): nll_loss, g_loss and the adaptive weight on the decoder's last layer,
+    captured from the reference's own forward, against the HIP engine's log of the same step."""
+    gfx = load_fixture("gan_generator_tiny")
+    fx, sd, dsd, eng = _gan_engine(**gfx["hp"])
+    loss, _, xrec, log = eng.loss_and_backward(gfx["x"].cuda(), noise=gfx["noise"].cuda())
+    assert rel_err(xrec, gfx["xrec"]) <= 3e-2
+    assert abs(float(log["nll_loss"]) - float(gfx["nll"])) <= 1e-2 * abs(float(gfx["nll"]))
+    assert abs(float(log["g_loss"]) - float(gfx["g_loss"])) <= 2e-2 * abs(float(gfx["g_loss"])) + 2e-3
+    assert 1.0 < float(gfx["d_weight"]) < 9000.0                       # the fixture's weight is not sitting on its clamp
+    assert abs(float(log["d_weight"]) - float(gfx["d_weight"])) <= 0.1 * float(gfx["d_weight"])
 
 
 def test_alternating_training_steps_and_discriminator_update():
