@@ -1080,6 +1080,284 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dkdv_kernel(const AttnP
   }
 }
 
+// ---- backward in ONE kernel for at most 96 keys (head dim 64): the UNet's cross-attention (77 text tokens) ----
+// The two-kernel backward above costs a cross-attention layer three launches (dQ, dK / dV over query splits, their reduction), each of
+// them mostly fixed cost: 23 + 17 + 6 us for 3 GFLOP (profiles/r04_attention_kernels.txt).  With every key inside one workgroup nothing
+// has to be recomputed: waves 0-2 own 32 keys each (K, V fragments in registers, keys on lanes, exactly the dK / dV kernel's tile loop),
+// write dS^T to LDS, and wave 3 -- which has no keys -- turns the PREVIOUS tile's dS^T into dQ^T = K^T dS^T (complete: no sum across
+// workgroups) while the others are on the next tile.  Q' = bf16(Q scale log2 e), -lse2 and -delta = -rowsum(dO o O) are made on the fly
+// per 32-query tile, from rows fetched two tiles ahead by LDS-DMA.
+// dK / dV leave as fp32 partials per query split (summed by attn_dkv_reduce_kernel) or, with one split, directly.
+#define SMALL_DSROW 72                               // bytes per row of the dS^T image [96 keys][32 queries] (64 + 8: conflict-free 8-byte writes)
+__global__ __launch_bounds__(256, 2) void attn64_bwd_small_kernel(const AttnParams p) {
+  constexpr int TILE = 32 * 128, STAGE = 3 * TILE + 256 + 1024;   // Q' image, dO image, [32] -lse2, [32] -delta | O rows | 4 x 256 B raw log-sum-exp
+  constexpr int KIMG = 96 * 128, DSBUF = 96 * SMALL_DSROW;
+  constexpr int NST = 3;                                          // stages: the tile in work and the two ahead of it
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // [K image][3 stages][2 dS^T buffers]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h5 = lane >> 5, kl = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y, qs = blockIdx.x;
+  const float c = p.scale * LOG2E;
+  const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * 64;
+  const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * 64;
+  const bf16_t* Vb = p.V + (long)b * p.bv + (long)hd * 64;
+  const bf16_t* dOb = p.dO + (long)b * p.bdo + (long)hd * 64;
+  const bf16_t* Ocb = p.Oc + (long)b * p.bo + (long)hd * 64;
+  const float* lse = p.LSE + ((long)b * p.H + hd) * p.Lq;
+  const int nt_all = (p.Lq + 31) / 32;
+  const int per = (nt_all + p.qsplit - 1) / p.qsplit;
+  const int t_lo = qs * per, t_hi = min(nt_all, t_lo + per);
+  const int nt = max(t_hi - t_lo, 0);
+  const unsigned smem_a = (unsigned)(size_t)(lds_c)smem;
+  const unsigned stage_a = smem_a + KIMG, ds_a = stage_a + NST * STAGE;
+  const int k0 = wave * 32;                    // waves 0-2: first key of the wave's block
+
+  // K, V fragments of the wave's keys (waves 0-2); the K image (rows past Lk zero) for wave 3's K^T reads
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4_t zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+    if (wave < 3 && k0 + kl < p.Lk) {
+      zk = *(const uint4_t*)(Kb + (long)(k0 + kl) * p.sk + 16 * ks + 8 * h5);
+      zv = *(const uint4_t*)(Vb + (long)(k0 + kl) * p.sv + 16 * ks + 8 * h5);
+    }
+    kf[ks] = __builtin_bit_cast(bf16x8_t, zk);
+    vf[ks] = __builtin_bit_cast(bf16x8_t, zv);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int row = i * 32 + (tid >> 3);
+    uint4_t z = {0u, 0u, 0u, 0u};
+    if (row < p.Lk) z = *(const uint4_t*)(Kb + (long)row * p.sk + (tid & 7) * 8);
+    A64_WR128(smem_a + (unsigned)(row * 128 + (((tid & 7) ^ a64_swz(row)) << 4)), z);
+  }
+
+  // Tiles are fetched TWO ahead (a tile's compute, ~1 us, does not cover a loaded chip's memory latency), entirely by LDS-DMA -- no staging
+  // registers: wave w fetches rows 8 w .. 8 w + 7 of Q, dO and O (one 1 KiB piece each: its lane l holds chunk (l & 7) ^ swz(row) of row l >> 3
+  // in all three) and those rows' log-sum-exps (a 4-byte piece).  FOUR vector-memory operations per wave per fetch, so "the older tile has
+  // landed" is the counted wait vmcnt(4).  The wave then publishes ITS rows in place: Q -> Q' = bf16(Q scale log2 e), -lse2, and
+  // -delta = -rowsum(dO o O) from the matching chunks (a row's 8 chunks sit on 8 adjacent lanes).
+  Dma64<32, 4> dq_, do_, dc_;
+  dq_.init(p.sq, wave, lane);
+  do_.init(p.sdo, wave, lane);
+  dc_.init(p.so, wave, lane);
+  const int prow = wave * 8 + (lane >> 3);                         // the row of the tile this lane stages
+  const unsigned poff = (unsigned)(wave * 1024 + lane * 16);       // its slot in each image
+  auto fetch = [&](int q0, unsigned stage_off) {
+    char* st = smem + KIMG + stage_off;
+    dq_.issue(Qb, p.sq, q0, p.Lq, st, wave, lane);
+    do_.issue(dOb, p.sdo, q0, p.Lq, st + TILE, wave, lane);
+    dc_.issue(Ocb, p.so, q0, p.Lq, st + 2 * TILE + 256, wave, lane);
+    __builtin_amdgcn_global_load_lds((att_gptr)(lse + min(q0 + prow, p.Lq - 1)), (att_lptr)(st + 3 * TILE + 256 + wave * 256), 4, 0, 0);
+  };
+  auto publish = [&](int q0, unsigned stage_off, bool younger) {
+    if (younger) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned st = stage_a + stage_off;
+    uint4_t zq, zd, zo;
+    float lv;
+    A64_RD128(zq, st + poff, 0);
+    A64_RD128(zd, st + TILE + poff, 0);
+    A64_RD128(zo, st + 2 * TILE + 256 + poff, 0);
+    asm volatile("ds_read_b32 %0, %1" : "=v"(lv) : "v"(st + 3 * TILE + 256 + (unsigned)(wave * 256 + lane * 4)));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zq), "+v"(zd), "+v"(zo), "+v"(lv));
+    const bool ok = q0 + prow < p.Lq;                               // (rows past Lq are copies of the last row: Q' = 0, P = 0)
+    float fq[8], fo[8], fd[8];
+    unpack8(zq, fq);
+    unpack8(zo, fo);
+    unpack8(zd, fd);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { fq[e] = ok ? fq[e] * c : 0.f; acc += fo[e] * fd[e]; }
+    const uint4_t zs = pack8(fq);
+    A64_WR128(st + poff, zs);
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    if ((lane & 7) == 0) {
+      const float nd = ok ? -acc : 0.f, nl = ok ? -lv * LOG2E : -1.0e30f;
+      asm volatile("ds_write_b32 %0, %1" : : "v"(st + 2 * TILE + (unsigned)(128 + 4 * prow)), "v"(nd) : "memory");
+      asm volatile("ds_write_b32 %0, %1" : : "v"(st + 2 * TILE + (unsigned)(4 * prow)), "v"(nl) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  float16_t dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+  unsigned rab[4], tab[2][2];
+  a64_row_bases(rab, lane);
+  a64_tr_bases(tab, lane);
+  const unsigned stat_a = (unsigned)(2 * TILE + 16 * h5);
+  const bool tail_keys = wave < 3 && k0 + 32 > p.Lk;        // the wave's block reaches past Lk: those lanes' P must be zero
+  const bool key_ok = k0 + kl < p.Lk;
+
+  if (nt > 0) fetch(t_lo * 32, 0);
+  if (nt > 1) fetch((t_lo + 1) * 32, STAGE);
+  if (nt > 0) {
+    publish(t_lo * 32, 0, nt > 1);
+    __builtin_amdgcn_s_barrier();
+  }
+  const int nks = (p.Lk + 15) / 16;                          // 16-key steps of wave 3's product
+  // wave 3: dQ of tile `tq` (first query q0) from the dS^T buffer `buf`
+  auto dq_tile = [&](int q0, unsigned buf) {
+    float16_t dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    for (int kk = 0; kk < nks; ++kk) {
+      const bf16x8_t dsf = tr_frag((const char*)smem + KIMG + NST * STAGE + buf, SMALL_DSROW, 16 * kk, 0, lane);
+      short4_t lo0, hi0, lo1, hi1;
+      const unsigned ko = smem_a + (unsigned)(16 * kk * 128);
+      A64_RDTR(lo0, ko + tab[0][0], 0); A64_RDTR(hi0, ko + tab[1][0], 0); A64_RDTR(lo1, ko + tab[0][1], 0); A64_RDTR(hi1, ko + tab[1][1], 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+      dq[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(lo0, hi0), dsf, dq[0], 0, 0, 0);
+      dq[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(lo1, hi1), dsf, dq[1], 0, 0, 0);
+    }
+    const int q = q0 + kl;
+    if (q < p.Lq) {
+      bf16_t* dQb = p.dQ + (long)b * p.bdq + (long)q * p.sdq + (long)hd * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          uint2_t a;
+          a.x = pack2bf(dq[dt][4 * r4 + 0] * p.scale, dq[dt][4 * r4 + 1] * p.scale);
+          a.y = pack2bf(dq[dt][4 * r4 + 2] * p.scale, dq[dt][4 * r4 + 3] * p.scale);
+          *(uint2_t*)(dQb + dt * 32 + 8 * r4 + 4 * h5) = a;
+        }
+    }
+  };
+
+  for (int t = 0; t < nt; ++t) {
+    const unsigned so = (unsigned)((t % NST) * STAGE), sn = (unsigned)(((t + 1) % NST) * STAGE), s2 = (unsigned)(((t + 2) % NST) * STAGE);
+    const unsigned dbuf = (unsigned)((t & 1) * DSBUF);
+    const bool more = t + 1 < nt, more2 = t + 2 < nt;
+    // (wave 3 fetches BEHIND its dQ stores, so that for every wave the youngest vector-memory operations at the end of the tile are the four of
+    // this fetch; the stage of tile t + 2 is the one tile t - 1 used: free since the barrier that ended that tile)
+    if (more2 && wave < 3) fetch((t_lo + t + 2) * 32, s2);
+    if (wave < 3) {
+      const unsigned qt = stage_a + so, dot = qt + TILE, st = qt + stat_a;
+      float16_t s, dp;
+      {
+        float4_t c0, c1, c2, c3;
+        bf16x8_t qr[4];
+        A64_RD128(c0, st, 0); A64_RD128(c1, st, 32); A64_RD128(c2, st, 64); A64_RD128(c3, st, 96);
+        A64_RD128(qr[0], qt + rab[0], 0); A64_RD128(qr[1], qt + rab[1], 0); A64_RD128(qr[2], qt + rab[2], 0); A64_RD128(qr[3], qt + rab[3], 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        s = __builtin_shufflevector(__builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(c2, c3, 0, 1, 2, 3, 4, 5, 6, 7),
+                                    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[ks], kf[ks], s, 0, 0, 0);
+        A64_PIN(s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        float4_t e0, e1, e2, e3;
+        bf16x8_t dr[4];
+        A64_RD128(e0, st, 128); A64_RD128(e1, st, 160); A64_RD128(e2, st, 192); A64_RD128(e3, st, 224);
+        A64_RD128(dr[0], dot + rab[0], 0); A64_RD128(dr[1], dot + rab[1], 0); A64_RD128(dr[2], dot + rab[2], 0); A64_RD128(dr[3], dot + rab[3], 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        dp = __builtin_shufflevector(__builtin_shufflevector(e0, e1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(e2, e3, 0, 1, 2, 3, 4, 5, 6, 7),
+                                     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dr[ks], vf[ks], dp, 0, 0, 0);
+        A64_PIN(dp);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      short4_t olo[2][2], ohi[2][2];
+      {
+        const unsigned o00 = dot + tab[0][0], o01 = dot + tab[0][1], o10 = dot + tab[1][0], o11 = dot + tab[1][1];
+        A64_RDTR(olo[0][0], o00, 0); A64_RDTR(olo[0][1], o01, 0); A64_RDTR(ohi[0][0], o10, 0); A64_RDTR(ohi[0][1], o11, 0);
+        A64_RDTR(olo[1][0], o00, 2048); A64_RDTR(olo[1][1], o01, 2048); A64_RDTR(ohi[1][0], o10, 2048); A64_RDTR(ohi[1][1], o11, 2048);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = EXP2(s[r]);
+        dp[r] *= s[r];
+      }
+      if (tail_keys) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = key_ok ? s[r] : 0.f;
+          dp[r] = key_ok ? dp[r] : 0.f;
+        }
+      }
+      bf16x8_t pf[2], dsf[2];
+      pf[0] = pack_frag(s, 0); pf[1] = pack_frag(s, 1);
+      dsf[0] = pack_frag(dp, 0); dsf[1] = pack_frag(dp, 1);
+      A64_PIN(pf[0]); A64_PIN(pf[1]); A64_PIN(dsf[0]); A64_PIN(dsf[1]);
+      // dS^T [key][32 queries] for wave 3: register pair j of the lane = queries 8 j + 4 h5 .. + 3 of its key
+      {
+        const unsigned da = ds_a + dbuf + (unsigned)((k0 + kl) * SMALL_DSROW + 8 * h5);
+        const uint4_t d0 = __builtin_bit_cast(uint4_t, dsf[0]), d1 = __builtin_bit_cast(uint4_t, dsf[1]);
+        const uint2_t w0 = {d0.x, d0.y}, w1 = {d0.z, d0.w}, w2 = {d1.x, d1.y}, w3 = {d1.z, d1.w};
+        A64_WR64(da, w0, 0); A64_WR64(da, w1, 16); A64_WR64(da, w2, 32); A64_WR64(da, w3, 48);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      short4_t qlo[2][2], qhi[2][2];
+      {
+        const unsigned q00 = qt + tab[0][0], q01 = qt + tab[0][1], q10 = qt + tab[1][0], q11 = qt + tab[1][1];
+        A64_RDTR(qlo[0][0], q00, 0); A64_RDTR(qlo[0][1], q01, 0); A64_RDTR(qhi[0][0], q10, 0); A64_RDTR(qhi[0][1], q11, 0);
+        A64_RDTR(qlo[1][0], q00, 2048); A64_RDTR(qlo[1][1], q01, 2048); A64_RDTR(qhi[1][0], q10, 2048); A64_RDTR(qhi[1][1], q11, 2048);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(olo[s2][dt], ohi[s2][dt]), pf[s2], dv[dt], 0, 0, 0);
+      A64_PIN(dv[0]); A64_PIN(dv[1]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(qlo[s2][dt], qhi[s2][dt]), dsf[s2], dk[dt], 0, 0, 0);
+      A64_PIN(dk[0]); A64_PIN(dk[1]);
+    } else {
+      if (t > 0) dq_tile((t_lo + t - 1) * 32, (unsigned)(((t - 1) & 1) * DSBUF));
+      if (more2) fetch((t_lo + t + 2) * 32, s2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) publish((t_lo + t + 1) * 32, sn, more2);
+    __builtin_amdgcn_s_barrier();           // dS^T of tile t written; this wave's rows of tile t + 1 published: Q' / -lse2 / -delta / dO in place
+  }
+  if (wave == 3 && nt > 0) dq_tile((t_lo + nt - 1) * 32, (unsigned)(((nt - 1) & 1) * DSBUF));
+
+  const float ln2 = 0.6931471805599453f;
+  const int key = k0 + kl;
+  if (wave < 3 && key < p.Lk) {
+    if (p.qsplit > 1) {
+      const long hd_all = (long)p.H * 64;
+      const long plane = (long)p.B * p.Lk * hd_all;
+      float* pk = p.dkv_part + ((long)qs * 2) * plane + ((long)b * p.Lk + key) * hd_all + (long)hd * 64;
+      float* pv = pk + plane;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int d = dt * 32 + 8 * r4 + 4 * h5;
+          *(float4_t*)(pk + d) = (float4_t){dk[dt][4 * r4 + 0] * ln2, dk[dt][4 * r4 + 1] * ln2, dk[dt][4 * r4 + 2] * ln2, dk[dt][4 * r4 + 3] * ln2};
+          *(float4_t*)(pv + d) = (float4_t){dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1], dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]};
+        }
+      return;
+    }
+    bf16_t* dKb = p.dK + (long)b * p.bdk + (long)key * p.sdk + (long)hd * 64;
+    bf16_t* dVb = p.dV + (long)b * p.bdv + (long)key * p.sdv + (long)hd * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = dt * 32 + 8 * r4 + 4 * h5;
+        uint2_t a, v;
+        a.x = pack2bf(dk[dt][4 * r4 + 0] * ln2, dk[dt][4 * r4 + 1] * ln2);
+        a.y = pack2bf(dk[dt][4 * r4 + 2] * ln2, dk[dt][4 * r4 + 3] * ln2);
+        v.x = pack2bf(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
+        v.y = pack2bf(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
+        *(uint2_t*)(dKb + d) = a;
+        *(uint2_t*)(dVb + d) = v;
+      }
+  }
+}
+
 // ================================================================================================
 // backward: dK, dV.  Workgroup = 128 keys (4 waves x 32 keys on lanes), loops over 32-query tiles.
 // ================================================================================================
@@ -1483,6 +1761,18 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
   return nk_check_launch("attn_fwd_kernel");
 }
 
+// NK_ATTN64_SMALL=0: cross-attention backward through the two-kernel path (A/B switch of round 4; read per call)
+static bool attn64_small_enabled() {
+  const char* e = getenv("NK_ATTN64_SMALL");
+  return !e || atoi(e) != 0;
+}
+// query splits of the one-kernel backward: enough workgroups for the chip (two per CU fit), at least two 32-query tiles each
+static int attn_small_qsplit(const NkAttnDesc* d) {
+  const int base = d->B * d->H;
+  int s = 1;
+  while (s < 64 && base * s * 2 <= 512 && d->Lq / (s * 2) >= 64) s *= 2;      // (at most one round of two workgroups per CU)
+  return s;
+}
 static int attn_qsplit(const NkAttnDesc* d) {
   // a single key block (cross-attention, Lk = 77) gives only B*H workgroups that each walk the whole query range:
   // split the query range so the grid has >= ~512 workgroups
@@ -1494,6 +1784,7 @@ static int attn_qsplit(const NkAttnDesc* d) {
 }
 extern "C" long nk_attention_bwd_ws_floats(const NkAttnDesc* d) {
   int s = attn_qsplit(d);
+  if (d->D == 64 && d->Lk <= 96 && attn_small_qsplit(d) > s) s = attn_small_qsplit(d);
   long part = s > 1 ? (long)s * 2 * d->B * d->Lk * d->H * d->D : 0;
   if (d->D == 64) return Attn64Ws::make(d->B, d->H, d->Lq).part + part + 64;     // -delta, -lse2, Q' (whichever kernels run)
   long delta = (long)d->B * d->H * d->Lq;
@@ -1519,6 +1810,25 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   p.sdq = d->sdq; p.sdk = d->sdk; p.sdv = d->sdv; p.sdo = d->sdo;
   p.bdq = d->bdq; p.bdk = d->bdk; p.bdv = d->bdv; p.bdo = d->bdo;
   p.scale = d->scale;
+  if (d->D == 64 && d->Lk <= 96 && attn64_enabled() && attn64_small_enabled()) {
+    // head dim 64, at most 96 keys (cross-attention): everything in one kernel (+ the sum of the query splits' dK / dV partials)
+    NK_CHECK_ARG(((uintptr_t)delta_ws & 15) == 0);
+    const Attn64Ws w = Attn64Ws::make(d->B, d->H, d->Lq);
+    p.qsplit = attn_small_qsplit(d);
+    p.dkv_part = p.qsplit > 1 ? delta_ws + w.part : nullptr;
+    const int smem = 96 * 128 + 3 * (3 * 32 * 128 + 256 + 1024) + 2 * 96 * SMALL_DSROW;
+    set_smem(attn64_bwd_small_kernel, smem);
+    hipLaunchKernelGGL(attn64_bwd_small_kernel, dim3(p.qsplit, d->H, d->B), dim3(256), smem, stream, p);
+    if (int e = nk_check_launch("attn64_bwd_small_kernel")) return e;
+    if (p.qsplit > 1) {
+      long total = (long)d->B * d->Lk * ((long)d->H * d->D / 4);
+      long blocks = (total + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, p);
+      if (int e = nk_check_launch("attn_dkv_reduce_kernel")) return e;
+    }
+    return NK_OK;
+  }
   if (d->D == 64 && attn64_enabled()) {
     // head dim 64: the dQ kernel (which also writes -delta, -lse2 and Q' into the workspace), then dK / dV
     NK_CHECK_ARG(((uintptr_t)delta_ws & 15) == 0);

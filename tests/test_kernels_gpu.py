@@ -347,6 +347,29 @@ def test_attention(ops, B, H, Lq, Lk, D):
     assert_close(dv, vr.grad, TOL_BF16, "attn dv")
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 64, 16), (2, 3, 96, 96), (1, 4, 520, 77), (2, 2, 33, 3), (4, 20, 1024, 77), (1, 1, 4100, 80)])
+def test_attention_backward_in_one_kernel_for_few_keys(ops, B, H, Lq, Lk, monkeypatch):
+    """Head dim 64 with at most 96 keys (the UNet's cross-attention: 77 tokens) runs its whole backward in one kernel (csrc/attention.hip,
+    attn64_bwd_small_kernel: keys on lanes in waves 0-2, dS^T through LDS, dQ by wave 3, Q' / -lse2 / -delta made per 32-query tile from rows
+    fetched two tiles ahead).  One tile, two, many; one query split and several; ragged last tiles; three keys; a key block that ends
+    inside a wave -- against fp32, and against the two-kernel path on the same inputs."""
+    D = 64
+    q, k, v = rnd(B * Lq, H * D), rnd(B * Lk, H * D, seed=5), rnd(B * Lk, H * D, seed=6)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, B, H, D)
+    do = rnd(B * Lq, H * D, seed=9)
+    ref.backward(do)
+    o, bwd = ops.attention_fwd(dev(q), dev(k), dev(v), B, H, D)
+    dq, dk, dv = bwd(dev(do))
+    assert_close(dq, qr.grad, TOL_BF16, "one-kernel dq")
+    assert_close(dk, kr.grad, TOL_BF16, "one-kernel dk")
+    assert_close(dv, vr.grad, TOL_BF16, "one-kernel dv")
+    monkeypatch.setenv("NK_ATTN64_SMALL", "0")          # read per call
+    dq2, dk2, dv2 = bwd(dev(do))
+    for a, b, name in ((dq, dq2, "dq"), (dk, dk2, "dk"), (dv, dv2, "dv")):
+        assert_close(a, b.float().cpu(), 1e-2, f"one-kernel vs two-kernel {name}")
+
+
 def test_attention_fused_qkv_slices_and_spike(ops):
     """q/k/v as column slices of one buffer; one key spiked so the online-softmax rescale path is taken late."""
     B, H, L, D = 1, 2, 320, 64
