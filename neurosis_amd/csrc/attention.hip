@@ -415,21 +415,6 @@ __device__ __forceinline__ bf16x8_t a64_join(const short4_t& lo, const short4_t&
 
 #define A64_WR128(addr, val) asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(val) : "memory")
 #define A64_WR64(addr, val, OFF) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(val), "n"(OFF) : "memory")
-// A workgroup's [NW * 32 rows][64] block of Q / dO / O / dQ moves between HBM and the LDS image in WHOLE ROWS: thread (piece i) handles
-// the 16-byte chunk (tid & 7) of row i * (NW * 8) + (tid >> 3), so a wave instruction covers 8 rows x 128 bytes.  (Row-per-lane
-// fragment loads / stores -- 32 rows x 32 bytes per instruction -- ran the prologues and epilogues at ~2 TB/s: 10-20 us of every
-// launch, most of a cross-attention launch: profiles/r04_attention_*.txt.)
-template <int NW>
-struct Rows64 {
-  static constexpr int PER = 4;            // NW * 32 rows * 8 chunks / (NW * 64 threads)
-  // byte offset of this thread's piece i in the image
-  static __device__ __forceinline__ unsigned img_off(int i, int tid) {
-    const int row = i * (NW * 8) + (tid >> 3);
-    return (unsigned)(row * 128 + (((tid & 7) ^ a64_swz(row)) << 4));
-  }
-  static __device__ __forceinline__ int row_of(int i, int tid) { return i * (NW * 8) + (tid >> 3); }
-};
-
 // ---- forward ----
 // The generic kernel above spends, per 64-key tile and wave, 16 MFMAs (512 matrix-pipe cycles) against ~200 vector issue slots (~930
 // cycles: 32 fmax, 32 fma, 32 v_exp at two slots each, 32 adds, 16 conversions, the alpha path, 4 ds_write_b128 of the staged tile):
@@ -446,8 +431,22 @@ struct Rows64 {
 //    and the tile exponentiated against the new m -- the textbook order, so nothing is ever scaled twice or not at all;
 //  * K / V tiles arrive by LDS-DMA two tiles ahead into a ring of three stages (no staging registers, no ds_write, counted vmcnt).
 #define RESCALE_SUM 8192.0f
+// Diagnostic build only (make EXTRA=-DNK_ATTN_STAMPS; tools/attn_stamps.py): wave 0 of every workgroup stamps s_memtime at entry, after the
+// prologue, after the key loop and after the epilogue, plus s_memrealtime around the loop.  None of it exists in the shipped library.
+#ifdef NK_ATTN_STAMPS
+__device__ unsigned long long nk_attn_stamp_buf[8 * 8192];
+#define ATT_STAMP(slot) do { if (threadIdx.x == 0) { const unsigned w_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (w_ < 8192) nk_attn_stamp_buf[w_ * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define ATT_STAMP_RT(slot) do { if (threadIdx.x == 0) { const unsigned w_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (w_ < 8192) nk_attn_stamp_buf[w_ * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+extern "C" int nk_debug_attn_stamps(unsigned long long* host_out, int nwg) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nk_attn_stamp_buf), (size_t)nwg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#else
+#define ATT_STAMP(slot)
+#define ATT_STAMP_RT(slot)
+#endif
 template <int NW = 4>
 __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams p) {
+  ATT_STAMP(0);
   constexpr int TILE = 64 * 128, STAGE = 2 * TILE;
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [3 stages][K, V][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -471,33 +470,23 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
     dv.issue(Vb, p.sv, 64, p.Lk, smem + STAGE + TILE, wave, lane);
   }
 
-  // Q' = bf16(Q * scale * log2 e): whole rows from HBM, scaled, into stage 2 as an image; each wave then reads its fragments from it
+  // Q' = bf16(Q * scale * log2 e), straight into the lane's fragments.  (Whole rows through an LDS image instead -- coalesced, one more
+  // barrier -- measured SLOWER: 13.3 vs 11.5 us on a cross-attention launch; the prologue is bound by the burst of every workgroup's first
+  // tiles, ~11 B / clk / CU, not by the shape of these loads: tools/attn_stamps.py.)
   const unsigned smem_a = (unsigned)(size_t)(lds_c)smem;
-  {
-    const int Q0 = blockIdx.x * (NW * 32);
-#pragma unroll
-    for (int i = 0; i < Rows64<NW>::PER; ++i) {
-      const int r = Q0 + Rows64<NW>::row_of(i, tid);
-      uint4_t z = {0u, 0u, 0u, 0u};
-      if (r < p.Lq) z = *(const uint4_t*)(Qb + (long)r * p.sq + (tid & 7) * 8);
-      float f[8];
-      unpack8(z, f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] *= c;
-      const uint4_t zs = pack8(f);
-      A64_WR128(smem_a + 2 * STAGE + Rows64<NW>::img_off(i, tid), zs);
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
   unsigned kab[4], vab[2][2];
   a64_row_bases(kab, lane);
   a64_tr_bases(vab, lane);
   bf16x8_t qf[4];
-  {
-    const unsigned qa = smem_a + 2 * STAGE + wave * 4096;
-    A64_RD128(qf[0], qa + kab[0], 0); A64_RD128(qf[1], qa + kab[1], 0); A64_RD128(qf[2], qa + kab[2], 0); A64_RD128(qf[3], qa + kab[3], 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4_t z = {0u, 0u, 0u, 0u};
+    if (q0 + ql < p.Lq) z = *(const uint4_t*)(Qb + (long)(q0 + ql) * p.sq + 16 * ks + 8 * h5);
+    float f[8];
+    unpack8(z, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= c;
+    qf[ks] = __builtin_bit_cast(bf16x8_t, pack8(f));
   }
   float16_t oacc[2], negm;
 #pragma unroll
@@ -505,11 +494,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
   float m = 0.f, l = 0.f;      // m: the reference point of this lane's query row, log2 units; l: this lane's half of the row sum
 
 
-  // tile 0 has landed for everyone (it is older than tile 1's four pieces); the barrier also orders every wave's reads of the Q' image
-  // before the DMA of tile 2 into that stage
+  // tile 0 has landed for everyone (the Q loads and tile 0 are older than tile 1's four pieces)
   if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  ATT_STAMP(1); ATT_STAMP_RT(4);
   unsigned so = 0, sn = 2 * STAGE;      // stage of tile t / of tile t + 2
   // FIRST: tile 0 (defines m).  MASKED: tile t reaches past Lk, or the causal variant.  ISSUE: 2 = tile t + 2 lies wholly inside K / V,
   // 1 = it may not (or may not exist).  Compile-time flags: as run-time wave-uniform branches hipcc flattens them into the common path.
@@ -647,14 +636,12 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
     for (; t < nt; ++t) iteration(t, F{}, T{}, I1{});
   }
 
+  ATT_STAMP(2); ATT_STAMP_RT(5);
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
   const int q = q0 + ql;
-  if (q < p.Lq && h5 == 0) p.LSE[((long)b * p.H + hd) * p.Lq + q] = (m + __log2f(l)) * 0.6931471805599453f;
-  // O leaves through an LDS image (every DMA has landed: the last iteration waited for vmcnt(0)) and is stored in whole rows
-  {
-    const int row = wave * 32 + ql, f = a64_swz(row);
-    const unsigned oa = smem_a + (unsigned)(row * 128 + 8 * h5);
+  if (q < p.Lq) {
+    bf16_t* Ob = p.O + (long)b * p.bo + (long)q * p.so + (long)hd * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -662,22 +649,14 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
         uint2_t o;
         o.x = pack2bf(oacc[dt][4 * r4 + 0] * inv, oacc[dt][4 * r4 + 1] * inv);
         o.y = pack2bf(oacc[dt][4 * r4 + 2] * inv, oacc[dt][4 * r4 + 3] * inv);
-        const unsigned a = oa + (unsigned)((((dt * 4 + r4) ^ f)) << 4);
-        asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(o) : "memory");
+        *(uint2_t*)(Ob + dt * 32 + 8 * r4 + 4 * h5) = o;
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int Q0 = blockIdx.x * (NW * 32);
-    uint4_t z[Rows64<NW>::PER];
-#pragma unroll
-    for (int i = 0; i < Rows64<NW>::PER; ++i) A64_RD128(z[i], smem_a + Rows64<NW>::img_off(i, tid), 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
-#pragma unroll
-    for (int i = 0; i < Rows64<NW>::PER; ++i) {
-      const int r = Q0 + Rows64<NW>::row_of(i, tid);
-      if (r < p.Lq) *(uint4_t*)(p.O + (long)b * p.bo + (long)r * p.so + (long)hd * 64 + (tid & 7) * 8) = z[i];
-    }
+    if (h5 == 0) p.LSE[((long)b * p.H + hd) * p.Lq + q] = (m + __log2f(l)) * 0.6931471805599453f;
   }
+#ifdef NK_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_STAMP(3);
+#endif
 }
 
 // ---- backward, dQ (head dim 64) ----

@@ -71,7 +71,7 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
         batch = bench.synthetic_batch(dev, 4, (1024, 1024), gen)
-        sig = bench.draw_sigmas(4, gen_cpu, dev)
+        sig = bench.draw_sigmas(4, gen, dev)
         ev[1].record()
         loss = eng.training_step(batch, 0, sigmas=sig)
         ev[2].record()
