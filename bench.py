@@ -341,6 +341,9 @@ def main():
     ap.add_argument("--wire-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: dtype of the gradient all-reduce (fp32 = what Lightning DDP exchanges for the reference's fp32 parameters; "
                          "bf16 halves the bytes on xGMI and sums in bf16)")
+    ap.add_argument("--recompute", choices=["none", "norms"], default="none",
+                    help="selective activation recompute in the transformer blocks (UNetModel.set_recompute): norms = LayerNorm outputs and GEGLU products "
+                         "rebuilt in backward instead of held (less memory, two more elementwise passes per block); reported in config")
     ap.add_argument("--stream-optimizer", action="store_true",
                     help="N = 1 A/B: issue each top-level UNet block's Adafactor update behind that block's backward (DiffusionEngine.stream_optimizer) "
                          "instead of the whole update after backward")
@@ -374,6 +377,8 @@ def main():
     lib.load()  # fail loudly if the HIP library is missing
     eng = build_engine(device, (args.res, args.res), None if args.precomputed_te else build_conditioner(device))
     unet = eng.model.diffusion_model
+    if args.recompute != "none":
+        unet.set_recompute(args.recompute)
     if args.stream_optimizer:
         eng.stream_optimizer = True
     if args.optimizer == "adafactor":
@@ -450,6 +455,8 @@ def main():
     barrier()
     if os.environ.get("NK_SYNC_DEBUG_AFTER_WARMUP") == "1":      # tools/sync_debug.py: report every host-synchronising call of the timed steps
         torch.cuda.set_sync_debug_mode("warn")
+    setup_peak = torch.cuda.max_memory_allocated()      # priming + warm-up: an eager pass and the graph captures live side by side
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step(mark=True)
@@ -568,8 +575,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SDXL-base {'mixed-res buckets (~1024^2 pixels)' if args.mixed_res else str(args.res) + '^2'} bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, {'frozen TE outputs synthetic' if args.precomputed_te else 'frozen CLIP-L + OpenCLIP-bigG conditioner on synthetic token ids'}",
-                       "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}", "allreduce_dtype": args.wire_dtype, "activation_checkpointing": False, "accumulate_grad_batches": args.accumulate},
-            "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                       "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}", "allreduce_dtype": args.wire_dtype, "activation_checkpointing": False if args.recompute == "none" else f"selective ({args.recompute})", "accumulate_grad_batches": args.accumulate},
+            "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "max_mem_setup_gb": round(setup_peak / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "step_ms_in_order": [round(t, 1) for t in in_order], "comm": comm,
             "host": {"unet_chain": "hipGraph replay" if priming else "eager launches", "graph_priming_steps": priming},
             "stream_k_fixup_timeouts": lib.query("nk_gemm_sk_status"),   # 0: every K-split tile was joined (gemm.hip)

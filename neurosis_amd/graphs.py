@@ -95,7 +95,7 @@ class ChainGraphs:
     # ------------------------------------------------------------------------------------------------
     def run(self, fwd: Callable, inputs: Sequence[Optional[Tensor]], extra_key=()):
         mode = ops.wgrad_mode(self.owner)
-        key = (extra_key, tuple(_sig(t) for t in inputs), mode, torch.is_grad_enabled())
+        key = (extra_key, tuple(_sig(t) for t in inputs), mode, ops.recording())     # (a forward that keeps activations for a backward is another launch sequence)
         pair = self.pairs.get(key)
         if pair is None:
             pair = self.pairs[key] = _Pair()

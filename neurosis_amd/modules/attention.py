@@ -58,10 +58,13 @@ class FeedForward(nn.Module):
             raise NotImplementedError("FeedForward(glu=False) is unused by SD1.5/SDXL UNets")
         self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
 
-    def fwd(self, x: Tensor, residual: Optional[Tensor] = None):
+    def fwd(self, x: Tensor, residual: Optional[Tensor] = None, x_saved=None, recompute_h: bool = False):
+        """x_saved / recompute_h (selective recompute, BasicTransformerBlock.recompute): the projection's input is rebuilt by `x_saved()` and
+        the GEGLU product h = a * gelu(g) from the kept projection output u when the weight gradients need them; neither is held."""
         proj = self.net[0].proj
-        u, g, b_proj = ops.linear_geglu_fwd(x, proj.weight, proj.bias)       # the GEGLU rides in the projection's epilogue where it can
-        y, b_out = linear_module_fwd(self.net[2], g, residual)
+        u, g, b_proj = ops.linear_geglu_fwd(x, proj.weight, proj.bias, x_saved)       # the GEGLU rides in the projection's epilogue where it can
+        y, b_out = linear_module_fwd(self.net[2], g, residual, x_saved=(lambda: ops.geglu_fwd(u)[0]) if recompute_h else None)
+        del g
 
         def bwd(dy: Tensor):
             # net[2]'s input gradient with the GEGLU backward in its epilogue: one launch, d(a * gelu(g)) never goes to HBM
@@ -99,9 +102,12 @@ class CrossAttention(nn.Module):
         self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
 
-    def fwd(self, x: Tensor, context: Optional[Tensor], B: int, residual: Optional[Tensor] = None, need_dctx: bool = False):
-        """x [B*L, C]; context [B*Lc, Cc] or None (self-attention).  Returns (out, bwd); bwd(dy) -> (dx, dctx|None)."""
+    def fwd(self, x: Tensor, context: Optional[Tensor], B: int, residual: Optional[Tensor] = None, need_dctx: bool = False, x_saved=None):
+        """x [B*L, C]; context [B*Lc, Cc] or None (self-attention).  Returns (out, bwd); bwd(dy) -> (dx, dctx|None).
+        x_saved: a callable that rebuilds x for the weight gradients (selective recompute: the closures then do not hold x)."""
         wq, wk, wv = self.to_q.weight, self.to_k.weight, self.to_v.weight
+        x_back = (lambda: x_keep) if x_saved is None else x_saved
+        x_keep = x if x_saved is None else None
         inner = wq.shape[0]
         self_attn = context is None
         acc = lambda: ops.wgrad_mode(wq)
@@ -118,12 +124,15 @@ class CrossAttention(nn.Module):
                 dqkv = torch.empty_like(qkv)
                 b_att(do, dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:])
                 g_qkv = torch.as_strided(ops.grad_flat(wq), (3 * inner, wq.shape[1]), (wq.shape[1], 1))
-                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dqkv, x, g_qkv, acc()), dqkv, x, owner=wq)
+                xb = x_back()
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dqkv, xb, g_qkv, acc()), dqkv, xb, owner=wq)
                 return ops.gemm_nn(dqkv, w_qkv), None
 
+            del x
             return y, bwd
 
         ctx = x if self_attn else context
+        ctx_back = x_back if self_attn else (lambda: context)       # what the K / V weight gradients read, rebuilt with x when it is x
         q = ops.gemm_nt(x, ops.w2d(wq))
         fused_kv = adjacent(wk, wv)
         if fused_kv:
@@ -140,26 +149,29 @@ class CrossAttention(nn.Module):
             v = ops.gemm_nt(ctx, ops.w2d(wv))
         o, b_att = ops.attention_fwd(q, k, v, B, self.heads, self.dim_head)
         y, b_out = linear_module_fwd(self.to_out[0], o, residual)
+        del x, ctx                      # (the closure below reaches the layer's input through x_back / ctx_back only)
 
         def bwd(dy: Tensor):
             do = b_out(dy)
+            xb = x_back()
+            cb = xb if self_attn else ctx_back()
             if fused_kv:
                 dkv = torch.empty_like(kv)
                 dq, _, _ = b_att(do, None, dkv[:, :inner], dkv[:, inner:])
                 g_kv = torch.as_strided(ops.grad_flat(wk), (2 * inner, wk.shape[1]), (wk.shape[1], 1))
-                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dkv, ctx, g_kv, acc()), dkv, ctx, owner=wq)
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dkv, cb, g_kv, acc()), dkv, cb, owner=wq)
             else:
                 dq, dk, dv = b_att(do)
 
                 def wg_kv():
-                    ops.gemm_tn_f32(dk, ctx, ops.g2d(wk), acc())
-                    ops.gemm_tn_f32(dv, ctx, ops.g2d(wv), acc())
+                    ops.gemm_tn_f32(dk, cb, ops.g2d(wk), acc())
+                    ops.gemm_tn_f32(dv, cb, ops.g2d(wv), acc())
 
-                ops.on_wgrad_stream(wg_kv, dk, dv, ctx, owner=wq)
-            if ops._wgrad_queue is not None and ops._wgrad_queue.takes(wq) and dq.is_contiguous() and x.is_contiguous():
-                ops._wgrad_queue.add(dq, x, ops.g2d(wq))
+                ops.on_wgrad_stream(wg_kv, dk, dv, cb, owner=wq)
+            if ops._wgrad_queue is not None and ops._wgrad_queue.takes(wq) and dq.is_contiguous() and xb.is_contiguous():
+                ops._wgrad_queue.add(dq, xb, ops.g2d(wq))
             else:
-                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dq, x, ops.g2d(wq), acc()), dq, x, owner=wq)
+                ops.on_wgrad_stream(lambda: ops.gemm_tn_f32(dq, xb, ops.g2d(wq), acc()), dq, xb, owner=wq)
             dx = ops.gemm_nn(dq, ops.w2d(wq))
             dctx = None
             if self_attn or need_dctx:
@@ -222,14 +234,27 @@ class BasicTransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.norm3 = nn.LayerNorm(dim)
         self.checkpoint = checkpoint
+        # Selective recompute (the reference only has the whole-block torch.utils.checkpoint above): "norms" keeps
+        # every GEMM output (the fused q/k/v, the attention outputs, the FeedForward projection u) and REBUILDS in backward what is cheap to
+        # rebuild -- the three LayerNorm outputs (from the residual stream, which the LayerNorm backward holds anyway) and the GEGLU
+        # product a * gelu(g) (from u) -- instead of holding them: 7 of the block's 19 saved token matrices' worth of bytes for two
+        # elementwise passes.  Bit-identical results (the same kernels on the same inputs).  UNetModel.set_recompute() sets it network-wide.
+        self.recompute: Optional[str] = None
 
     def _fwd(self, x: Tensor, context: Optional[Tensor], B: int, need_dctx: bool):
+        if self.recompute not in (None, "norms"):
+            raise ValueError(f"BasicTransformerBlock.recompute must be None or 'norms', got {self.recompute!r}")
+        lean = self.recompute == "norms" and ops.recording()
+        again = (lambda t, n: (lambda: ops.layernorm_fwd(t, n.weight, n.bias, n.eps)[0])) if lean else (lambda t, n: None)
         n1, b_n1 = ops.layernorm_fwd(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        a1, b_a1 = self.attn1.fwd(n1, context if self.disable_self_attn else None, B, residual=x, need_dctx=need_dctx)
+        a1, b_a1 = self.attn1.fwd(n1, context if self.disable_self_attn else None, B, residual=x, need_dctx=need_dctx, x_saved=again(x, self.norm1))
+        del n1
         n2, b_n2 = ops.layernorm_fwd(a1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        a2, b_a2 = self.attn2.fwd(n2, context, B, residual=a1, need_dctx=need_dctx)
+        a2, b_a2 = self.attn2.fwd(n2, context, B, residual=a1, need_dctx=need_dctx, x_saved=again(a1, self.norm2))
+        del n2
         n3, b_n3 = ops.layernorm_fwd(a2, self.norm3.weight, self.norm3.bias, self.norm3.eps)
-        y, b_ff = self.ff.fwd(n3, residual=a2)
+        y, b_ff = self.ff.fwd(n3, residual=a2, x_saved=again(a2, self.norm3), recompute_h=lean)
+        del n3
 
         def bwd(dy: Tensor):
             with ops.batched_wgrads(self.norm1.weight):   # the block's small same-shape weight gradients go out as one launch
@@ -248,7 +273,7 @@ class BasicTransformerBlock(nn.Module):
     def fwd(self, x: Tensor, context: Optional[Tensor], B: int, need_dctx: bool = False):
         """x [B*L, C] tokens.  With `checkpoint` the block's activations are dropped and recomputed in backward
         (the reference wraps _forward in torch.utils.checkpoint, attention.py:482-485)."""
-        if not (self.checkpoint and torch.is_grad_enabled()):
+        if not (self.checkpoint and ops.recording()):
             return self._fwd(x, context, B, need_dctx)
         y, _ = self._fwd(x, context, B, need_dctx)
 

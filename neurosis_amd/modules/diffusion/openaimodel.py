@@ -211,7 +211,7 @@ class ResBlock(TimestepBlock):
     def fwd(self, x: Img, emb: Tensor):
         """bwd(dy tokens) -> (dx tokens, demb).  use_checkpoint drops and recomputes the block's activations
         (the reference wraps _forward in torch.utils.checkpoint, openaimodel.py:310-313)."""
-        if not (self.use_checkpoint and torch.is_grad_enabled()):
+        if not (self.use_checkpoint and ops.recording()):
             return self._fwd(x, emb)
         out, _ = self._fwd(x, emb)
 
@@ -397,6 +397,20 @@ class UNetModel(nn.Module):
         s, b1 = ops.silu_fwd(a)
         o, b2 = linear_module_fwd(seq[2], s)
         return o, (lambda g: b0(b1(b2(g))))
+
+    def set_recompute(self, policy: Optional[str]) -> "UNetModel":
+        """Selective activation recompute for every transformer block (BasicTransformerBlock.recompute): None keeps everything (default: 58 GB
+        at SDXL batch 4 on a 288 GB part), "norms" rebuilds LayerNorm outputs and GEGLU products in backward instead of holding them.  The
+        reference's own knob -- use_checkpoint, whole blocks through torch.utils.checkpoint -- is separate and still honoured."""
+        from ..attention import BasicTransformerBlock
+
+        if policy not in (None, "norms"):
+            raise ValueError(f"recompute policy must be None or 'norms', got {policy!r}")
+        for m in self.modules():
+            if isinstance(m, BasicTransformerBlock):
+                m.recompute = policy
+        self._nk_graphs = None          # captured launch sequences belong to the old policy
+        return self
 
     def _project_context(self, context: Tensor) -> None:
         """`to_k(context)`, `to_v(context)` of EVERY cross-attention of the network before the first block runs (reference

@@ -24,7 +24,8 @@ class NkFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, run: Callable, n_in: int, *args):
-        out, bwd = run(*args[:n_in])
+        with ops.recording_backward():      # (grad mode is off in here: the modules ask ops.recording() whether a backward follows)
+            out, bwd = run(*args[:n_in])
         ctx.bwd = bwd
         ctx.n_in = n_in
         ctx.n_args = len(args)
@@ -211,8 +212,8 @@ class Conv2d(nn.Module):
         return apply_module(run, [x], self)
 
 
-def linear_module_fwd(lin: nn.Linear, x: Tensor, residual: Optional[Tensor] = None, need_dx: bool = True):
-    return ops.linear_fwd(x, lin.weight, lin.bias, residual, need_dx)
+def linear_module_fwd(lin: nn.Linear, x: Tensor, residual: Optional[Tensor] = None, need_dx: bool = True, x_saved=None):
+    return ops.linear_fwd(x, lin.weight, lin.bias, residual, need_dx, x_saved)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -110,6 +110,26 @@ def wgrad_mode(p=None) -> int:
     return 2 if st.assume_zeroed else 0
 
 
+# Whether the forward now running will be followed by a backward (its closures are kept).  torch.is_grad_enabled() cannot answer that
+# inside the autograd bridge: torch.autograd.Function.forward always runs with grad mode off.  nn.NkFunction.forward raises the flag around
+# `run`; the activation-dropping policies (ResBlock.use_checkpoint, BasicTransformerBlock.checkpoint / .recompute) read it.
+_recording = 0
+
+
+class recording_backward:
+    def __enter__(self):
+        global _recording
+        _recording += 1
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording -= 1
+
+
+def recording() -> bool:
+    return _recording > 0
+
+
 def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None) -> None:
     """Run `fn` (kernels that only WRITE parameter gradients of `owner`'s engine) on that engine's side stream if it has one.
 
@@ -470,14 +490,15 @@ def colsum(dy: Tensor, out: Tensor, accumulate: bool) -> None:
     call("nk_colsum", dy.data_ptr(), out.data_ptr(), ws.data_ptr(), M, N, dy.stride(0), int(accumulate), _stream())
 
 
-def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor] = None, need_dx: bool = True):
+def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor] = None, need_dx: bool = True, x_saved=None):
     """nn.Linear forward on a token matrix, with optional fused residual add.
-    bwd(dy, dx_add=None) -> dx (None if need_dx is False); writes weight.grad / bias.grad."""
+    bwd(dy, dx_add=None) -> dx (None if need_dx is False); writes weight.grad / bias.grad.
+    x_saved: a zero-argument callable that REBUILDS x for the weight gradient (selective recompute: the caller drops x after the forward)."""
     y = gemm_nt(x, w2d(weight), bias, residual)
-    return y, _linear_bwd(x, weight, bias, need_dx)
+    return y, _linear_bwd(x if x_saved is None else x_saved, weight, bias, need_dx)
 
 
-def linear_geglu_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor]):
+def linear_geglu_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_saved=None):
     """FeedForward.net[0] = GEGLU (modules/attention.py:50-57): u = x @ weight^T + bias [M, 2I] and h = u[:, :I] * gelu(u[:, I:]) [M, I].
     One launch (the GEGLU in the projection's epilogue, nk_linear_fwd_geglu) where the 256 x 256 kernel takes the shape -- the two SDXL
     FeedForward widths at batch 4 -- else the GEMM followed by the GEGLU kernel.  Returns (u, h, bwd); bwd(du) as linear_fwd's."""
@@ -494,13 +515,14 @@ def linear_geglu_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor]):
     else:
         u = gemm_nt(x, wq, bias, None)
         h = geglu_fwd(u)[0]
-    return u, h, _linear_bwd(x, weight, bias, True)
+    return u, h, _linear_bwd(x if x_saved is None else x_saved, weight, bias, True)
 
 
-def _linear_bwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], need_dx: bool):
+def _linear_bwd(x_in, weight: Tensor, bias: Optional[Tensor], need_dx: bool):
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None, geglu_u: Optional[Tensor] = None):
         """geglu_u = the [a | g] matrix whose GEGLU produced x (FeedForward): the returned gradient is then d/du [M, 2K], the GEGLU
         backward applied in the input-gradient GEMM's epilogue (nk_linear_dgrad_geglu)"""
+        x = x_in() if callable(x_in) else x_in         # (selective recompute: the layer's input is rebuilt now, on the current stream)
         queued = _wgrad_queue is not None and _wgrad_queue.takes(weight) and dy.is_contiguous() and x.is_contiguous()
         # the bias gradient (column sums of dy) comes out of the weight-gradient launch: every parameter gradient is OVERWRITTEN by its
         # (single) producer unless accumulating -- the same mode for both
