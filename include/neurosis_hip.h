@@ -75,6 +75,9 @@ int nk_health_clear(void);
 int nk_health_export(int* dst, void* stream);
 int nk_health_import(const int* src, void* stream);
 int nk_debug_raise_health(void* stream);
+/* Diagnostic: writes the device's 100 MHz constant clock (s_memrealtime) to *dst, stream-ordered and capturable into a hipGraph
+ * (tools/step_timeline.py: where the replayed backward segments of the two streams lie in time, untraced). */
+int nk_debug_stamp(unsigned long long* dst, void* stream);
 
 /* `count` (<= 8) weight gradients of identical shape in ONE launch: the three 1280x1280 projections of a transformer
  * block are 100 tiles each, far below one workgroup per CU on their own.  dy / x / dw are HOST arrays of device pointers. */

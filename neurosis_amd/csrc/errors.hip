@@ -103,6 +103,16 @@ extern "C" int nk_debug_raise_health(void* stream) {
   return nk_check_launch("nk_raise_health_kernel");
 }
 
+// diagnostic: a stream-ordered timestamp (the 100 MHz constant clock, s_memrealtime) into a caller-owned device word -- capturable into a
+// hipGraph, which HIP events are not: tools/step_timeline.py stamps the replayed segments of the backward with it, UNTRACED (the kernel trace
+// perturbs how two streams overlap)
+__global__ void nk_stamp_kernel(unsigned long long* dst) { *dst = __builtin_amdgcn_s_memrealtime(); }
+extern "C" int nk_debug_stamp(unsigned long long* dst, void* stream) {
+  NK_CHECK_ARG(dst != nullptr);
+  hipLaunchKernelGGL(nk_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst);
+  return nk_check_launch("nk_stamp_kernel");
+}
+
 // ---- the health word across data-parallel ranks: export this rank's word into a caller-owned int32 (the caller reduces it over the ranks with
 // MAX, on the exchange stream), import the result back (OR).  A rank whose stream-K fix-up gave up poisons its gradient tile with NaN and the
 // all-reduce spreads that NaN to every rank: with the word merged, every rank's optimizer kernels skip the update, not only the flagged one's.

@@ -57,6 +57,37 @@ def graphs_enabled(kind: str = "unet") -> bool:
     return kind in v.split(",")
 
 
+class Stamps:
+    """Diagnostic (tools/step_timeline.py): named device timestamps, nk_debug_stamp launches on the current stream -- captured into the
+    replayed segments when enabled BEFORE the capture.  `read()` synchronises and returns {label: microseconds since the earliest}."""
+
+    def __init__(self, device, slots: int = 1024):
+        self.buf = torch.zeros(slots, dtype=torch.int64, device=device)
+        self.slot: dict = {}
+
+    def mark(self, label: str) -> None:
+        from .lib import call
+
+        i = self.slot.setdefault(label, len(self.slot))
+        if i >= self.buf.numel():
+            raise RuntimeError("neurosis_amd.graphs.Stamps: out of slots")
+        call("nk_debug_stamp", self.buf.data_ptr() + 8 * i, ops._stream())
+
+    def read(self) -> dict:
+        torch.cuda.synchronize()
+        v = self.buf.cpu().tolist()
+        t0 = min(v[i] for i in self.slot.values() if v[i])
+        return {k: (v[i] - t0) / 100.0 for k, i in self.slot.items() if v[i]}      # 100 MHz -> us
+
+
+stamps: Optional[Stamps] = None      # set by the tool; None in production: no launch, no branch inside a captured sequence
+
+
+def _mark(label: str) -> None:
+    if stamps is not None:
+        stamps.mark(label)
+
+
 class _Pair:
     __slots__ = ("g_f", "segments", "static_in", "out", "closure", "dout", "dx", "gen", "warm")
 
@@ -183,7 +214,9 @@ class ChainGraphs:
         with torch.cuda.stream(self.stream), ops.capture_scope():
             g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
             try:
+                _mark("F.begin")
                 pair.out, pair.closure = fwd(*pair.static_in)
+                _mark("F.end")
             finally:
                 g.capture_end()
         pair.g_f = g
@@ -202,11 +235,13 @@ class ChainGraphs:
         def begin():
             cur[0] = torch.cuda.CUDAGraph()
             cur[0].capture_begin(pool=self.pool, capture_error_mode="thread_local")
+            _mark(f"M{len(segments)}.begin")
 
         def cut(module=None):
             """End of a segment of the main chain: close M_k, capture what the segment parked for the side stream as W_k."""
             if module is None:
                 self.ticks.add_(1)        # (the tail after the last block may hold no launch at all: an empty graph cannot be instantiated)
+            _mark(f"M{len(segments)}.end")
             cur[0].capture_end()
             g_m, g_w = cur[0], None
             parked, st.deferred = st.deferred, ([] if side is not None else None)
@@ -215,8 +250,10 @@ class ChainGraphs:
                 with torch.cuda.stream(side):
                     g_w.capture_begin(pool=self.pool_w, capture_error_mode="thread_local")
                     try:
+                        _mark(f"W{len(segments)}.begin")
                         for fn, _reads in parked:
                             fn()
+                        _mark(f"W{len(segments)}.end")
                     finally:
                         g_w.capture_end()
                 held.append(parked)       # the closures hold what W_k reads: nothing of it may be recycled by a later M capture

@@ -98,6 +98,7 @@ SIGNATURES: dict[str, list] = {
     "nk_adamw_flat": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp],
     "nk_ema_flat": [vp, vp, i64, f32, vp],
     "nk_debug_raise_health": [vp],
+    "nk_debug_stamp": [vp, vp],
     "nk_health_clear": [],
     "nk_health_export": [vp, vp],
     "nk_health_import": [vp, vp],
