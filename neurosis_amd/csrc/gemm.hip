@@ -1376,8 +1376,10 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
 }
 
 static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk);
+__global__ void nk_zero_f32_kernel(float* __restrict__ dst, size_t n);
 #include "gemm_g2.h"
 #include "conv_halo.h"
+#include "conv_wgrad_halo.h"
 
 static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk) {
   static int on = -1;
@@ -1620,6 +1622,8 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   }
   // 3 x 3 / stride 1 / padding 1 convolutions over whole 64-channel slabs: the halo-tile kernel (conv_halo.h)
   if (use_halo(p, amode, bmode, out_f32)) return launch_halo(p, stream);
+  // ... and their weight gradients: nine taps from one staged halo per pixel tile (conv_wgrad_halo.h)
+  if (use_wgrad_halo(p, amode, bmode, out_f32)) return launch_wgrad_halo(p, stream);
   if (p.stats_part) {      // the GroupNorm statistics epilogue exists in the halo-tile kernel only
     nk_set_error(__FILE__, __LINE__, "statistics epilogue on a convolution the halo-tile kernel does not take (ask nk_conv2d_stats_tiles first)");
     return NK_ERR_ARG;

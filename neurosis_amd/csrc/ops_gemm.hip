@@ -284,6 +284,7 @@ static int conv_wgrad(const NkConvDesc* d, const void* dy, const void* x, float*
   p.C = dw; p.ldc = p.N;
   p.accumulate = accumulate;
   p.dbias = dbias;
+  p.halo_nb = (d->KH == 3 && d->KW == 3) ? d->N : 0;       // 3 x 3 / stride 1 / padding 1 shapes may take the halo-tile weight-gradient kernel
   return nk_gemm_dispatch(p, NK_OP_MC, NK_OP_MCG, 1, 1, (hipStream_t)stream);
 }
 extern "C" int nk_conv2d_wgrad(const NkConvDesc* d, const void* dy, const void* x, float* dw, int accumulate,
