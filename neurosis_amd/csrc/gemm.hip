@@ -77,6 +77,25 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
                                                  int lane, int wm, int wn) {
   // ---- epilogue: accumulators -> LDS (fp32, [128][CS_LD]) -> coalesced global stores ----
   float* cs = (float*)smem;
+  // GEGLU backward (below): the saved u = [a | g] of this thread's chunks is fetched BEFORE the accumulators are staged -- issued inside the
+  // store loop, two iterations at a time, the loads' latency (two dependent HBM round trips per tile, nothing else in flight at two
+  // workgroups per CU) was a third of the launch
+  constexpr int GIT = OUT_F32 ? 1 : (TBM * BN / 8) / TNT;
+  uint4_t gu_a[GIT], gu_g[GIT];
+  const bool geglu = !OUT_F32 && p.geglu_u != nullptr && (p.N & 7) == 0;      // wave-uniform
+  if constexpr (!OUT_F32) {
+    if (geglu) {
+#pragma unroll
+      for (int it = 0; it < GIT; ++it) {
+        const int idx = tid + it * TNT;
+        const int m = m0 + (idx >> 4), n = n0 + (idx & 15) * 8;
+        const bool ok = m < p.M && n < p.N;
+        const bf16_t* up = p.geglu_u + (long)(ok ? m : 0) * p.ld_u + (ok ? n : 0);
+        gu_a[it] = *(const uint4_t*)up;
+        gu_g[it] = *(const uint4_t*)(up + p.N);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -88,6 +107,40 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
         cs[row * CS_LD + col] = acc[i][j][r];
       }
   __syncthreads();
+
+  if constexpr (!OUT_F32) {
+    if (geglu) {
+      // GEGLU backward (modules/attention.py:55-57, y = a * gelu(g)): this tile holds d = dL/dy; u = [a | g] was saved by the forward
+      bf16_t* C = (bf16_t*)p.C;
+#pragma unroll
+      for (int it = 0; it < GIT; ++it) {
+        const int idx = tid + it * TNT;
+        const int row = idx >> 4, cc = idx & 15;
+        const int m = m0 + row, n = n0 + cc * 8;
+        if (m >= p.M || n >= p.N) continue;
+        const float4_t c0 = *(const float4_t*)(cs + row * CS_LD + cc * 8);
+        const float4_t c1 = *(const float4_t*)(cs + row * CS_LD + cc * 8 + 4);
+        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        if (p.alpha != 1.0f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+        }
+        float a[8], g[8], da[8], dg[8];
+        unpack8(gu_a[it], a);
+        unpack8(gu_g[it], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float cdf, pdf;
+          normal_cdf_pdf(g[e], cdf, pdf);
+          da[e] = v[e] * (g[e] * cdf);
+          dg[e] = v[e] * a[e] * (cdf + g[e] * pdf);
+        }
+        *(uint4_t*)(C + (long)m * p.ldc + n) = pack8(da);
+        *(uint4_t*)(C + (long)m * p.ldc + p.N + n) = pack8(dg);
+      }
+      return;
+    }
+  }
 
   if constexpr (OUT_F32) {
     float* C = (float*)(p.nbatch ? p.Cb[blockIdx.z] : p.C);
@@ -133,22 +186,6 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
       if (p.alpha != 1.0f) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-      }
-      if (vec && p.geglu_u) {
-        // GEGLU backward (modules/attention.py:55-57, y = a * gelu(g)): this tile holds d = dL/dy; u = [a | g] was saved by the forward
-        float a[8], g[8], da[8], dg[8];
-        unpack8(*(const uint4_t*)(p.geglu_u + (long)m * p.ld_u + n), a);
-        unpack8(*(const uint4_t*)(p.geglu_u + (long)m * p.ld_u + p.N + n), g);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float cdf, pdf;
-          normal_cdf_pdf(g[e], cdf, pdf);
-          da[e] = v[e] * (g[e] * cdf);
-          dg[e] = v[e] * a[e] * (cdf + g[e] * pdf);
-        }
-        *(uint4_t*)(C + (long)m * p.ldc + n) = pack8(da);
-        *(uint4_t*)(C + (long)m * p.ldc + p.N + n) = pack8(dg);
-        continue;
       }
       if (vec) {
         if (p.bias) {
