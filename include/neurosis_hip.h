@@ -149,7 +149,7 @@ int nk_conv2d_wgrad_bias(const NkConvDesc* d, const void* dy, const void* x, flo
  * column slices of a fused projection buffer.  lse is [B][H][Lq] fp32 (saved for the backward).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct NkAttnDesc {
-  int B, H, Lq, Lk, D;          /* D % 8 == 0, D <= 160 */
+  int B, H, Lq, Lk, D;          /* D % 8 == 0, D <= 160; forward only: D == 512 (the VAE mid block's single head, model.py:224-243; lse may be NULL) */
   long sq, sk, sv, so;          /* row strides of q, k, v, o */
   long bq, bk, bv, bo;          /* batch strides */
   long sdq, sdk, sdv, sdo;      /* backward only: row strides of dq, dk, dv, do */
@@ -163,8 +163,9 @@ int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* k, const vo
 long nk_attention_bwd_ws_floats(const NkAttnDesc* d);
 int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, const void* o,
                      const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* delta_ws, void* stream);
-/* in-place row softmax on bf16 [M][L]: the unfused single-head d=512 attention of the VAE mid block
- * (modules/diffusion/model.py:224-243) = nk_linear_fwd (q k^T) -> nk_softmax_rows -> nk_linear_dgrad (p v) */
+/* in-place row softmax on bf16 [M][L]: unfused single-head attention = nk_linear_fwd (q k^T) -> nk_softmax_rows -> nk_linear_dgrad (p v).
+ * Serves the VAE mid block (modules/diffusion/model.py:224-243) when the autoencoder is TRAINED (the probabilities are kept for the
+ * backward) and head dims the flash kernels do not take; the frozen encoder's d = 512 forward is nk_attention_fwd. */
 int nk_softmax_rows(void* s, long M, int L, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

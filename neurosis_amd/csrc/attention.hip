@@ -1683,10 +1683,12 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParam
 // ================================================================================================
 // host
 // ================================================================================================
+#include "attn512.h"
+
 static int attn_check(const NkAttnDesc* d) {
   NK_CHECK_ARG(d != nullptr);
   NK_CHECK_ARG(d->B > 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0 && d->D > 0);
-  NK_CHECK_ARG((d->D & 7) == 0 && d->D <= 160);
+  NK_CHECK_ARG((d->D & 7) == 0 && (d->D <= 160 || d->D == 512));     // 512: forward only (attn512.h)
   NK_CHECK_ARG((d->sq & 7) == 0 && (d->sk & 7) == 0 && (d->sv & 7) == 0 && (d->so & 7) == 0);
   NK_CHECK_ARG((d->bq & 7) == 0 && (d->bk & 7) == 0 && (d->bv & 7) == 0 && (d->bo & 7) == 0);
   NK_CHECK_ARG(d->B <= 65535 && d->H <= 65535);
@@ -1711,7 +1713,7 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
                                 void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = attn_check(d)) return e;
-  NK_CHECK_ARG(q && k && v && o && lse);
+  NK_CHECK_ARG(q && k && v && o && (lse || d->D == 512));
   AttnParams p = {};
   p.Q = (const bf16_t*)q; p.K = (const bf16_t*)k; p.V = (const bf16_t*)v; p.O = (bf16_t*)o; p.LSE = lse;
   p.B = d->B; p.H = d->H; p.Lq = d->Lq; p.Lk = d->Lk; p.D = d->D;
@@ -1722,6 +1724,14 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
   NK_CHECK_ARG(!d->causal || d->Lq == d->Lk);
   constexpr int nw = ATTN_NW;
   dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
+  if (d->D == 512) {
+    // the VAE mid block's single head: one workgroup per CU, 512 registers per lane, 128 KiB of LDS (attn512.h); lse may be null
+    NK_CHECK_ARG(!d->causal);
+    const int smem512 = 4 * 32 * 1024;
+    set_smem(attn512_fwd_kernel, smem512);
+    hipLaunchKernelGGL(attn512_fwd_kernel, grid, dim3(256), smem512, stream, p);
+    return nk_check_launch("attn512_fwd_kernel");
+  }
   const int dp = attn_dp(d->D);
   const int smem = 2 * 2 * 64 * (dp * 2 + 16);
 #define FWD_CASE(DP_)                                                                          \
@@ -1777,6 +1787,7 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   if (int e = attn_check(d)) return e;
   NK_CHECK_ARG(q && k && v && o && lse && d_o && dq && dk && dv && delta_ws);
   NK_CHECK_ARG(!d->causal);   // the causal variant serves the frozen text encoders: forward only
+  NK_CHECK_ARG(d->D <= 160);  // head dim 512 (VAE mid block): forward only here; its training path keeps the probabilities (ops.attention_unfused_fwd)
   NK_CHECK_ARG((d->sdq & 7) == 0 && (d->sdk & 7) == 0 && (d->sdv & 7) == 0 && (d->sdo & 7) == 0);
   NK_CHECK_ARG((d->bdq & 7) == 0 && (d->bdk & 7) == 0 && (d->bdv & 7) == 0 && (d->bdo & 7) == 0);
   AttnParams p = {};

@@ -1,0 +1,362 @@
+// Head dim 512: the single-head attention of the VAE mid block (modules/diffusion/model.py:224-243, AttnBlock / TorchSDPAttnBlock:
+// softmax(q k^T / sqrt(512)) v over H*W tokens), as ONE flash kernel -- no [L][L] score matrix in HBM.  Included by attention.hip.
+//
+// Why this shape.  At d = 512 the operands are what is large: a query row is 1 KiB, the O accumulator of 32 queries is 64 KiB of fp32.
+// The only place both fit is the register file of a wave that owns its SIMD: 4 waves per workgroup, ONE workgroup per CU,
+// launch_bounds(256, 1) = 512 registers per lane:
+//   Q'^T fragments (32 queries x 512, bf16, pre-multiplied by scale * log2 e)   128 VGPRs
+//   O^T accumulator (512 x 32 queries, fp32)                                    256 AGPRs
+//   a score block, two batches of K / V fragments, addresses                    ~100 VGPRs
+// K and V tiles of 32 keys (32 KiB each) arrive by LDS-DMA one tile ahead into two stages each (128 KiB of the CU's 160).
+// Per 32-key tile and wave: 32 + 32 v_mfma_f32_32x32x16_bf16 (2 048 matrix-pipe cycles) against 16 exponentials per lane, so unlike
+// head dim 64 the loop is matrix-bound; what has to be hidden is LDS latency with one wave per SIMD, hence the explicit batches
+// (eight fragments requested while the previous eight are multiplied).  LDS traffic: every wave reads the whole K and V tile,
+// 256 KiB per tile and CU = 1 024 of the 2 048 cycles at 256 B / clk; the fill path carries 64 KiB per tile = 1 024 cycles at 64 B / clk.
+//
+// LDS image of a [32 keys][512] bf16 tile (1 KiB rows): the 16-byte chunk c of row r lives in slot  (c & 48) | ((c & 15) ^ g(r)),
+// g(r) = (r & 3) << 2 | (r >> 2) & 3:
+//  * row reads (ds_read_b128, lane & 31 = row, one chunk; a pass = 16 lanes = rows {0-3,12-15,20-27} or {4-11,16-19,28-31}): the 16 rows
+//    of a pass have 16 different g -> 16 different 16-byte windows of the 256-byte bank line: conflict-free;
+//  * transposed reads (ds_read_b64_tr_b16; a 32-lane half = 4 consecutive rows x 64 bytes): bits 2-3 of g are the row's bits 0-1, so the
+//    four rows take the four 64-byte windows: conflict-free.
+// One DMA wave instruction deposits 1 KiB = one row linearly; the swizzle is applied on the SOURCE side (lane l fetches chunk
+// (l & 48) | ((l & 15) ^ g(r))).  Rows past Lk are fetched from row Lk - 1 and their scores masked.
+#pragma once
+
+__device__ __forceinline__ int a512_g(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+#define A512_RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define A512_RDTR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define A512_WAIT4(x) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+#define A512_WAIT4_KEEP4(x) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]))
+
+struct A512V {          // one batch of V^T fragments: four d-tiles x (low, high) 8 key rows
+  short4_t lo[4], hi[4];
+};
+#define A512_WAITV(x)                                                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x.lo[0]), "+v"(x.lo[1]), "+v"(x.lo[2]), "+v"(x.lo[3]), "+v"(x.hi[0]), "+v"(x.hi[1]), \
+               "+v"(x.hi[2]), "+v"(x.hi[3]))
+#define A512_WAITV_KEEP8(x)                                                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x.lo[0]), "+v"(x.lo[1]), "+v"(x.lo[2]), "+v"(x.lo[3]), "+v"(x.hi[0]), "+v"(x.hi[1]), \
+               "+v"(x.hi[2]), "+v"(x.hi[3]))
+
+// ---- the O^T accumulator: the whole AGPR file, a[16 n : 16 n + 15] = d-tile n, addressed PHYSICALLY from inline asm.
+// Left to the register allocator (MFMA builtins, or inline-asm MFMAs on "+a" operands) a kernel with 256 accumulator + 128 operand registers
+// copied accumulator blocks between the two register files at the loop head and spilled 340-370 registers per lane.  Here the compiler never
+// sees the accumulator: it allocates no AGPR of its own (checked in the ISA: tools/check_resources.sh lists 0 bytes of scratch and the only
+// v_accvgpr_* / a[...] instructions are the ones below), the "a255" clobber makes it reserve the file.  What the hazard recogniser therefore
+// cannot see is covered by construction: an accumulator block is read as SrcC >= 16 MFMAs after it was written, v_accvgpr_read / _write run
+// only after a score chain's result has been consumed by vector code (all earlier MFMAs have retired) or behind explicit s_nops.
+// every AGPR, as a clobber list: the compiler may keep nothing of its own in the accumulator file across the statements that carry it
+#define A512_ALL_AGPRS \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+  "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+  "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+  "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+  "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+  "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+  "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+  "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", \
+  "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+  "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", \
+  "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+  "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+  "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+  "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+  "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+  "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+#define A512_R16(OP_, IDX_)                                                                                                      \
+  OP_(IDX_, 0) OP_(IDX_, 1) OP_(IDX_, 2) OP_(IDX_, 3) OP_(IDX_, 4) OP_(IDX_, 5) OP_(IDX_, 6) OP_(IDX_, 7)                        \
+  OP_(IDX_, 8) OP_(IDX_, 9) OP_(IDX_, 10) OP_(IDX_, 11) OP_(IDX_, 12) OP_(IDX_, 13) OP_(IDX_, 14) OP_(IDX_, 15)
+template <int N>
+__device__ __forceinline__ void a512_acc_zero() {
+#define A512_Z(IDX_, I_) "v_accvgpr_write_b32 a[%0*16+" #I_ "], 0\n\t"
+  asm volatile(A512_R16(A512_Z, 0) : : "n"(N) : A512_ALL_AGPRS);
+#undef A512_Z
+}
+template <int N>
+__device__ __forceinline__ void a512_acc_scale(float alpha) {
+  float t0, t1;
+#define A512_S(IDX_, I_) "v_accvgpr_read_b32 %0, a[%3*16+" #I_ "]\n\tv_mul_f32 %0, %2, %0\n\tv_accvgpr_write_b32 a[%3*16+" #I_ "], %0\n\t"
+  asm volatile(A512_R16(A512_S, 0) : "=&v"(t0), "=&v"(t1) : "v"(alpha), "n"(N));
+#undef A512_S
+}
+template <int N>
+__device__ __forceinline__ float16_t a512_acc_read() {
+  float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
+#define A512_G(IDX_, I_) "v_accvgpr_read_b32 %" #I_ ", a[%16*16+" #I_ "]\n\t"
+  asm volatile(A512_R16(A512_G, 0)
+               : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7), "=v"(r8), "=v"(r9), "=v"(r10), "=v"(r11),
+                 "=v"(r12), "=v"(r13), "=v"(r14), "=v"(r15)
+               : "n"(N));
+#undef A512_G
+  float16_t r = {r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15};
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void a512_mfma(const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%2*16:%2*16+15], %0, %1, a[%2*16:%2*16+15]" : : "v"(a), "v"(b), "n"(N));
+}
+template <int N, typename F>
+__device__ __forceinline__ void a512_for_blocks(F&& f) {
+  if constexpr (N < 16) {
+    f(std::integral_constant<int, N>{});
+    a512_for_blocks<N + 1>(f);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p) {
+  constexpr int KT = 32, ROWB = 1024, TILE = KT * ROWB;     // 32 KiB
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // K stage 0, K stage 1, V stage 0, V stage 1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h5 = lane >> 5, ql = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float c = p.scale * LOG2E;
+
+  const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * 512;
+  const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * 512;
+  const bf16_t* Vb = p.V + (long)b * p.bv + (long)hd * 512;
+  const int nt = (p.Lk + KT - 1) / KT;
+
+  // ---- LDS-DMA: a tile is 32 rows = 32 wave instructions, 8 per wave; lane l of row r fetches chunk (l & 48) | ((l & 15) ^ g(r)).
+  // Whole tiles: wave-uniform tile pointer + one per-lane byte offset per piece, kept in registers (K and V share them: whole-tile path needs sk == sv).
+  int doff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = wave * 8 + j;
+    const int ch = (lane & 48) | ((lane & 15) ^ a512_g(row));
+    doff[j] = (int)((row * p.sk + ch * 8) * 2);
+  }
+  auto issue_whole = [&](const bf16_t* tile, char* img) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      __builtin_amdgcn_global_load_lds((att_gptr)((const char*)tile + doff[j]), (att_lptr)(img + (wave * 8 + j) * ROWB), 16, 0, 0);
+  };
+  // the last tile when Lk % 32 != 0: rows past the end come from row Lk - 1 (masked below)
+  auto issue_tail = [&](const bf16_t* base, long stride, int row0, char* img) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = wave * 8 + j;
+      const int r = min(row0 + row, p.Lk - 1);
+      const int ch = (lane & 48) | ((lane & 15) ^ a512_g(row));
+      __builtin_amdgcn_global_load_lds((att_gptr)(base + (long)r * stride + ch * 8), (att_lptr)(img + row * ROWB), 16, 0, 0);
+    }
+  };
+  auto issue = [&](int t, int st) {
+    if ((t + 1) * KT <= p.Lk && p.sk == p.sv) {
+      issue_whole(Kb + (long)t * KT * p.sk, smem + st * TILE);
+      issue_whole(Vb + (long)t * KT * p.sv, smem + (2 + st) * TILE);
+    } else {
+      issue_tail(Kb, p.sk, t * KT, smem + st * TILE);
+      issue_tail(Vb, p.sv, t * KT, smem + (2 + st) * TILE);
+    }
+  };
+  issue(0, 0);
+
+  // ---- per-lane fragment addresses (tile-relative)
+  // K row reads: fragment ks = chunk 2 ks + h5 of row ql  ->  kab[ks & 7] + (ks >> 3) * 256
+  unsigned kab[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) kab[j] = (unsigned)(ql * ROWB + (((2 * j + h5) ^ a512_g(ql)) << 4));
+  // V^T transposed reads (see tr_frag): lane -> row 4 h + q4 (+ 8 for the high half, + 16 s2), 8 bytes at columns 32 dt + 16 (g4 & 1) + 4 pp:
+  // chunk 4 dt + c0, c0 = 2 (g4 & 1) + (pp >> 1); slot = (dt >> 2) * 16 + (((dt & 3) ^ q4) << 2 | (c0 ^ ((h + 2 j) & 3)))
+  unsigned vab[2][4];
+  {
+    const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h = g4 >> 1;
+    const int c0 = 2 * (g4 & 1) + (pp >> 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int d4 = 0; d4 < 4; ++d4)
+        vab[j][d4] = (unsigned)((4 * h + q4 + 8 * j) * ROWB + ((((d4 ^ q4) << 2) | (c0 ^ ((h + 2 * j) & 3))) << 4) + 8 * (pp & 1));
+  }
+
+  // ---- Q'^T fragments: bf16(Q * scale * log2 e), as the head-dim-64 kernel (and the reference's math path) rounds them
+  bf16x8_t qf[32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    uint4_t z = {0u, 0u, 0u, 0u};
+    if (q0 + ql < p.Lq) z = *(const uint4_t*)(Qb + (long)(q0 + ql) * p.sq + 16 * ks + 8 * h5);
+    float f[8];
+    unpack8(z, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= c;
+    qf[ks] = __builtin_bit_cast(bf16x8_t, pack8(f));
+    if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);     // eight rows' worth of loads in flight at a time (register pressure)
+  }
+  a512_for_blocks<0>([&](auto n) { a512_acc_zero<decltype(n)::value>(); });
+  float m = 0.f, l = 0.f;      // m: reference point of this lane's query row (log2 units); l: this lane's half of the row sum
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const unsigned smem_a = (unsigned)(size_t)(lds_c)smem;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("" ::: A512_ALL_AGPRS);      // (nothing of the compiler's lives in the AGPRs across an iteration)
+    const int st = t & 1;
+    if (t + 1 < nt) issue(t + 1, st ^ 1);
+    const unsigned kt = smem_a + st * TILE, vt = smem_a + (2 + st) * TILE;
+
+    // ---- S'^T[key][q] = K Q'^T: 32 chained MFMAs, K fragments in four batches of eight, each requested one batch ahead
+    float16_t s;
+    {
+      bf16x8_t ka[4], kb[4];
+      // batch B_ (0..7) = fragments ks = 4 B_ .. 4 B_ + 3: addresses kab[(4 B_ & 7) + j] + (B_ >> 1) * 256
+#define A512_RDK(dst, B_)                                                                                                       \
+      A512_RD128(dst[0], kt + kab[4 * ((B_) & 1) + 0], ((B_) >> 1) * 256); A512_RD128(dst[1], kt + kab[4 * ((B_) & 1) + 1], ((B_) >> 1) * 256); \
+      A512_RD128(dst[2], kt + kab[4 * ((B_) & 1) + 2], ((B_) >> 1) * 256); A512_RD128(dst[3], kt + kab[4 * ((B_) & 1) + 3], ((B_) >> 1) * 256)
+#define A512_MMK(src, B_)                                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                             \
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(src[j]), "v"(qf[4 * (B_) + j]))
+      A512_RDK(ka, 0);
+      A512_RDK(kb, 1);
+      A512_WAIT4_KEEP4(ka);
+      __builtin_amdgcn_sched_barrier(0);
+      // (the score chain in VGPRs by inline asm as well: as a builtin chain the compiler placed it in a[0:15], on top of d-tile 0.  Back-to-back
+      // MFMAs accumulating into the same block need no wait states; the vector reads behind the chain get theirs from the s_nop below.)
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(s) : "v"(ka[0]), "v"(qf[0]));
+#pragma unroll
+      for (int j = 1; j < 4; ++j) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(ka[j]), "v"(qf[j]));
+      A512_RDK(ka, 2);
+      A512_WAIT4_KEEP4(kb);
+      __builtin_amdgcn_sched_barrier(0);
+      A512_MMK(kb, 1);
+      A512_RDK(kb, 3);
+      A512_WAIT4_KEEP4(ka);
+      __builtin_amdgcn_sched_barrier(0);
+      A512_MMK(ka, 2);
+      A512_RDK(ka, 4);
+      A512_WAIT4_KEEP4(kb);
+      __builtin_amdgcn_sched_barrier(0);
+      A512_MMK(kb, 3);
+      A512_RDK(kb, 5);
+      A512_WAIT4_KEEP4(ka);
+      __builtin_amdgcn_sched_barrier(0);
+      A512_MMK(ka, 4);
+      A512_RDK(ka, 6);
+      A512_WAIT4_KEEP4(kb);
+      __builtin_amdgcn_sched_barrier(0);
+      A512_MMK(kb, 5);
+      A512_RDK(kb, 7);
+      A512_WAIT4_KEEP4(ka);
+      __builtin_amdgcn_sched_barrier(0);
+      A512_MMK(ka, 6);
+      A512_WAIT4(kb);
+      __builtin_amdgcn_sched_barrier(0);
+      A512_MMK(kb, 7);
+      asm volatile("s_nop 15" : "+v"(s));
+#undef A512_RDK
+#undef A512_MMK
+    }
+    // ---- the first two batches of V^T fragments are requested NOW (they do not depend on P; the softmax below covers their latency)
+    // batch (s2, q) = k-step s2 (keys 16 s2 ..), d-tiles 4 q .. 4 q + 3
+    A512V va, vb;
+#define A512_RDV(dst, S2_, Q_)                                                                                                  \
+    A512_RDTR(dst.lo[0], vt + vab[0][0], (S2_) * 16384 + (Q_) * 256); A512_RDTR(dst.hi[0], vt + vab[1][0], (S2_) * 16384 + (Q_) * 256); \
+    A512_RDTR(dst.lo[1], vt + vab[0][1], (S2_) * 16384 + (Q_) * 256); A512_RDTR(dst.hi[1], vt + vab[1][1], (S2_) * 16384 + (Q_) * 256); \
+    A512_RDTR(dst.lo[2], vt + vab[0][2], (S2_) * 16384 + (Q_) * 256); A512_RDTR(dst.hi[2], vt + vab[1][2], (S2_) * 16384 + (Q_) * 256); \
+    A512_RDTR(dst.lo[3], vt + vab[0][3], (S2_) * 16384 + (Q_) * 256); A512_RDTR(dst.hi[3], vt + vab[1][3], (S2_) * 16384 + (Q_) * 256)
+    A512_RDV(va, 0, 0);
+    A512_RDV(vb, 0, 1);
+
+    // ---- online softmax in log2 units; m moves only when a score exceeds it by more than 2^8 ("defer-max", cdna guide T13)
+    if (t == nt - 1 && (p.Lk & (KT - 1))) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = (t * KT + acc_row(r, h5)) < p.Lk ? s[r] : NEG_BIG;
+    }
+    float mloc = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    if (t == 0 || __any(mloc > m + 8.0f)) {
+      const float mnew = t == 0 ? mloc : fmaxf(m, mloc);      // the first tile defines m (whatever its sign); later m only rises
+      if (t != 0) {
+        const float alpha = EXP2(m - mnew);
+        l *= alpha;
+        a512_for_blocks<0>([&](auto n) { a512_acc_scale<decltype(n)::value>(alpha); });
+      }
+      m = mnew;
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = EXP2(s[r] - m);
+      lsum += s[r];
+    }
+    l += lsum;
+    const bf16x8_t pf0 = pack_frag(s, 0), pf1 = pack_frag(s, 1);
+
+    // ---- O^T += V^T P^T: 2 k-steps x 16 d-tiles, V^T fragments in eight batches of four, each requested two batches ahead
+#define A512_PIN4(Q_)
+#define A512_PV(src, PF_, Q_)                                                                                                   \
+    a512_mfma<4 * (Q_) + 0>(a64_join(src.lo[0], src.hi[0]), PF_); a512_mfma<4 * (Q_) + 1>(a64_join(src.lo[1], src.hi[1]), PF_);  \
+    a512_mfma<4 * (Q_) + 2>(a64_join(src.lo[2], src.hi[2]), PF_); a512_mfma<4 * (Q_) + 3>(a64_join(src.lo[3], src.hi[3]), PF_)
+    A512_WAITV_KEEP8(va);
+    __builtin_amdgcn_sched_barrier(0);
+    A512_PV(va, pf0, 0);
+    A512_PIN4(0);
+    A512_RDV(va, 0, 2);
+    A512_WAITV_KEEP8(vb);
+    __builtin_amdgcn_sched_barrier(0);
+    A512_PV(vb, pf0, 1);
+    A512_PIN4(1);
+    A512_RDV(vb, 0, 3);
+    A512_WAITV_KEEP8(va);
+    __builtin_amdgcn_sched_barrier(0);
+    A512_PV(va, pf0, 2);
+    A512_PIN4(2);
+    A512_RDV(va, 1, 0);
+    A512_WAITV_KEEP8(vb);
+    __builtin_amdgcn_sched_barrier(0);
+    A512_PV(vb, pf0, 3);
+    A512_PIN4(3);
+    A512_RDV(vb, 1, 1);
+    A512_WAITV_KEEP8(va);
+    __builtin_amdgcn_sched_barrier(0);
+    A512_PV(va, pf1, 0);
+    A512_PIN4(0);
+    A512_RDV(va, 1, 2);
+    A512_WAITV_KEEP8(vb);
+    __builtin_amdgcn_sched_barrier(0);
+    A512_PV(vb, pf1, 1);
+    A512_PIN4(1);
+    A512_RDV(vb, 1, 3);
+    A512_WAITV_KEEP8(va);
+    __builtin_amdgcn_sched_barrier(0);
+    A512_PV(va, pf1, 2);
+    A512_WAITV(vb);
+    __builtin_amdgcn_sched_barrier(0);
+    A512_PV(vb, pf1, 3);
+#undef A512_PV
+#undef A512_PIN4
+#undef A512_RDV
+
+    // tile t + 1 has landed (this wave's rows by the wait, everyone's by the barrier, which also releases tile t's stages)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // (the last MFMAs are invisible to the compiler's hazard recogniser: their wait states before the AGPRs are read)
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory", A512_ALL_AGPRS);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  const int q = q0 + ql;
+  if (q < p.Lq) {
+    bf16_t* Ob = p.O + (long)b * p.bo + (long)q * p.so + (long)hd * 512;
+    a512_for_blocks<0>([&](auto n) {
+      constexpr int dt = decltype(n)::value;
+      const float16_t oa = a512_acc_read<dt>();
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        uint2_t o;
+        o.x = pack2bf(oa[4 * r4 + 0] * inv, oa[4 * r4 + 1] * inv);
+        o.y = pack2bf(oa[4 * r4 + 2] * inv, oa[4 * r4 + 3] * inv);
+        *(uint2_t*)(Ob + dt * 32 + 8 * r4 + 4 * h5) = o;
+      }
+    });
+    if (h5 == 0 && p.LSE) p.LSE[((long)b * p.H + hd) * p.Lq + q] = (m + __log2f(l)) * 0.6931471805599453f;
+  }
+}

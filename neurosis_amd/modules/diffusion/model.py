@@ -136,7 +136,9 @@ class ResnetBlock(nn.Module):
 
 class AttnBlock(nn.Module):
     """model.py:144-243 (AttnBlock / MemoryEfficientAttnBlock / TorchSDPAttnBlock): single-head self-attention over
-    H*W tokens with head dim = C (512 for the SD VAE): q k^T and p v as MFMA GEMMs around a row softmax."""
+    H*W tokens with head dim = C.  C = 512 (the SD / SDXL VAE) runs the one-kernel flash forward of csrc/attn512.h -- no [L][L] score
+    matrix in HBM --, C <= 160 the flash kernels of the UNet (forward and backward); other widths, and the backward at C = 512
+    (autoencoder training keeps the probabilities), go through two MFMA GEMMs around a row softmax."""
 
     def __init__(self, in_channels: int):
         super().__init__()
@@ -150,7 +152,8 @@ class AttnBlock(nn.Module):
     def fwd(self, x: Img) -> Img:
         hn = _gn(x, self.norm, False)
         q, k, v = (ops.gemm_nt(hn.t, ops.w2d(m.weight), m.bias) for m in (self.q, self.k, self.v))
-        o = ops.attention_unfused(q, k, v, x.N)
+        C = self.in_channels
+        o = ops.attention_fwd(q, k, v, x.N, 1, C, need_lse=False)[0] if (C == 512 or C <= 160) else ops.attention_unfused(q, k, v, x.N)
         y = ops.gemm_nt(o, ops.w2d(self.proj_out.weight), self.proj_out.bias, residual=x.t)
         return Img(y, x.N, x.H, x.W)
 
@@ -158,7 +161,10 @@ class AttnBlock(nn.Module):
         n = self.norm
         hn, b_n = ops.groupnorm_fwd(x, n.weight, n.bias, n.num_groups, n.eps, False)
         (q, b_q), (k, b_k), (v, b_v) = (m.fwd(hn) for m in (self.q, self.k, self.v))
-        o, b_att = ops.attention_unfused_fwd(q.t, k.t, v.t, x.N)
+        if self.in_channels <= 160:
+            o, b_att = ops.attention_fwd(q.t, k.t, v.t, x.N, 1, self.in_channels)
+        else:
+            o, b_att = ops.attention_unfused_fwd(q.t, k.t, v.t, x.N)
         y, b_p = self.proj_out.fwd(Img(o, x.N, x.H, x.W), residual=x.t)
 
         def bwd(dy: Tensor) -> Tensor:

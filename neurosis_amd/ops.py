@@ -868,25 +868,29 @@ def cat_fwd(a: Img, b: Img):
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
-def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head: int, causal: bool = False):
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head: int, causal: bool = False, need_lse: bool = True):
     """softmax(q k^T / sqrt(d)) v.  q [B*Lq, H*D], k/v [B*Lk, H*D] token matrices (column slices allowed).
-    bwd(do) -> (dq, dk, dv) dense token matrices.  causal=True (frozen text transformers) is forward only."""
+    bwd(do) -> (dq, dk, dv) dense token matrices.  causal=True (frozen text transformers) is forward only, and so is
+    dim_head = 512 (the VAE mid block, csrc/attn512.h; need_lse=False skips the log-sum-exp output there)."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _check2d(t, n)
     Lq, Lk = q.shape[0] // B, k.shape[0] // B
     HD = heads * dim_head
     o = torch.empty(B * Lq, HD, dtype=BF16, device=q.device)
-    lse = torch.empty(B, heads, Lq, dtype=torch.float32, device=q.device)
+    lse = torch.empty(B, heads, Lq, dtype=torch.float32, device=q.device) if (need_lse or dim_head != 512) else None
     d = NkAttnDesc()
     d.B, d.H, d.Lq, d.Lk, d.D = B, heads, Lq, Lk, dim_head
     d.sq, d.sk, d.sv, d.so = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
     d.bq, d.bk, d.bv, d.bo = Lq * q.stride(0), Lk * k.stride(0), Lk * v.stride(0), Lq * o.stride(0)
     d.scale = float(dim_head) ** -0.5
     d.causal = int(causal)
-    call("nk_attention_fwd", C.byref(d), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), _stream())
+    call("nk_attention_fwd", C.byref(d), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr() if lse is not None else None,
+         _stream())
 
     def bwd(do: Tensor, dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None):
         _check2d(do, "do")
+        if dim_head > 160:
+            raise NotImplementedError("attention backward: head dim <= 160 (head dim 512 is forward only; attention_unfused_fwd has a backward)")
         dq = torch.empty(B * Lq, HD, dtype=BF16, device=do.device) if dq is None else dq
         dk = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dk is None else dk
         dv = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dv is None else dv

@@ -1,0 +1,135 @@
+"""Head-dim-512 flash attention forward (csrc/attn512.h): the VAE mid block's single head,
+reference modules/diffusion/model.py:224-243 (softmax(q k^T / sqrt(C)) v over H*W tokens)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "..", "neurosis_amd", "csrc")
+
+
+def _ref(q, k, v, B):
+    L, D = q.shape[0] // B, q.shape[1]
+    Lk = k.shape[0] // B
+    qf, kf, vf = q.float().view(B, L, D), k.float().view(B, Lk, D), v.float().view(B, Lk, D)
+    s = torch.einsum("bqd,bkd->bqk", qf, kf) * D ** -0.5
+    return torch.einsum("bqk,bkd->bqd", torch.softmax(s, -1), vf).reshape(B * L, D), torch.logsumexp(s, -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lq,Lk", [(2, 256, 256), (1, 128, 32), (3, 200, 200), (1, 96, 333), (2, 1024, 1024)])
+def test_attn512_forward_matches_fp32_softmax(B, Lq, Lk):
+    from neurosis_amd import ops
+
+    torch.manual_seed(B * 1000 + Lq + Lk)
+    dev = "cuda"
+    q = (torch.randn(B * Lq, 512, device=dev) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(B * Lk, 512, device=dev) * 1.5).to(torch.bfloat16)
+    v = torch.randn(B * Lk, 512, device=dev).to(torch.bfloat16)
+    o, _ = ops.attention_fwd(q, k, v, B, 1, 512)
+    ref, lse = _ref(q, k, v, B)
+    err = (o.float() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err          # bf16 output, bf16 probabilities: the tolerance of every attention test
+    cos = torch.nn.functional.cosine_similarity(o.float().flatten(), ref.flatten(), dim=0).item()
+    assert cos >= 0.9995, cos
+
+
+@pytest.mark.gpu
+def test_attn512_lse_and_rising_maximum():
+    """Keys ordered so that the running maximum rises by more than the deferred-rescale threshold (2^8) several times:
+    exercises the AGPR rescale path; the log-sum-exp output pins m and l."""
+    import ctypes as C
+
+    from neurosis_amd import ops
+    from neurosis_amd.lib import NkAttnDesc
+
+    torch.manual_seed(7)
+    dev = "cuda"
+    B, L = 1, 512
+    q = torch.randn(B * L, 512, device=dev).to(torch.bfloat16)
+    k = torch.randn(B * L, 512, device=dev)
+    k = (k * torch.linspace(0.05, 6.0, L, device=dev)[:, None]).to(torch.bfloat16)      # later keys score far higher (and far lower)
+    v = torch.randn(B * L, 512, device=dev).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    lse = torch.empty(B, 1, L, dtype=torch.float32, device=dev)
+    d = NkAttnDesc()
+    d.B, d.H, d.Lq, d.Lk, d.D = B, 1, L, L, 512
+    d.sq = d.sk = d.sv = d.so = 512
+    d.bq = d.bk = d.bv = d.bo = L * 512
+    d.scale = 512 ** -0.5
+    d.causal = 0
+    ops.call("nk_attention_fwd", C.byref(d), q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), ops._stream())
+    ref, ref_lse = _ref(q, k, v, B)
+    assert (ref_lse.max() - ref_lse.min()).item() > 10.0           # the case is what it claims to be
+    # q * scale is rounded to bf16 once (2^-9 relative) and these scores reach ~20: tolerance relative to the magnitude
+    assert (lse.view(B, L) - ref_lse).abs().max().item() <= 3e-3 * ref_lse.abs().max().item()
+    assert (o.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_attn512_full_size_agrees_with_the_two_gemm_path():
+    """BASELINE config 2's shape, one image: 128 x 128 latent tokens.  The unfused path (q k^T GEMM, row softmax, p v GEMM) is the
+    independent implementation; both round probabilities to bf16."""
+    from neurosis_amd import ops
+
+    torch.manual_seed(3)
+    dev = "cuda"
+    L = 16384
+    q = torch.randn(L, 512, device=dev).to(torch.bfloat16)
+    k = torch.randn(L, 512, device=dev).to(torch.bfloat16)
+    v = torch.randn(L, 512, device=dev).to(torch.bfloat16)
+    o = ops.attention_fwd(q, k, v, 1, 1, 512, need_lse=False)[0]
+    o2 = ops.attention_unfused(q, k, v, 1)
+    assert torch.isfinite(o.float()).all()
+    err = (o.float() - o2.float()).abs().max().item()
+    assert err <= 2e-2 * max(1.0, o2.float().abs().max().item()), err
+    rows = torch.randint(0, L, (64,), device=dev)
+    s = (q[rows].float() @ k.float().t()) * 512 ** -0.5
+    ref = torch.softmax(s, -1) @ v.float()
+    assert (o[rows].float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_attn512_accumulator_file_is_not_shared_with_the_compiler():
+    """attn512.h addresses the AGPR file physically from inline asm.  That is only sound while hipcc allocates no AGPR of its own in
+    the kernel and spills nothing inside the key loop: check the ISA it generates (no GPU needed)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-function", "-S",
+                          "--cuda-device-only", os.path.join(CSRC, "attention.hip"), "-o", "-"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z18attn512_fwd_kernel"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    in_asm, first_acc, loop_head, loop_end = False, None, None, None
+    foreign, scratch = [], []
+    for i in range(start, end):
+        l = lines[i]
+        if "ASMSTART" in l:
+            in_asm = True
+            continue
+        if "ASMEND" in l:
+            in_asm = False
+            continue
+        if "Loop Header" in l and loop_head is None:
+            loop_head = i
+        if "s_barrier" in l and loop_head is not None:
+            loop_end = i
+        if in_asm and first_acc is None and "v_accvgpr_write_b32 a[0*16+0]" in l:
+            first_acc = i
+        if not in_asm and first_acc is not None and re.search(r"accvgpr|\ba\[|\ba\d+\b", l):
+            foreign.append(l.strip())
+        if "scratch_" in l:
+            scratch.append(i)
+    assert first_acc is not None and loop_head is not None and loop_end is not None
+    assert not foreign, foreign[:5]
+    # scratch traffic in the key loop is tolerated only on the ragged-tail path (the block that clamps rows with v_min_i32)
+    hot = [i for i in scratch if loop_head <= i <= loop_end]
+    for i in hot:
+        block = "\n".join(lines[max(loop_head, i - 40):i + 40])
+        assert "v_min_i32" in block, lines[i]
+    body = [l for l in lines[loop_head:loop_end] if "v_mfma_f32_32x32x16_bf16" in l]
+    assert len(body) == 64, len(body)
