@@ -10,6 +10,7 @@ training the autoencoder itself (models/autoencoder.AutoencodingEngine; SURVEY 8
 """
 from __future__ import annotations
 
+import os
 import math
 from typing import Optional, Sequence
 
@@ -153,7 +154,8 @@ class AttnBlock(nn.Module):
         hn = _gn(x, self.norm, False)
         q, k, v = (ops.gemm_nt(hn.t, ops.w2d(m.weight), m.bias) for m in (self.q, self.k, self.v))
         C = self.in_channels
-        o = ops.attention_fwd(q, k, v, x.N, 1, C, need_lse=False)[0] if (C == 512 or C <= 160) else ops.attention_unfused(q, k, v, x.N)
+        fused = (C == 512 and os.environ.get("NK_ATTN512", "1") != "0") or C <= 160      # NK_ATTN512=0: A/B switch
+        o = ops.attention_fwd(q, k, v, x.N, 1, C, need_lse=False)[0] if fused else ops.attention_unfused(q, k, v, x.N)
         y = ops.gemm_nt(o, ops.w2d(self.proj_out.weight), self.proj_out.bias, residual=x.t)
         return Img(y, x.N, x.H, x.W)
 

@@ -14,7 +14,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(42); gen_cpu = torch.Generator().manual_seed(42)
     def step():
         batch = bench.synthetic_batch(dev, 4, (1024, 1024), gen)
-        sig = bench.draw_sigmas(4, gen_cpu, dev)
+        sig = bench.draw_sigmas(4, gen, dev)
         loss = eng.training_step(batch, 0, sigmas=sig); loss.backward(); eng.optimizer_step(lr=1e-6)
     variants = {}
     est = eng.store.state
