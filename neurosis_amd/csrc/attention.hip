@@ -413,6 +413,29 @@ __device__ __forceinline__ bf16x8_t a64_join(const short4_t& lo, const short4_t&
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// Row-per-lane epilogue of a [64 columns][32 rows] accumulator pair (acc[dt][4 r4 + e] = column 32 dt + 8 r4 + 4 h5 + e of this lane's row):
+// a row is split across the half-waves (lane: columns 8 k .. 8 k + 3, lane + 32: 8 k + 4 .. 8 k + 7, k = 4 dt + r4).  One
+// v_permlane32_swap per register pairs the column groups k and k + 1, so that every lane stores 16 contiguous bytes: four stores per lane
+// instead of eight (cdna guide T21: these tails are store-issue-bound; forward 39.1 -> 36.6 us at B = 4, H = 20, L = 1024, cross-attention
+// 18.1 -> 15.6 us).  EVERY lane of the wave must call it (the swaps); `live` only gates the stores.  `row` = the lane's row, 16-byte aligned.
+__device__ __forceinline__ void a64_store_row(bf16_t* row, bool live, const float16_t& t0, const float16_t& t1, float scale, int h5) {
+  uint2_t o2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float16_t& t = k < 4 ? t0 : t1;
+    o2[k].x = pack2bf(t[4 * (k & 3) + 0] * scale, t[4 * (k & 3) + 1] * scale);
+    o2[k].y = pack2bf(t[4 * (k & 3) + 2] * scale, t[4 * (k & 3) + 3] * scale);
+  }
+  bf16_t* dst = row + 8 * h5;
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const auto sx = __builtin_amdgcn_permlane32_swap(o2[k].x, o2[k + 1].x, false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(o2[k].y, o2[k + 1].y, false, false);
+    const uint4_t w = {sx[0], sy[0], sx[1], sy[1]};
+    if (live) *(uint4_t*)(dst + 8 * k) = w;
+  }
+}
+
 #define A64_WR128(addr, val) asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(val) : "memory")
 #define A64_WR64(addr, val, OFF) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(val), "n"(OFF) : "memory")
 // ---- forward ----
@@ -641,17 +664,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
   const float inv = 1.0f / l;
   const int q = q0 + ql;
   if (q < p.Lq) {
-    bf16_t* Ob = p.O + (long)b * p.bo + (long)q * p.so + (long)hd * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        uint2_t o;
-        o.x = pack2bf(oacc[dt][4 * r4 + 0] * inv, oacc[dt][4 * r4 + 1] * inv);
-        o.y = pack2bf(oacc[dt][4 * r4 + 2] * inv, oacc[dt][4 * r4 + 3] * inv);
-        *(uint2_t*)(Ob + dt * 32 + 8 * r4 + 4 * h5) = o;
-      }
     if (h5 == 0) p.LSE[((long)b * p.H + hd) * p.Lq + q] = (m + __log2f(l)) * 0.6931471805599453f;
+  }
+  {
+    const bool live = q < p.Lq;
+    a64_store_row(p.O + (long)b * p.bo + (long)(live ? q : 0) * p.so + (long)hd * 64, live, oacc[0], oacc[1], inv, h5);
   }
 #ifdef NK_ATTN_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -827,17 +844,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dq_kernel(const AttnPar
     for (; t < nt; ++t) iteration(t, T{}, I1{});
   }
 
-  if (q < p.Lq) {
-    bf16_t* dQb = p.dQ + (long)b * p.bdq + (long)q * p.sdq + (long)hd * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        uint2_t a;
-        a.x = pack2bf(dq[dt][4 * r4 + 0] * p.scale, dq[dt][4 * r4 + 1] * p.scale);
-        a.y = pack2bf(dq[dt][4 * r4 + 2] * p.scale, dq[dt][4 * r4 + 3] * p.scale);
-        *(uint2_t*)(dQb + dt * 32 + 8 * r4 + 4 * h5) = a;
-      }
+  {
+    const bool live = q < p.Lq;
+    a64_store_row(p.dQ + (long)b * p.bdq + (long)(live ? q : 0) * p.sdq + (long)hd * 64, live, dq[0], dq[1], p.scale, h5);
   }
 }
 
@@ -1024,7 +1033,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dkdv_kernel(const AttnP
 
   const float ln2 = 0.6931471805599453f;
   const int key = k0 + kl;
-  if (key < p.Lk) {
+  const bool live = key < p.Lk;
+  if (live) {
     if (p.qsplit > 1) {
       // fp32 partials [qs][0=dK,1=dV][b][key][H*D]; summed in a fixed order by attn_dkv_reduce_kernel
       const long hd_all = (long)p.H * 64;
@@ -1039,23 +1049,12 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dkdv_kernel(const AttnP
           *(float4_t*)(pk + d) = (float4_t){dk[dt][4 * r4 + 0] * ln2, dk[dt][4 * r4 + 1] * ln2, dk[dt][4 * r4 + 2] * ln2, dk[dt][4 * r4 + 3] * ln2};
           *(float4_t*)(pv + d) = (float4_t){dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1], dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]};
         }
-      return;
     }
-    bf16_t* dKb = p.dK + (long)b * p.bdk + (long)key * p.sdk + (long)hd * 64;
-    bf16_t* dVb = p.dV + (long)b * p.bdv + (long)key * p.sdv + (long)hd * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int d = dt * 32 + 8 * r4 + 4 * h5;
-        uint2_t a, v;
-        a.x = pack2bf(dk[dt][4 * r4 + 0] * ln2, dk[dt][4 * r4 + 1] * ln2);
-        a.y = pack2bf(dk[dt][4 * r4 + 2] * ln2, dk[dt][4 * r4 + 3] * ln2);
-        v.x = pack2bf(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
-        v.y = pack2bf(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
-        *(uint2_t*)(dKb + d) = a;
-        *(uint2_t*)(dVb + d) = v;
-      }
+  }
+  if (p.qsplit <= 1) {      // (wave-uniform; every lane takes part in the half-wave swaps of the 16-byte stores)
+    const long krow = live ? key : 0;
+    a64_store_row(p.dK + (long)b * p.bdk + krow * p.sdk + (long)hd * 64, live, dk[0], dk[1], ln2, h5);
+    a64_store_row(p.dV + (long)b * p.bdv + krow * p.sdv + (long)hd * 64, live, dv[0], dv[1], 1.0f, h5);
   }
 }
 
@@ -1190,18 +1189,8 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_small_kernel(const AttnPara
       dq[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a64_join(lo1, hi1), dsf, dq[1], 0, 0, 0);
     }
     const int q = q0 + kl;
-    if (q < p.Lq) {
-      bf16_t* dQb = p.dQ + (long)b * p.bdq + (long)q * p.sdq + (long)hd * 64;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          uint2_t a;
-          a.x = pack2bf(dq[dt][4 * r4 + 0] * p.scale, dq[dt][4 * r4 + 1] * p.scale);
-          a.y = pack2bf(dq[dt][4 * r4 + 2] * p.scale, dq[dt][4 * r4 + 3] * p.scale);
-          *(uint2_t*)(dQb + dt * 32 + 8 * r4 + 4 * h5) = a;
-        }
-    }
+    const bool live = q < p.Lq;
+    a64_store_row(p.dQ + (long)b * p.bdq + (long)(live ? q : 0) * p.sdq + (long)hd * 64, live, dq[0], dq[1], p.scale, h5);
   };
 
   for (int t = 0; t < nt; ++t) {
@@ -1303,7 +1292,8 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_small_kernel(const AttnPara
 
   const float ln2 = 0.6931471805599453f;
   const int key = k0 + kl;
-  if (wave < 3 && key < p.Lk) {
+  const bool live = wave < 3 && key < p.Lk;
+  if (live) {
     if (p.qsplit > 1) {
       const long hd_all = (long)p.H * 64;
       const long plane = (long)p.B * p.Lk * hd_all;
@@ -1317,23 +1307,12 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_small_kernel(const AttnPara
           *(float4_t*)(pk + d) = (float4_t){dk[dt][4 * r4 + 0] * ln2, dk[dt][4 * r4 + 1] * ln2, dk[dt][4 * r4 + 2] * ln2, dk[dt][4 * r4 + 3] * ln2};
           *(float4_t*)(pv + d) = (float4_t){dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1], dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]};
         }
-      return;
     }
-    bf16_t* dKb = p.dK + (long)b * p.bdk + (long)key * p.sdk + (long)hd * 64;
-    bf16_t* dVb = p.dV + (long)b * p.bdv + (long)key * p.sdv + (long)hd * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int d = dt * 32 + 8 * r4 + 4 * h5;
-        uint2_t a, v;
-        a.x = pack2bf(dk[dt][4 * r4 + 0] * ln2, dk[dt][4 * r4 + 1] * ln2);
-        a.y = pack2bf(dk[dt][4 * r4 + 2] * ln2, dk[dt][4 * r4 + 3] * ln2);
-        v.x = pack2bf(dv[dt][4 * r4 + 0], dv[dt][4 * r4 + 1]);
-        v.y = pack2bf(dv[dt][4 * r4 + 2], dv[dt][4 * r4 + 3]);
-        *(uint2_t*)(dKb + d) = a;
-        *(uint2_t*)(dVb + d) = v;
-      }
+  }
+  if (p.qsplit <= 1) {      // (wave-uniform; every lane takes part in the half-wave swaps of the 16-byte stores)
+    const long krow = live ? key : 0;
+    a64_store_row(p.dK + (long)b * p.bdk + krow * p.sdk + (long)hd * 64, live, dk[0], dk[1], ln2, h5);
+    a64_store_row(p.dV + (long)b * p.bdv + krow * p.sdv + (long)hd * 64, live, dv[0], dv[1], 1.0f, h5);
   }
 }
 
@@ -1724,10 +1703,11 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
   NK_CHECK_ARG(!d->causal || d->Lq == d->Lk);
   constexpr int nw = ATTN_NW;
   dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
+  if (d->D == 512 || (d->D == 64 && attn64_enabled())) NK_CHECK_ARG(((uintptr_t)o & 15) == 0);      // 16-byte output stores
   if (d->D == 512) {
-    // the VAE mid block's single head: one workgroup per CU, 512 registers per lane, 128 KiB of LDS (attn512.h); lse may be null
+    // the VAE mid block's single head: one workgroup per CU, 512 registers per lane, all 160 KiB of LDS (attn512.h); lse may be null
     NK_CHECK_ARG(!d->causal);
-    const int smem512 = 4 * 32 * 1024;
+    const int smem512 = 5 * 32 * 1024;
     set_smem(attn512_fwd_kernel, smem512);
     hipLaunchKernelGGL(attn512_fwd_kernel, grid, dim3(256), smem512, stream, p);
     return nk_check_launch("attn512_fwd_kernel");
@@ -1800,6 +1780,8 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   p.sdq = d->sdq; p.sdk = d->sdk; p.sdv = d->sdv; p.sdo = d->sdo;
   p.bdq = d->bdq; p.bdk = d->bdk; p.bdv = d->bdv; p.bdo = d->bdo;
   p.scale = d->scale;
+  if (d->D == 64 && attn64_enabled())      // 16-byte gradient stores
+    NK_CHECK_ARG(((uintptr_t)dq & 15) == 0 && ((uintptr_t)dk & 15) == 0 && ((uintptr_t)dv & 15) == 0);
   if (d->D == 64 && d->Lk <= 96 && attn64_enabled() && attn64_small_enabled()) {
     // head dim 64, at most 96 keys (cross-attention): everything in one kernel (+ the sum of the query splits' dK / dV partials)
     NK_CHECK_ARG(((uintptr_t)delta_ws & 15) == 0);

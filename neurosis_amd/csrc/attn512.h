@@ -7,7 +7,7 @@
 //   Q'^T fragments (32 queries x 512, bf16, pre-multiplied by scale * log2 e)   128 VGPRs
 //   O^T accumulator (512 x 32 queries, fp32)                                    256 AGPRs
 //   a score block, two batches of K / V fragments, addresses                    ~100 VGPRs
-// K and V tiles of 32 keys (32 KiB each) arrive by LDS-DMA one tile ahead into two stages each (128 KiB of the CU's 160).
+// K and V tiles of 32 keys (32 KiB each) arrive by LDS-DMA: K two tiles ahead into three stages, V one ahead into two (all 160 KiB).
 // Per 32-key tile and wave: 32 + 32 v_mfma_f32_32x32x16_bf16 (2 048 matrix-pipe cycles) against 16 exponentials per lane, so unlike
 // head dim 64 the loop is matrix-bound; what has to be hidden is LDS latency with one wave per SIMD, hence the explicit batches
 // (eight fragments requested while the previous eight are multiplied).  LDS traffic: every wave reads the whole K and V tile,
@@ -107,7 +107,7 @@ __device__ __forceinline__ void a512_for_blocks(F&& f) {
 
 __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p) {
   constexpr int KT = 32, ROWB = 1024, TILE = KT * ROWB;     // 32 KiB
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // K stage 0, K stage 1, V stage 0, V stage 1
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // K stages 0-2, V stages 0-1: 160 KiB, all of the CU's LDS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, ql = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -121,12 +121,12 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
 
   // ---- LDS-DMA: a tile is 32 rows = 32 wave instructions, 8 per wave; lane l of row r fetches chunk (l & 48) | ((l & 15) ^ g(r)).
   // Whole tiles: wave-uniform tile pointer + one per-lane byte offset per piece, kept in registers (K and V share them: whole-tile path needs sk == sv).
-  int doff[8];
+  unsigned doff[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int row = wave * 8 + j;
     const int ch = (lane & 48) | ((lane & 15) ^ a512_g(row));
-    doff[j] = (int)((row * p.sk + ch * 8) * 2);
+    doff[j] = (unsigned)((row * p.sk + ch * 8) * 2);
   }
   auto issue_whole = [&](const bf16_t* tile, char* img) {
 #pragma unroll
@@ -143,34 +143,31 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
       __builtin_amdgcn_global_load_lds((att_gptr)(base + (long)r * stride + ch * 8), (att_lptr)(img + row * ROWB), 16, 0, 0);
     }
   };
-  auto issue = [&](int t, int st) {
-    if ((t + 1) * KT <= p.Lk && p.sk == p.sv) {
-      issue_whole(Kb + (long)t * KT * p.sk, smem + st * TILE);
-      issue_whole(Vb + (long)t * KT * p.sv, smem + (2 + st) * TILE);
-    } else {
-      issue_tail(Kb, p.sk, t * KT, smem + st * TILE);
-      issue_tail(Vb, p.sv, t * KT, smem + (2 + st) * TILE);
-    }
+  auto issue_k = [&](int t, char* img) {
+    if ((t + 1) * KT <= p.Lk && p.sk == p.sv) issue_whole(Kb + (long)t * KT * p.sk, img); else issue_tail(Kb, p.sk, t * KT, img);
   };
-  issue(0, 0);
+  auto issue_v = [&](int t, char* img) {
+    if ((t + 1) * KT <= p.Lk && p.sk == p.sv) issue_whole(Vb + (long)t * KT * p.sv, img); else issue_tail(Vb, p.sv, t * KT, img);
+  };
+  issue_k(0, smem);                       // K stages 0-2, V stages 3-4
+  issue_v(0, smem + 3 * TILE);
+  if (nt > 1) issue_k(1, smem + TILE);
 
-  // ---- per-lane fragment addresses (tile-relative)
-  // K row reads: fragment ks = chunk 2 ks + h5 of row ql  ->  kab[ks & 7] + (ks >> 3) * 256
-  unsigned kab[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) kab[j] = (unsigned)(ql * ROWB + (((2 * j + h5) ^ a512_g(ql)) << 4));
+  // ---- per-lane fragment addresses: ONE tile-relative base per operand; every other fragment address is that base XOR a constant
+  // (eight + eight precomputed addresses, and the per-stage sums the compiler kept of them, were what pushed this kernel into scratch --
+  // and a scratch reload inside the key loop waits for vmcnt(0), i.e. for the tile DMA).  The XORs run in the shadow of the MFMAs.
+  // K row reads: fragment ks = chunk 2 ks + h5 of row ql: slot (2 ks) ^ h5 ^ g(ql) -> kab0 ^ ((ks & 7) << 5), + (ks >> 3) * 256
+  const unsigned kab0 = (unsigned)(ql * ROWB + ((h5 ^ a512_g(ql)) << 4));
   // V^T transposed reads (see tr_frag): lane -> row 4 h + q4 (+ 8 for the high half, + 16 s2), 8 bytes at columns 32 dt + 16 (g4 & 1) + 4 pp:
   // chunk 4 dt + c0, c0 = 2 (g4 & 1) + (pp >> 1); slot = (dt >> 2) * 16 + (((dt & 3) ^ q4) << 2 | (c0 ^ ((h + 2 j) & 3)))
-  unsigned vab[2][4];
+  //   -> vab0 ^ ((dt & 3) << 6) ^ (j ? 8192 | 32 : 0)      (h <= 1: (h + 2) & 3 == h ^ 2; row + 8 sets bit 13)
+  unsigned vab0;
   {
     const int g4 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h = g4 >> 1;
     const int c0 = 2 * (g4 & 1) + (pp >> 1);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int d4 = 0; d4 < 4; ++d4)
-        vab[j][d4] = (unsigned)((4 * h + q4 + 8 * j) * ROWB + ((((d4 ^ q4) << 2) | (c0 ^ ((h + 2 * j) & 3))) << 4) + 8 * (pp & 1));
+    vab0 = (unsigned)((4 * h + q4) * ROWB + (((q4 << 2) | (c0 ^ h)) << 4) + 8 * (pp & 1));
   }
+  if ((unsigned)(size_t)(lds_c)smem & (TILE - 1)) __builtin_trap();      // the XOR addressing needs stage bases that are multiples of 32 KiB
 
   // ---- Q'^T fragments: bf16(Q * scale * log2 e), as the head-dim-64 kernel (and the reference's math path) rounds them
   bf16x8_t qf[32];
@@ -192,83 +189,75 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
   __builtin_amdgcn_s_barrier();
 
   const unsigned smem_a = (unsigned)(size_t)(lds_c)smem;
+  // batch B_ (0..7) of a score chain = fragments ks = 4 B_ .. 4 B_ + 3: addresses (stage + kab0) ^ ((4 (B_ & 1) + j) << 5), + (B_ >> 1) * 256
+#define A512_RDK(dst, KT_, B_)                                                                                                  \
+  A512_RD128(dst[0], KT_ ^ ((4 * ((B_) & 1) + 0) << 5), ((B_) >> 1) * 256); A512_RD128(dst[1], KT_ ^ ((4 * ((B_) & 1) + 1) << 5), ((B_) >> 1) * 256); \
+  A512_RD128(dst[2], KT_ ^ ((4 * ((B_) & 1) + 2) << 5), ((B_) >> 1) * 256); A512_RD128(dst[3], KT_ ^ ((4 * ((B_) & 1) + 3) << 5), ((B_) >> 1) * 256)
+  // (the score chain in VGPRs by inline asm as well: as a builtin chain the compiler placed it in a[0:15], on top of d-tile 0.  Back-to-back
+  // MFMAs accumulating into the same block need no wait states; the vector reads behind a chain get theirs from an s_nop.)
+#define A512_MMK0(S_, src)                                                                                                      \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(S_) : "v"(src[0]), "v"(qf[0]));                                 \
+  _Pragma("unroll") for (int j = 1; j < 4; ++j)                                                                                 \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S_) : "v"(src[j]), "v"(qf[j]))
+#define A512_MMK(S_, src, B_)                                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                                 \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S_) : "v"(src[j]), "v"(qf[4 * (B_) + j]))
+#define A512_SB() __builtin_amdgcn_sched_barrier(0)
+
+  // ---- S'^T(0) = K(0) Q'^T: 32 chained MFMAs, K fragments in eight batches of four, each requested one batch ahead
+  float16_t s_cur, s_nxt;
+  {
+    bf16x8_t ka[4], kb[4];
+    unsigned kt = smem_a + kab0;
+    A64_PIN(kt);
+    A512_RDK(ka, kt, 0); A512_RDK(kb, kt, 1);
+    A512_WAIT4_KEEP4(ka); A512_SB(); A512_MMK0(s_cur, ka);
+    A512_RDK(ka, kt, 2); A512_WAIT4_KEEP4(kb); A512_SB(); A512_MMK(s_cur, kb, 1);
+    A512_RDK(kb, kt, 3); A512_WAIT4_KEEP4(ka); A512_SB(); A512_MMK(s_cur, ka, 2);
+    A512_RDK(ka, kt, 4); A512_WAIT4_KEEP4(kb); A512_SB(); A512_MMK(s_cur, kb, 3);
+    A512_RDK(kb, kt, 5); A512_WAIT4_KEEP4(ka); A512_SB(); A512_MMK(s_cur, ka, 4);
+    A512_RDK(ka, kt, 6); A512_WAIT4_KEEP4(kb); A512_SB(); A512_MMK(s_cur, kb, 5);
+    A512_RDK(kb, kt, 7); A512_WAIT4_KEEP4(ka); A512_SB(); A512_MMK(s_cur, ka, 6);
+    A512_WAIT4(kb); A512_SB(); A512_MMK(s_cur, kb, 7);
+    asm volatile("s_nop 15" : "+v"(s_cur));
+  }
+
+  // ---- the key loop, software-pipelined: iteration t runs the score chain of tile t + 1 (matrix pipe) UNDER the softmax of tile t
+  // (vector pipe; with one wave per SIMD nothing else would cover it: ~500 of ~2 800 cycles per tile in the unpipelined version), then
+  // O^T += V(t)^T P(t)^T.  K tiles therefore arrive two tiles ahead (three stages), V tiles one ahead (two stages).
+  // (Measured and dropped: K three tiles ahead / V awaited only in front of the second product, with counted vmcnt and a second barrier per
+  // iteration -- 2 301 vs 2 233 us at 4 x 16384 tokens: the loop is not waiting for the tile DMA.)
+  unsigned kst_n = TILE, kst_i = 2 * TILE;     // K stage of tile t + 1 (read here) / of tile t + 2 (filled here); tile t's was read an iteration ago
   for (int t = 0; t < nt; ++t) {
     asm volatile("" ::: A512_ALL_AGPRS);      // (nothing of the compiler's lives in the AGPRs across an iteration)
-    const int st = t & 1;
-    if (t + 1 < nt) issue(t + 1, st ^ 1);
-    const unsigned kt = smem_a + st * TILE, vt = smem_a + (2 + st) * TILE;
+    const int vs = t & 1;
+    if (t + 2 < nt) issue_k(t + 2, smem + kst_i);
+    if (t + 1 < nt) issue_v(t + 1, smem + (3 + (vs ^ 1)) * TILE);
+    unsigned kt = smem_a + kst_n + kab0, vt = smem_a + (3 + vs) * TILE + vab0;
+    A64_PIN(kt); A64_PIN(vt);       // (opaque: keeps the XORed addresses from being hoisted out of the loop into registers)
+    // (past the last tile the chain below runs on whatever its stage holds and its result is dropped: cheaper than a second copy of the loop body)
 
-    // ---- S'^T[key][q] = K Q'^T: 32 chained MFMAs, K fragments in four batches of eight, each requested one batch ahead
-    float16_t s;
-    {
-      bf16x8_t ka[4], kb[4];
-      // batch B_ (0..7) = fragments ks = 4 B_ .. 4 B_ + 3: addresses kab[(4 B_ & 7) + j] + (B_ >> 1) * 256
-#define A512_RDK(dst, B_)                                                                                                       \
-      A512_RD128(dst[0], kt + kab[4 * ((B_) & 1) + 0], ((B_) >> 1) * 256); A512_RD128(dst[1], kt + kab[4 * ((B_) & 1) + 1], ((B_) >> 1) * 256); \
-      A512_RD128(dst[2], kt + kab[4 * ((B_) & 1) + 2], ((B_) >> 1) * 256); A512_RD128(dst[3], kt + kab[4 * ((B_) & 1) + 3], ((B_) >> 1) * 256)
-#define A512_MMK(src, B_)                                                                                                       \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                             \
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(src[j]), "v"(qf[4 * (B_) + j]))
-      A512_RDK(ka, 0);
-      A512_RDK(kb, 1);
-      A512_WAIT4_KEEP4(ka);
-      __builtin_amdgcn_sched_barrier(0);
-      // (the score chain in VGPRs by inline asm as well: as a builtin chain the compiler placed it in a[0:15], on top of d-tile 0.  Back-to-back
-      // MFMAs accumulating into the same block need no wait states; the vector reads behind the chain get theirs from the s_nop below.)
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(s) : "v"(ka[0]), "v"(qf[0]));
-#pragma unroll
-      for (int j = 1; j < 4; ++j) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(ka[j]), "v"(qf[j]));
-      A512_RDK(ka, 2);
-      A512_WAIT4_KEEP4(kb);
-      __builtin_amdgcn_sched_barrier(0);
-      A512_MMK(kb, 1);
-      A512_RDK(kb, 3);
-      A512_WAIT4_KEEP4(ka);
-      __builtin_amdgcn_sched_barrier(0);
-      A512_MMK(ka, 2);
-      A512_RDK(ka, 4);
-      A512_WAIT4_KEEP4(kb);
-      __builtin_amdgcn_sched_barrier(0);
-      A512_MMK(kb, 3);
-      A512_RDK(kb, 5);
-      A512_WAIT4_KEEP4(ka);
-      __builtin_amdgcn_sched_barrier(0);
-      A512_MMK(ka, 4);
-      A512_RDK(ka, 6);
-      A512_WAIT4_KEEP4(kb);
-      __builtin_amdgcn_sched_barrier(0);
-      A512_MMK(kb, 5);
-      A512_RDK(kb, 7);
-      A512_WAIT4_KEEP4(ka);
-      __builtin_amdgcn_sched_barrier(0);
-      A512_MMK(ka, 6);
-      A512_WAIT4(kb);
-      __builtin_amdgcn_sched_barrier(0);
-      A512_MMK(kb, 7);
-      asm volatile("s_nop 15" : "+v"(s));
-#undef A512_RDK
-#undef A512_MMK
-    }
-    // ---- the first two batches of V^T fragments are requested NOW (they do not depend on P; the softmax below covers their latency)
-    // batch (s2, q) = k-step s2 (keys 16 s2 ..), d-tiles 4 q .. 4 q + 3
-    A512V va, vb;
-#define A512_RDV(dst, S2_, Q_)                                                                                                  \
-    A512_RDTR(dst.lo[0], vt + vab[0][0], (S2_) * 16384 + (Q_) * 256); A512_RDTR(dst.hi[0], vt + vab[1][0], (S2_) * 16384 + (Q_) * 256); \
-    A512_RDTR(dst.lo[1], vt + vab[0][1], (S2_) * 16384 + (Q_) * 256); A512_RDTR(dst.hi[1], vt + vab[1][1], (S2_) * 16384 + (Q_) * 256); \
-    A512_RDTR(dst.lo[2], vt + vab[0][2], (S2_) * 16384 + (Q_) * 256); A512_RDTR(dst.hi[2], vt + vab[1][2], (S2_) * 16384 + (Q_) * 256); \
-    A512_RDTR(dst.lo[3], vt + vab[0][3], (S2_) * 16384 + (Q_) * 256); A512_RDTR(dst.hi[3], vt + vab[1][3], (S2_) * 16384 + (Q_) * 256)
-    A512_RDV(va, 0, 0);
-    A512_RDV(vb, 0, 1);
-
-    // ---- online softmax in log2 units; m moves only when a score exceeds it by more than 2^8 ("defer-max", cdna guide T13)
+    bf16x8_t ka[4], kb[4];
+    A512_RDK(ka, kt, 0); A512_RDK(kb, kt, 1);
+    A512_WAIT4_KEEP4(ka); A512_SB(); A512_MMK0(s_nxt, ka);
+    // -- softmax(t), part 1: mask, row maximum (both halves of the key tile through one v_permlane32_swap: no LDS traffic among the counted reads)
+    A64_PIN(s_cur);
     if (t == nt - 1 && (p.Lk & (KT - 1))) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = (t * KT + acc_row(r, h5)) < p.Lk ? s[r] : NEG_BIG;
+      for (int r = 0; r < 16; ++r) s_cur[r] = (t * KT + acc_row(r, h5)) < p.Lk ? s_cur[r] : NEG_BIG;
     }
-    float mloc = s[0];
+    float mloc = fmaxf(fmaxf(s_cur[0], s_cur[1]), s_cur[2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    for (int r = 3; r < 15; r += 2) mloc = fmaxf(fmaxf(mloc, s_cur[r]), s_cur[r + 1]);
+    mloc = fmaxf(mloc, s_cur[15]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    A64_PIN(mloc); A512_SB();
+    A512_RDK(ka, kt, 2); A512_WAIT4_KEEP4(kb); A512_SB(); A512_MMK(s_nxt, kb, 1);
+    // -- part 2: the reference point m moves only when a score exceeds it by more than 2^8 ("defer-max", cdna guide T13); rare after tile 0
+    A64_PIN(mloc);
     if (t == 0 || __any(mloc > m + 8.0f)) {
       const float mnew = t == 0 ? mloc : fmaxf(m, mloc);      // the first tile defines m (whatever its sign); later m only rises
       if (t != 0) {
@@ -278,85 +267,101 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
       }
       m = mnew;
     }
-    float lsum = 0.f;
+    A64_PIN(m); A512_SB();
+    A512_RDK(kb, kt, 3); A512_WAIT4_KEEP4(ka); A512_SB(); A512_MMK(s_nxt, ka, 2);
+    // -- parts 3-6: the exponentials, four registers per gap
+#define A512_EXP4(R0_)                                                                                                          \
+    A64_PIN(s_cur);                                                                                                             \
+    _Pragma("unroll") for (int r = (R0_); r < (R0_) + 4; ++r) s_cur[r] = EXP2(s_cur[r] - m);                                    \
+    A64_PIN(s_cur); A512_SB()
+    A512_EXP4(0);
+    A512_RDK(ka, kt, 4); A512_WAIT4_KEEP4(kb); A512_SB(); A512_MMK(s_nxt, kb, 3);
+    A512_EXP4(4);
+    A512_RDK(kb, kt, 5); A512_WAIT4_KEEP4(ka); A512_SB(); A512_MMK(s_nxt, ka, 4);
+    A512_EXP4(8);
+    A512_RDK(ka, kt, 6); A512_WAIT4_KEEP4(kb); A512_SB(); A512_MMK(s_nxt, kb, 5);
+    A512_EXP4(12);
+#undef A512_EXP4
+    A512_RDK(kb, kt, 7); A512_WAIT4_KEEP4(ka); A512_SB(); A512_MMK(s_nxt, ka, 6);
+    // -- part 7: row sum, P^T as the bf16 B operands of the second product
+    A64_PIN(s_cur);
+    float lsum = (s_cur[0] + s_cur[1]) + (s_cur[2] + s_cur[3]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = EXP2(s[r] - m);
-      lsum += s[r];
-    }
+    for (int r = 4; r < 16; r += 4) lsum += (s_cur[r] + s_cur[r + 1]) + (s_cur[r + 2] + s_cur[r + 3]);
     l += lsum;
-    const bf16x8_t pf0 = pack_frag(s, 0), pf1 = pack_frag(s, 1);
+    bf16x8_t pf0 = pack_frag(s_cur, 0), pf1 = pack_frag(s_cur, 1);
+    A64_PIN(pf0); A64_PIN(pf1); A64_PIN(l); A512_SB();
+    A512_WAIT4(kb); A512_SB();
+    // ---- the first two batches of V^T fragments are requested right behind the chain's last four MFMAs, which cover most of their latency
+    // batch (s2, q) = k-step s2 (keys 16 s2 ..), d-tiles 4 q .. 4 q + 3
+    A512V va, vb;
+#define A512_RDV(dst, S2_, Q_)                                                                                                  \
+    A512_RDTR(dst.lo[0], vt, (S2_) * 16384 + (Q_) * 256);              A512_RDTR(dst.hi[0], vt ^ 8224u, (S2_) * 16384 + (Q_) * 256);              \
+    A512_RDTR(dst.lo[1], vt ^ (1u << 6), (S2_) * 16384 + (Q_) * 256);  A512_RDTR(dst.hi[1], vt ^ (8224u | (1u << 6)), (S2_) * 16384 + (Q_) * 256);  \
+    A512_RDTR(dst.lo[2], vt ^ (2u << 6), (S2_) * 16384 + (Q_) * 256);  A512_RDTR(dst.hi[2], vt ^ (8224u | (2u << 6)), (S2_) * 16384 + (Q_) * 256);  \
+    A512_RDTR(dst.lo[3], vt ^ (3u << 6), (S2_) * 16384 + (Q_) * 256);  A512_RDTR(dst.hi[3], vt ^ (8224u | (3u << 6)), (S2_) * 16384 + (Q_) * 256)
+    A512_MMK(s_nxt, kb, 7);
+    A512_RDV(va, 0, 0);
+    A512_RDV(vb, 0, 1);
 
     // ---- O^T += V^T P^T: 2 k-steps x 16 d-tiles, V^T fragments in eight batches of four, each requested two batches ahead
-#define A512_PIN4(Q_)
 #define A512_PV(src, PF_, Q_)                                                                                                   \
     a512_mfma<4 * (Q_) + 0>(a64_join(src.lo[0], src.hi[0]), PF_); a512_mfma<4 * (Q_) + 1>(a64_join(src.lo[1], src.hi[1]), PF_);  \
     a512_mfma<4 * (Q_) + 2>(a64_join(src.lo[2], src.hi[2]), PF_); a512_mfma<4 * (Q_) + 3>(a64_join(src.lo[3], src.hi[3]), PF_)
-    A512_WAITV_KEEP8(va);
-    __builtin_amdgcn_sched_barrier(0);
-    A512_PV(va, pf0, 0);
-    A512_PIN4(0);
-    A512_RDV(va, 0, 2);
-    A512_WAITV_KEEP8(vb);
-    __builtin_amdgcn_sched_barrier(0);
-    A512_PV(vb, pf0, 1);
-    A512_PIN4(1);
-    A512_RDV(vb, 0, 3);
-    A512_WAITV_KEEP8(va);
-    __builtin_amdgcn_sched_barrier(0);
-    A512_PV(va, pf0, 2);
-    A512_PIN4(2);
-    A512_RDV(va, 1, 0);
-    A512_WAITV_KEEP8(vb);
-    __builtin_amdgcn_sched_barrier(0);
-    A512_PV(vb, pf0, 3);
-    A512_PIN4(3);
-    A512_RDV(vb, 1, 1);
-    A512_WAITV_KEEP8(va);
-    __builtin_amdgcn_sched_barrier(0);
-    A512_PV(va, pf1, 0);
-    A512_PIN4(0);
-    A512_RDV(va, 1, 2);
-    A512_WAITV_KEEP8(vb);
-    __builtin_amdgcn_sched_barrier(0);
-    A512_PV(vb, pf1, 1);
-    A512_PIN4(1);
-    A512_RDV(vb, 1, 3);
-    A512_WAITV_KEEP8(va);
-    __builtin_amdgcn_sched_barrier(0);
-    A512_PV(va, pf1, 2);
-    A512_WAITV(vb);
-    __builtin_amdgcn_sched_barrier(0);
-    A512_PV(vb, pf1, 3);
+    A512_WAITV_KEEP8(va); A512_SB(); A512_PV(va, pf0, 0);
+    A512_RDV(va, 0, 2); A512_WAITV_KEEP8(vb); A512_SB(); A512_PV(vb, pf0, 1);
+    A512_RDV(vb, 0, 3); A512_WAITV_KEEP8(va); A512_SB(); A512_PV(va, pf0, 2);
+    A512_RDV(va, 1, 0); A512_WAITV_KEEP8(vb); A512_SB(); A512_PV(vb, pf0, 3);
+    A512_RDV(vb, 1, 1); A512_WAITV_KEEP8(va); A512_SB(); A512_PV(va, pf1, 0);
+    A512_RDV(va, 1, 2); A512_WAITV_KEEP8(vb); A512_SB(); A512_PV(vb, pf1, 1);
+    A512_RDV(vb, 1, 3); A512_WAITV_KEEP8(va); A512_SB(); A512_PV(va, pf1, 2);
+    A512_WAITV(vb); A512_SB(); A512_PV(vb, pf1, 3);
 #undef A512_PV
-#undef A512_PIN4
 #undef A512_RDV
 
-    // tile t + 1 has landed (this wave's rows by the wait, everyone's by the barrier, which also releases tile t's stages)
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // K(t + 2) and V(t + 1) have landed (this wave's rows by the wait, everyone's by the barrier, which also releases K(t + 1)'s and V(t)'s stages);
+    // the s_nop gives the score chain of tile t + 1 its wait states before vector code reads it
+    A512_SB();
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" : "+v"(s_nxt) : : "memory");
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+    A512_SB();
+    s_cur = s_nxt;
+    kst_n += TILE; if (kst_n == 3 * TILE) kst_n = 0;
+    kst_i += TILE; if (kst_i == 3 * TILE) kst_i = 0;
   }
+#undef A512_RDK
+#undef A512_MMK0
+#undef A512_MMK
+#undef A512_SB
 
   // (the last MFMAs are invisible to the compiler's hazard recogniser: their wait states before the AGPRs are read)
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory", A512_ALL_AGPRS);
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
   const int q = q0 + ql;
-  if (q < p.Lq) {
-    bf16_t* Ob = p.O + (long)b * p.bo + (long)q * p.so + (long)hd * 512;
+  {
+    // 16-byte stores: column groups k, k + 1 of a row paired across the half-waves by v_permlane32_swap (see attn64_fwd_kernel's epilogue)
+    const bool live = q < p.Lq;
+    bf16_t* Ob = p.O + (long)b * p.bo + (long)(live ? q : 0) * p.so + (long)hd * 512 + 8 * h5;
     a512_for_blocks<0>([&](auto n) {
       constexpr int dt = decltype(n)::value;
       const float16_t oa = a512_acc_read<dt>();
+      uint2_t o2[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        uint2_t o;
-        o.x = pack2bf(oa[4 * r4 + 0] * inv, oa[4 * r4 + 1] * inv);
-        o.y = pack2bf(oa[4 * r4 + 2] * inv, oa[4 * r4 + 3] * inv);
-        *(uint2_t*)(Ob + dt * 32 + 8 * r4 + 4 * h5) = o;
+        o2[r4].x = pack2bf(oa[4 * r4 + 0] * inv, oa[4 * r4 + 1] * inv);
+        o2[r4].y = pack2bf(oa[4 * r4 + 2] * inv, oa[4 * r4 + 3] * inv);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4 += 2) {
+        const auto sx = __builtin_amdgcn_permlane32_swap(o2[r4].x, o2[r4 + 1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(o2[r4].y, o2[r4 + 1].y, false, false);
+        uint4_t w = {sx[0], sy[0], sx[1], sy[1]};
+        if (live) *(uint4_t*)(Ob + dt * 32 + 8 * r4) = w;
       }
     });
+  }
+  if (q < p.Lq) {
     if (h5 == 0 && p.LSE) p.LSE[((long)b * p.H + hd) * p.Lq + q] = (m + __log2f(l)) * 0.6931471805599453f;
   }
 }
