@@ -229,18 +229,30 @@ class GemmTimer:
 def host_cores() -> int:
     """CPUs this process may actually use: the cgroup quota if there is one (a GPU box exposes every host core in
     sched_getaffinity but caps the container at its share), else the affinity mask."""
-    n = os.cpu_count() or 1
+    return host_cores_and_source()[0]
+
+
+def host_cores_and_source():
+    """(threads, where the number comes from).  Without a cgroup quota a pool box shows every host core in the affinity mask although the
+    container's share is 16 per GPU (the pool's documented rule): that case, and only that one, falls back to the rule."""
+    n, src = os.cpu_count() or 1, "os.cpu_count"
     try:
-        n = min(n, len(os.sched_getaffinity(0)))
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, src = a, "sched_getaffinity"
     except Exception:
         pass
     try:
         quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
         if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period) + 0.999)))
+            q = max(1, int(int(quota) / int(period) + 0.999))
+            if q <= n:
+                return q, "cgroup cpu.max quota"
     except Exception:
         pass
-    return max(1, min(n, 16))   # a 1-GPU box gives the container a 16-CPU share even when it exposes every host core
+    if n > 16:
+        return 16, f"pool rule: 16 CPUs per GPU share ({src} shows {n}, no cgroup quota)"
+    return max(1, n), src
 
 
 SD15_UNET = dict(use_checkpoint=False, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
@@ -288,12 +300,13 @@ def cpu_baseline():
         loss.backward()
         t = time.time() - t1
         print(f"[cpu_baseline] SD1.5 512^2 step: {t:.2f} s", file=sys.stderr, flush=True)
-        return {"value": round((1.0 / t) * TFLOP_PER_IMAGE_SD15 / TFLOP_PER_IMAGE, 6), "unit": "images/s", "cores": cores, "kind": "port",
-                "sample": f"oracle (torch CPU fp32 eager), BASELINE config 1: one SD1.5 512x512 batch-1 training step (VAE encode + UNet fwd + loss + bwd, "
+        return {"value": round((1.0 / t) * TFLOP_PER_IMAGE_SD15 / TFLOP_PER_IMAGE, 6), "unit": "images/s", "cores": cores, "cores_source": host_cores_and_source()[1],
+                "kind": "port", "sample": f"oracle (torch CPU fp32 eager), BASELINE config 1: one SD1.5 512x512 batch-1 training step (VAE encode + UNet fwd + loss + bwd, "
                           f"3.53 algorithmic TFLOP) in {t:.2f} s = {TFLOP_PER_IMAGE_SD15 / t:.3f} TFLOP/s; value = SDXL-1024^2-image equivalents/s "
                           f"(x 3.53/25.16)"}
     except Exception as ex:  # the baseline is reported, never required
-        return {"value": None, "unit": "images/s", "cores": host_cores(), "kind": "port", "sample": f"failed: {type(ex).__name__}: {ex}"}
+        return {"value": None, "unit": "images/s", "cores": host_cores(), "cores_source": host_cores_and_source()[1], "kind": "port",
+                "sample": f"failed: {type(ex).__name__}: {ex}"}
 
 
 def pmc_traffic():
@@ -302,7 +315,7 @@ def pmc_traffic():
     import csv
 
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((p for p in (os.path.join(prof, f"r0{r}_pmc_summary.csv") for r in (3, 2, 1)) if os.path.exists(p)), "")
+    path = next((p for p in (os.path.join(prof, f"r{r:02d}_pmc_summary.csv") for r in range(9, 0, -1)) if os.path.exists(p)), "")      # newest round
     try:
         rows = list(csv.reader(open(path)))[1:]
     except OSError:
