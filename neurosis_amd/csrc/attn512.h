@@ -106,6 +106,7 @@ __device__ __forceinline__ void a512_for_blocks(F&& f) {
 }
 
 __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p) {
+  ATT_STAMP(0);
   constexpr int KT = 32, ROWB = 1024, TILE = KT * ROWB;     // 32 KiB
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // K stages 0-2, V stages 0-1: 160 KiB, all of the CU's LDS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,6 +190,13 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
   __builtin_amdgcn_s_barrier();
 
   const unsigned smem_a = (unsigned)(size_t)(lds_c)smem;
+  ATT_STAMP(1); ATT_STAMP_RT(4);
+#ifdef NK_ATTN_STAMPS      // (diagnostic build, tools/attn512_stamps.py: where an iteration's cycles go; stamps only where no LDS read is outstanding)
+  unsigned long long st_a = 0, st_b = 0, st_c = 0, acc_s = 0, acc_pv = 0, acc_sync = 0;
+#define A512_STAMP(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define A512_STAMP(x)
+#endif
   // batch B_ (0..7) of a score chain = fragments ks = 4 B_ .. 4 B_ + 3: addresses (stage + kab0) ^ ((4 (B_ & 1) + j) << 5), + (B_ >> 1) * 256
 #define A512_RDK(dst, KT_, B_)                                                                                                  \
   A512_RD128(dst[0], KT_ ^ ((4 * ((B_) & 1) + 0) << 5), ((B_) >> 1) * 256); A512_RD128(dst[1], KT_ ^ ((4 * ((B_) & 1) + 1) << 5), ((B_) >> 1) * 256); \
@@ -225,11 +233,17 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
   // ---- the key loop, software-pipelined: iteration t runs the score chain of tile t + 1 (matrix pipe) UNDER the softmax of tile t
   // (vector pipe; with one wave per SIMD nothing else would cover it: ~500 of ~2 800 cycles per tile in the unpipelined version), then
   // O^T += V(t)^T P(t)^T.  K tiles therefore arrive two tiles ahead (three stages), V tiles one ahead (two stages).
-  // (Measured and dropped: K three tiles ahead / V awaited only in front of the second product, with counted vmcnt and a second barrier per
-  // iteration -- 2 301 vs 2 233 us at 4 x 16384 tokens: the loop is not waiting for the tile DMA.)
+  // Where an iteration's ~4 450 cycles go (diagnostic build, tools/attn512_stamps.py; MFMA floor 2 x 1 024): score phase 2 590, second product
+  // 1 250, DMA wait + barrier 325.  The score phase carries the ISSUE of the sixteen 1-KiB DMA instructions: a wave issues in order and the
+  // fill path takes 64 B / clk / CU, ~960 cycles with all four waves issuing (timing-only build without the DMA: 1 630).  Measured and
+  // dropped, all slower at 4 x 16384 tokens (2 233 us): K three tiles ahead / V awaited in front of the second product with counted vmcnt
+  // (2 301); the pieces spread one or two per MFMA batch (2 654 / 2 935) or staggered over the waves (2 454) -- more than sixteen pieces in
+  // flight per wave stall at issue, and every variant the compiler answered with scratch reloads that wait for vmcnt(0); two score chains
+  // instead of one (2 257: the chain's dependency is not what the phase waits for); the chain's accumulator in AGPRs (no change).
   unsigned kst_n = TILE, kst_i = 2 * TILE;     // K stage of tile t + 1 (read here) / of tile t + 2 (filled here); tile t's was read an iteration ago
   for (int t = 0; t < nt; ++t) {
     asm volatile("" ::: A512_ALL_AGPRS);      // (nothing of the compiler's lives in the AGPRs across an iteration)
+    A512_STAMP(st_a);
     const int vs = t & 1;
     if (t + 2 < nt) issue_k(t + 2, smem + kst_i);
     if (t + 1 < nt) issue_v(t + 1, smem + (3 + (vs ^ 1)) * TILE);
@@ -292,6 +306,7 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
     bf16x8_t pf0 = pack_frag(s_cur, 0), pf1 = pack_frag(s_cur, 1);
     A64_PIN(pf0); A64_PIN(pf1); A64_PIN(l); A512_SB();
     A512_WAIT4(kb); A512_SB();
+    A512_STAMP(st_b);
     // ---- the first two batches of V^T fragments are requested right behind the chain's last four MFMAs, which cover most of their latency
     // batch (s2, q) = k-step s2 (keys 16 s2 ..), d-tiles 4 q .. 4 q + 3
     A512V va, vb;
@@ -315,7 +330,9 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
     A512_RDV(vb, 1, 1); A512_WAITV_KEEP8(va); A512_SB(); A512_PV(va, pf1, 0);
     A512_RDV(va, 1, 2); A512_WAITV_KEEP8(vb); A512_SB(); A512_PV(vb, pf1, 1);
     A512_RDV(vb, 1, 3); A512_WAITV_KEEP8(va); A512_SB(); A512_PV(va, pf1, 2);
-    A512_WAITV(vb); A512_SB(); A512_PV(vb, pf1, 3);
+    A512_WAITV(vb); A512_SB();
+    A512_STAMP(st_c);
+    A512_PV(vb, pf1, 3);
 #undef A512_PV
 #undef A512_RDV
 
@@ -325,10 +342,21 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" : "+v"(s_nxt) : : "memory");
     __builtin_amdgcn_s_barrier();
     A512_SB();
+#ifdef NK_ATTN_STAMPS
+    { const unsigned long long st_d = __builtin_amdgcn_s_memtime(); acc_s += st_b - st_a; acc_pv += st_c - st_b; acc_sync += st_d - st_c; }
+#endif
     s_cur = s_nxt;
     kst_n += TILE; if (kst_n == 3 * TILE) kst_n = 0;
     kst_i += TILE; if (kst_i == 3 * TILE) kst_i = 0;
   }
+  ATT_STAMP(2); ATT_STAMP_RT(5);
+#ifdef NK_ATTN_STAMPS
+  if (threadIdx.x == 0) {
+    const unsigned w_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (w_ < 8192) { nk_attn_stamp_buf[w_ * 8 + 3] = acc_s; nk_attn_stamp_buf[w_ * 8 + 6] = acc_pv; nk_attn_stamp_buf[w_ * 8 + 7] = acc_sync; }
+  }
+#endif
+#undef A512_STAMP
 #undef A512_RDK
 #undef A512_MMK0
 #undef A512_MMK

@@ -98,7 +98,7 @@ def test_attn512_accumulator_file_is_not_shared_with_the_compiler():
     """attn512.h addresses the AGPR file physically from inline asm.  That is only sound while hipcc allocates no AGPR of its own in
     the kernel and spills nothing inside the key loop: check the ISA it generates (no GPU needed)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-function", "-S",
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-function", "-Wno-inline-asm", "-S",
                           "--cuda-device-only", os.path.join(CSRC, "attention.hip"), "-o", "-"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.splitlines()
@@ -126,11 +126,11 @@ def test_attn512_accumulator_file_is_not_shared_with_the_compiler():
     assert not foreign, foreign[:5]
     loop_head = min(loop_marks)
     loop_end = next(i for i in range(max(loop_marks) + 1, end) if re.match(r"^\.LBB", lines[i]) or "s_endpgm" in lines[i])
-    # scratch traffic in the key loop is tolerated only on the ragged-tail path (the blocks that clamp rows with v_min_i32): a reload
+    # scratch traffic in the key loop is tolerated only on the ragged-tail path (the blocks that clamp rows with v_min_i32 / s_min_i32): a reload
     # waits for vmcnt(0), i.e. for the tile DMA in flight
     hot = [i for i in scratch if loop_head <= i <= loop_end]
     for i in hot:
         block = "\n".join(lines[max(loop_head, i - 60):i + 60])
-        assert "v_min_i32" in block, (i - start, lines[i])
+        assert "v_min_i32" in block or "s_min_i32" in block, (i - start, lines[i])
     body = [l for l in lines[loop_head:loop_end] if "v_mfma_f32_32x32x16_bf16" in l]
     assert len(body) == 64, len(body)
