@@ -89,7 +89,7 @@ def _mark(label: str) -> None:
 
 
 class _Pair:
-    __slots__ = ("g_f", "segments", "static_in", "out", "closure", "dout", "dx", "gen", "warm")
+    __slots__ = ("g_f", "segments", "static_in", "out", "closure", "dout", "dx", "gen", "warm", "bwd_replays", "tail", "cal")
 
     def __init__(self):
         self.g_f = None
@@ -100,6 +100,9 @@ class _Pair:
         self.dout = self.dx = None
         self.gen = 0
         self.warm = False
+        self.bwd_replays = 0
+        self.tail = None            # indices of the segments whose W_k replays on the MAIN stream behind the last M (see _replay_backward)
+        self.cal = None             # events of the calibration replay
 
 
 def _sig(t: Optional[Tensor]):
@@ -248,7 +251,9 @@ class ChainGraphs:
             if parked:
                 g_w = torch.cuda.CUDAGraph()
                 with torch.cuda.stream(side):
-                    g_w.capture_begin(pool=self.pool_w, capture_error_mode="thread_local")
+                    # a pool of its OWN: the W graphs behind the end of the main chain replay on two streams at once (_replay_backward),
+                    # and graphs that share a pool may share the memory of their temporaries (split-K / partial-sum workspaces)
+                    g_w.capture_begin(pool=torch.cuda.graph_pool_handle(), capture_error_mode="thread_local")
                     try:
                         _mark(f"W{len(segments)}.begin")
                         for fn, _reads in parked:
@@ -280,21 +285,81 @@ class ChainGraphs:
         pair.segments = segments
 
     def _replay_backward(self, pair: _Pair) -> None:
+        """M_0, W_0 | M_1, W_1 | ...: M_k on the main stream, W_k on the side stream behind it.  The main chain ends before the side stream does
+        (the last blocks' weight gradients: 2.9 ms of exposed tail at SDXL batch 4, profiles/r04_step_timeline.txt): single-GPU, the W graphs
+        that START behind the last M are shared out between BOTH streams (longest first).  Which ones those are is measured once, by events
+        around the third replay of a signature; the kernels and their arguments are the same either way."""
         st = ops.state_of(self.owner)
         side = st.wgrad_stream
         main = torch.cuda.current_stream()
         hook = self.hook()
-        for g_m, g_w, module in pair.segments:
+        balance = side is not None and hook is None and os.environ.get("NK_TAIL_BALANCE", "1") != "0"
+        pair.bwd_replays += 1
+        if balance and pair.tail is None and pair.cal is not None and pair.cal["done"].query():
+            pair.tail = self._plan_tail(pair.cal)
+            pair.cal = None
+        calibrate = balance and pair.tail is None and pair.cal is None and pair.bwd_replays == 3
+        cal = None
+        if calibrate:
+            ev = lambda: torch.cuda.Event(enable_timing=True)
+            cal = {"t0": ev(), "m": [], "w": {}, "done": ev()}
+            cal["t0"].record(main)
+        tail = pair.tail if balance and pair.tail else ()
+        late = []
+        for k, (g_m, g_w, module) in enumerate(pair.segments):
             g_m.replay()
+            if cal is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(main)
+                cal["m"].append(e)
             if g_w is not None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    g_w.replay()
+                if k in tail:
+                    late.append(g_w)
+                else:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        if cal is not None:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(side)
+                            g_w.replay()
+                            e1.record(side)
+                            cal["w"][k] = (e0, e1)
+                        else:
+                            g_w.replay()
             if hook is not None and module is not None:
                 hook(module)
             self.replays += 1
+        for g_w in late:                  # behind every M on the main stream; each W_k only needs its own M_k
+            g_w.replay()
         if side is not None:
             main.wait_stream(side)
+        if cal is not None:
+            cal["done"].record(main)
+            pair.cal = cal
+
+    @staticmethod
+    def _plan_tail(cal) -> frozenset:
+        """From one timed replay: the W graphs that began after the main chain had ended, split over two bins by longest-processing-time;
+        the side stream's bin starts with what was still running there when the main chain ended."""
+        t0 = cal["t0"]
+        main_end = t0.elapsed_time(cal["m"][-1])
+        late, side_busy = [], 0.0
+        for k, (e0, e1) in cal["w"].items():
+            start, end = t0.elapsed_time(e0), t0.elapsed_time(e1)
+            if start >= main_end - 0.02:
+                late.append((end - start, k))
+            elif end > main_end:
+                side_busy = max(side_busy, end - main_end)
+        load = {"side": side_busy, "main": 0.0}
+        on_main = []
+        for dur, k in sorted(late, reverse=True):
+            if dur < 0.05:                  # (a handful of tiny launches: not worth a second queue)
+                continue
+            b = "main" if load["main"] < load["side"] else "side"
+            load[b] += dur
+            if b == "main":
+                on_main.append(k)
+        return frozenset(on_main)
 
 
 def _tree_map(fn: Callable, obj):

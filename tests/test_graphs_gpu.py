@@ -92,6 +92,37 @@ def test_graph_replay_reproduces_the_eager_chain_bit_for_bit():
     assert torch.equal(got, want) and torch.equal(got_e, want), (got.tolist(), got_e.tolist(), want.tolist())
 
 
+def test_tail_weight_gradient_graphs_may_replay_on_the_main_stream():
+    """ChainGraphs._replay_backward shares the W graphs that start behind the end of the main chain out between both streams (measured once,
+    by events).  Here the plan is FORCED to every W graph of the second half of the backward: same kernels, same arguments, so the gradients
+    must equal the eager chain's, and the W graphs have pools of their own (two of them run at once)."""
+    batches = _batches(6)
+    _, loss_e, grad_e = _steps(batches, graph=False)
+    os.environ["NK_GRAPH"] = "1"
+    try:
+        net, store, den, lossfn, wrapped = _setup()
+        grads = []
+        for i, b in enumerate(batches):
+            loss = lossfn._forward(wrapped, den, {"crossattn": b["ctx"], "vector": b["y"]}, b["x"], {}, sigmas=b["sigma"], noise=b["noise"])
+            loss.mean().backward()
+            torch.cuda.synchronize()
+            assert torch.equal(loss.detach(), loss_e[i])
+            grads.append(store.grad.clone())
+            store.adamw_step(1e-3, (0.9, 0.999), 1e-8, 0.0, 1.0)
+            cg = net._nk_graphs
+            pair = next(iter(cg.pairs.values())) if cg is not None and cg.pairs else None
+            if pair is not None and pair.segments is not None and i == 2:
+                n = len(pair.segments)
+                pair.tail = frozenset(k for k, (_, w, _) in enumerate(pair.segments) if w is not None and k >= n // 2)
+                pair.cal = None
+                assert len(pair.tail) >= 3
+    finally:
+        os.environ.pop("NK_GRAPH", None)
+    assert pair.tail is not None and len(pair.tail) >= 3
+    for i, (a, b) in enumerate(zip(grad_e, grads)):
+        assert float((a - b).norm() / a.norm()) <= 1e-5, i
+
+
 def test_each_input_signature_gets_its_own_pair_and_they_share_one_pool():
     """Aspect buckets: two resolutions alternate; each is captured on its second appearance and replayed afterwards."""
     sizes = [(16, 16), (8, 24), (16, 16), (8, 24), (16, 16), (8, 24)]
