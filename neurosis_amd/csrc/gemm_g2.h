@@ -46,11 +46,12 @@ __device__ unsigned long long nk_g2_stamp_buf[8 * 4096];
 #define G2_NS 4
 #define G2_SMEM_BYTES (G2_NS * G2_STAGE_BYTES)   // 147456
 
-// one operand of the tile: ROWS rows (128 for A; 128 or 160 for B), staged by all 8 waves: piece pc = wave + 8 i
-template <int MODE, int ROWS>
+// one operand of the tile: ROWS rows (128 for A; 128 or 160 for B), staged by NSW waves (all 8 of nk_gemm_g2_kernel, the 4 producer waves of
+// nk_gemm_g2p_kernel): piece pc = wave + NSW i
+template <int MODE, int ROWS, int NSW = 8>
 struct OpG2 {
   static constexpr int NPC = ROWS / 8;                 // 1 KiB pieces per slab
-  static constexpr int NPW = (NPC + 7) / 8;            // pieces per wave (waves past NPC - 8*(NPW-1) issue one fewer)
+  static constexpr int NPW = (NPC + NSW - 1) / NSW;    // pieces per wave (waves past NPC - NSW*(NPW-1) issue one fewer)
   static constexpr int CH = ROWS / 8;                  // MC: 16-byte chunks per k-row
   const bf16_t* rp[NPW];                               // running source pointer of each piece of this lane (KCG / MCT: the operand's base)
   int kk[NPW];                                         // KC: k offset of the lane's chunk (same for all pieces); MC: k row of the piece
@@ -63,7 +64,7 @@ struct OpG2 {
   const NkGather* g;                                   // KCG
   const NkTapW* tw;                                    // MCT
 
-  __device__ __forceinline__ int pieces(int wave) const { return wave + 8 * (NPW - 1) < NPC ? NPW : NPW - 1; }
+  __device__ __forceinline__ int pieces(int wave) const { return wave + NSW * (NPW - 1) < NPC ? NPW : NPW - 1; }
 
   __device__ __forceinline__ void init(const bf16_t* P, long ld, int R, int r0, int wave, int lane, const NkGather* g_ = nullptr,
                                        const NkTapW* tw_ = nullptr) {
@@ -71,7 +72,7 @@ struct OpG2 {
     g = g_; tw = tw_;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-      const int pc = wave + 8 * i;
+      const int pc = wave + NSW * i;
       if constexpr (MODE == OP_KCG) {                               // conv activations: the KC image, rows = output pixels
         const int row = pc * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (lane >> 3);
@@ -164,8 +165,8 @@ struct OpG2 {
   __device__ __forceinline__ void fire(const bf16_t* const (&src)[NPW], char* img, int wave) const {
 #pragma unroll
     for (int i = 0; i < NPW; ++i)
-      if (i < NPW - 1 || wave + 8 * i < NPC)      // (wave-uniform)
-        __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave + 8 * i) * 1024), 16, 0, 0);
+      if (i < NPW - 1 || wave + NSW * i < NPC)      // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((nk_gptr)src[i], (nk_lptr)(img + (wave + NSW * i) * 1024), 16, 0, 0);
   }
 };
 
@@ -433,6 +434,166 @@ extern "C" int nk_debug_g2_stamps(unsigned long long* host_out, int nwg) {
 }
 #endif
 
+
+// ---- producer-wave variant (round 4, this session) ---------------------------------------------------------------------------------
+// What the loop above waits for (tools/g2_stamps.py: 1 117 cycles per k-step at 4096 x 1280 x 1280 against an MFMA floor of 640): a wave
+// issues IN ORDER, and an LDS-DMA instruction does not issue until the 64 B / clk / CU fill path takes it.  A slab is 36 KiB = 562 cycles of
+// that path, so the 4-5 pieces of a wave cost it ~280 cycles of stalled issue per k-step on top of its fragment reads (~220): an R phase of
+// ~560 cycles against the 320 of the other group's M phase, twice per k-step = the 1 117 measured (attn512.h met the same wall: ~960 of the
+// ~4 450 cycles of an iteration).  Here the tile DMA belongs to FOUR PRODUCER WAVES that do nothing else (waves 8-11: with the cyclic wave ->
+// SIMD placement one per SIMD, beside one wave of each compute group; 125-136 VGPRs allow three waves per SIMD): a compute wave's R phase is
+// its fragment reads only, and the producers sit stalled at issue for as long as the fill path needs.  Same tile, same LDS images, same ring
+// of four stages and the same barrier numbering (producers keep group 0's cadence: one barrier per half k-step):
+//   slab s may be written after barrier 2s - 5 (its stage's last readers, group 1's R of slab s - 4, retired before barrier 2s - 7 ... 2s - 6)
+//   and is first read after barrier 2s - 1: the producers fire slab t + 2 between barriers 2t - 1 and 2t, and wait for slab t + 1 (counted
+//   vmcnt: one slab stays in flight) between barriers 2t and 2t + 1.
+template <int AMODE, int BMODE, int OUT_F32, int BN_>
+__global__ __launch_bounds__(768, 1) void nk_gemm_g2p_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HN = BN_ / 2, NJ = HN / 16;          // columns per group; 16-column blocks per wave: 4 or 5
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + BN_ - 1) / BN_, ntm = (p.M + G2_BM - 1) / G2_BM;
+  constexpr int GM = 4;
+  const int per_group = GM * ntn;
+  const int group = wg / per_group;
+  const int first_m = group * GM;
+  const int gm = min(GM, ntm - first_m);
+  const int in_group = wg - group * per_group;
+  const int nt = in_group / gm;
+  const int m0 = (first_m + (in_group - nt * gm)) * G2_BM, n0 = nt * BN_;
+  const int nk = (p.K + BK - 1) / BK;
+  const bf16_t* Ap = p.nbatch ? p.Ab[blockIdx.z] : p.A;
+  const bf16_t* Bp = p.nbatch ? p.Bb[blockIdx.z] : p.B;
+  void* Cp = p.nbatch ? p.Cb[blockIdx.z] : p.C;
+#define G2_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
+
+  if (wave >= 8) {
+    // ================= producer: the tile DMA of all 128 + BN_ rows, pieces pw + 4 i =================
+    const int pw = wave - 8;
+    OpG2<AMODE, 128, 4> oa;
+    OpG2<BMODE, BN_, 4> ob;
+    oa.init(Ap, p.lda, p.M, m0, pw, lane, &p.ga, &p.tw);
+    ob.init(Bp, p.ldb, p.N, n0, pw, lane, &p.gb, &p.tw);
+    static_assert(OpG2<AMODE, 128, 4>::NPC % 4 == 0 && OpG2<BMODE, BN_, 4>::NPC % 4 == 0, "every producer issues the same number of pieces");
+    constexpr int PPS = OpG2<AMODE, 128, 4>::NPW + OpG2<BMODE, BN_, 4>::NPW;      // pieces per slab and producer: 8 or 9
+    const bf16_t* sa[OpG2<AMODE, 128, 4>::NPW];
+    const bf16_t* sb[OpG2<BMODE, BN_, 4>::NPW];
+    oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);
+    oa.fire(sa, smem, pw); ob.fire(sb, smem + 16384, pw);
+    oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);
+    oa.fire(sa, smem + G2_STAGE_BYTES, pw); ob.fire(sb, smem + G2_STAGE_BYTES + 16384, pw);
+    oa.next_sources(p.K, sa); ob.next_sources(p.K, sb);             // sources of slab 2
+    if constexpr (PPS == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // slab 0 landed
+    G2_BAR();
+    unsigned sn = 2 * G2_STAGE_BYTES;                                // stage of slab t + 2
+    for (int t = 0; t < nk; ++t) {
+      // (the A pieces in front of barrier 2t, the B pieces behind it: 36 KiB are ~560 cycles of the fill path, and all of them in one half k-step
+      // made that half as long -- the compute waves wait at the barrier for the producers)
+      oa.fire(sa, smem + sn, pw);
+      oa.next_sources(p.K, sa);
+      G2_BAR();                                                      // 2t
+      ob.fire(sb, smem + sn + 16384, pw);
+      ob.next_sources(p.K, sb);
+      if constexpr (PPS == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // slab t + 1 landed
+      G2_BAR();                                                      // 2t + 1
+      sn += G2_STAGE_BYTES; if (sn == G2_NS * G2_STAGE_BYTES) sn = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the past-the-end zero-page pieces land before this wave gives up
+    G2_BAR();
+    return;
+  }
+
+  // ================= compute: nk_gemm_g2_kernel's two groups without any staging =================
+  const int grp = wave >> 2, wq = wave & 3;
+  constexpr int AF = (AMODE == OP_KC || AMODE == OP_KCG) ? OP_KC : OP_MC;
+  constexpr int BF = (BMODE == OP_KC || BMODE == OP_KCG) ? OP_KC : OP_MC;
+  typedef __attribute__((address_space(3))) const char* lds_c;
+  const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
+  FragG2<AF, 128, 2> fa;
+  FragG2<BF, BN_, NJ> fb;
+  fa.init(lds0, wq * 32, lane);
+  fb.init(lds0 + 16384u, grp * HN, lane);
+
+  float4_t acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[4], bfr[2 * NJ];
+  constexpr bool CAN_BIAS = AMODE == OP_MC && OUT_F32 == 1;
+  float* const dbias = CAN_BIAS ? (p.nbatch ? p.dbias_b[blockIdx.z] : p.dbias) : nullptr;
+  const bool do_bias = CAN_BIAS && dbias != nullptr && nt == 0;
+  float4_t accb = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  G2_BAR();
+  if (grp == 1) { G2_BAR(); }                                       // the second group runs one barrier behind
+  unsigned so = 0;
+  for (int t = 0; t < nk; ++t) {
+    // ---- R: fragment reads of slab t ----
+    __builtin_amdgcn_sched_barrier(0);
+    g2_read<BF, BN_, NJ>(bfr, fb, so);
+    g2_read<AF, 128, 2>(af, fa, so);
+    G2_BAR();
+    // ---- M: the wave's MFMAs ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)     // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks * NJ + j], af[ks * 2 + i], acc[i][j], 0, 0, 0);
+    if constexpr (CAN_BIAS) {
+      if (do_bias) {      // two wave-uniform branches, not `grp ? af[1] : af[0]`: hipcc turned that select into an indexed copy of the fragments in
+        if (grp) {        // scratch, stored right behind the asm reads and BEFORE their s_waitcnt -- garbage bias gradients (caught by the batched test)
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nk_ones_frag(), af[1], accb, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nk_ones_frag(), af[3], accb, 0, 0, 0);
+        } else {
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nk_ones_frag(), af[0], accb, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nk_ones_frag(), af[2], accb, 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    G2_BAR();
+    so += G2_STAGE_BYTES; if (so == G2_NS * G2_STAGE_BYTES) so = 0;
+  }
+  if (grp == 0) { G2_BAR(); }
+#undef G2_BAR
+
+  const int mb = m0 + wq * 32, nb = n0 + grp * HN;
+  if constexpr (CAN_BIAS) {
+    if (do_bias && lane < 16) {
+      const int m = mb + grp * 16 + lane;
+      if (m < p.M) dbias[m] = p.accumulate ? dbias[m] + accb[0] * p.alpha : accb[0] * p.alpha;
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < NJ / 2; ++half) {
+    float4_t pair[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { pair[i][0] = acc[i][2 * half]; pair[i][1] = acc[i][2 * half + 1]; }
+    reg_epilogue_64x32<OUT_F32, 2>(p, Cp, pair, mb, nb + half * 32, lane);
+  }
+  if constexpr (NJ & 1) {
+    float4_t last[2] = {acc[0][NJ - 1], acc[1][NJ - 1]};
+    reg_epilogue_col16<OUT_F32, 2>(p, Cp, last, mb, nb + (NJ - 1) * 16, lane);
+  }
+}
+
+// NK_GEMM_G2P: 1 (default) = the producer-wave variant wherever the two-group kernel is selected; 0 = nk_gemm_g2_kernel (A/B runs)
+static bool g2p_enabled() {
+  const char* e = getenv("NK_GEMM_G2P");
+  return !e || atoi(e) != 0;
+}
+
 // NK_GEMM_G2: 0 = never; 1 (default) = by shape; 2 = every eligible launch (A/B runs)
 static int g2_mode() {
   int mode = 1;
@@ -479,9 +640,15 @@ static bool use_g2(const NkGemmParams& p, int amode, int bmode, int out_f32, int
 
 template <int AMODE, int BMODE, int OUT_F32, int BN_>
 static int launch_g2_as(const NkGemmParams& p, hipStream_t stream) {
+  dim3 grid(((p.M + G2_BM - 1) / G2_BM) * ((p.N + BN_ - 1) / BN_), 1, p.nbatch ? p.nbatch : 1);
+  if (g2p_enabled()) {
+    auto kp = nk_gemm_g2p_kernel<AMODE, BMODE, OUT_F32, BN_>;
+    nk_optin_lds((const void*)kp, G2_SMEM_BYTES);
+    hipLaunchKernelGGL(kp, grid, dim3(768), G2_SMEM_BYTES, stream, p);
+    return nk_check_launch("nk_gemm_g2p_kernel");
+  }
   auto kern = nk_gemm_g2_kernel<AMODE, BMODE, OUT_F32, BN_>;
   nk_optin_lds((const void*)kern, G2_SMEM_BYTES);
-  dim3 grid(((p.M + G2_BM - 1) / G2_BM) * ((p.N + BN_ - 1) / BN_), 1, p.nbatch ? p.nbatch : 1);
   hipLaunchKernelGGL(kern, grid, dim3(512), G2_SMEM_BYTES, stream, p);
   return nk_check_launch("nk_gemm_g2_kernel");
 }
