@@ -620,7 +620,7 @@ static bool use_g2(const NkGemmParams& p, int amode, int bmode, int out_f32, int
   if (p.K < 2 * BK) return false;
   // not the SINGLE weight gradients: in the two-stream step they do better with the co-resident 128 x 128 kernels (187.6 vs 189.0 ms);
   // the batched ones (three 1280 x 1280 per launch = 240 tiles, one round) do better here: 49.7 vs 65.4 us alone, 177.2 vs 177.6 ms/step
-  if (amode == OP_MC && bmode == OP_MC && !p.nbatch) return false;
+  if (amode == OP_MC && bmode == OP_MC && !p.nbatch) return false;      // (round 4, with the producer-wave kernel: 158.0 / 157.9 vs 158.0 / 158.9 ms per step -- still nothing)
   const int bn = g2_bn(p.N);
   if (!bn) return false;
   if (mode == 2) return true;
