@@ -377,7 +377,15 @@ def main():
     device = torch.device("cuda", local)
     import torch.distributed as dist
 
-    if world > 1:
+    # NK_DP_FORCE=1 at N = 1: the single rank issues every collective of the exchange all the same (neurosis_amd/dp.py) -- the one way a 1-GPU box
+    # can run the full-size step's exchange through RCCL itself; what it measures is the cost of the exchange machinery without any wire time
+    forced = world == 1 and os.environ.get("NK_DP_FORCE", "0") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or forced:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -396,7 +404,7 @@ def main():
         eng.stream_optimizer = True
     if args.optimizer == "adafactor":
         eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)   # configs/sdxl/sdxl.example.yaml:158-164
-    dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if args.wire_dtype == "bf16" else None, mode=args.dp_mode) if world > 1 else None
+    dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if args.wire_dtype == "bf16" else None, mode=args.dp_mode) if world > 1 or forced else None
     if dp is not None and dp.sharded:
         if args.optimizer != "adafactor":
             raise SystemExit("--dp-mode rs_ag needs --optimizer adafactor (the chunked fused optimizer)")
@@ -588,7 +596,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SDXL-base {'mixed-res buckets (~1024^2 pixels)' if args.mixed_res else str(args.res) + '^2'} bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, {'frozen TE outputs synthetic' if args.precomputed_te else 'frozen CLIP-L + OpenCLIP-bigG conditioner on synthetic token ids'}",
-                       "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}", "allreduce_dtype": args.wire_dtype, "activation_checkpointing": False if args.recompute == "none" else f"selective ({args.recompute})", "accumulate_grad_batches": args.accumulate},
+                       "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}" + (" (exchange forced through RCCL at world 1: NK_DP_FORCE)" if forced else ""), "allreduce_dtype": args.wire_dtype, "activation_checkpointing": False if args.recompute == "none" else f"selective ({args.recompute})", "accumulate_grad_batches": args.accumulate},
             "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "max_mem_setup_gb": round(setup_peak / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "step_ms_in_order": [round(t, 1) for t in in_order], "comm": comm,
             "host": {"unet_chain": "hipGraph replay" if priming else "eager launches", "graph_priming_steps": priming},
@@ -596,7 +604,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

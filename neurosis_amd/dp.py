@@ -33,6 +33,12 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 
+def _forced() -> bool:
+    import os
+
+    return os.environ.get("NK_DP_FORCE", "0") == "1"
+
+
 class FlatGradReducer:
     """All-reduces slices [lo, hi) of a flat gradient tensor across ranks, asynchronously when the tensor is on a GPU; also owns the
     exchange stream, the counters and the timing events that the sharded mode (FlatDataParallel, rs_ag) shares.
@@ -43,6 +49,9 @@ class FlatGradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # a single rank has nothing to exchange; NK_DP_FORCE=1 issues the collectives all the same (tests/test_dp_gpu.py: the one way a 1-GPU box
+        # can run the exchange through RCCL itself -- communicator, streams, collective argument checks -- rather than through gloo)
+        self.active = self.world > 1 or (dist.is_initialized() and _forced())
         self.wire_dtype = wire_dtype
         self.max_chunk = max_chunk
         self.collectives = 0           # collective calls issued since take_counts()
@@ -73,7 +82,7 @@ class FlatGradReducer:
 
     def reduce_range(self, lo: int, hi: int, also_wait=None) -> None:
         """All-reduce flat[lo:hi] once the gradients in it are final (order_after_compute)."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         self.order_after_compute(also_wait)
         for a in range(lo, hi, self.max_chunk):
@@ -102,7 +111,7 @@ class FlatGradReducer:
 
     def finish(self) -> None:
         """Make the compute stream wait for every outstanding reduction."""
-        if self.cuda and self.world > 1:
+        if self.cuda and self.active:
             ev = torch.cuda.Event(enable_timing=self.record_timing)
             ev.record(self.stream)
             torch.cuda.current_stream().wait_event(ev)
@@ -174,7 +183,7 @@ class FlatDataParallel:
         self.plans = None                   # rs_ag: {(lo, hi): SlicePlan}
         self._vec_index = None
         self._stage = {}
-        if self.mode == "rs_ag" and world > 1:
+        if self.mode == "rs_ag" and (world > 1 or (dist.is_initialized() and _forced())):
             if wire_dtype is not None and wire_dtype != store.grad.dtype:
                 raise ValueError("rs_ag reduces in the gradient buffer's dtype (a narrower wire is an all-reduce option)")
             ranges = sorted(slices if slices is not None else _top_block_ranges(unet, store))
@@ -200,7 +209,7 @@ class FlatDataParallel:
         self.sync = True
         self._optimizers = []
         self._health = None
-        if broadcast_params and self.world > 1:
+        if broadcast_params and self.reducer.active:
             dist.broadcast(store.master, src=0, group=group)
             store.refresh()
         unet.grad_ready_hook = self._on_block_done
@@ -314,7 +323,7 @@ class FlatDataParallel:
         return 1.0 / self.world
 
     def _merge_health(self) -> None:
-        if self.world == 1 or not self.store.grad.is_cuda or not self.sync:
+        if not self.reducer.active or not self.store.grad.is_cuda or not self.sync:
             return
         from .lib import call
 

@@ -186,6 +186,69 @@ def test_exchange_modes_two_ranks_one_gpu():
         assert o["stale_before_sync"], o                                # foreign shards' masters ARE stale until sync_masters()
 
 
+def _worker_rccl_world1(rank, world, port, out):
+    """ONE rank, backend "nccl": NK_DP_FORCE=1 makes the single rank issue every collective of the exchange, so RCCL itself executes them on a
+    1-GPU box -- communicator set-up, the exchange stream's ordering against both compute streams and the replayed hipGraph segments, the
+    argument checks of all_reduce / reduce_scatter_tensor / all_gather_into_tensor / broadcast (stricter than gloo's).  A sum over one rank is
+    the identity: every configuration must end where the engine without any exchange ends."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", NK_DP_FORCE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from neurosis_amd.dp import FlatDataParallel
+
+    fx = load_fixture("unet_sdxl_tiny")
+    shapes = json.loads((G / "unet_sdxl_tiny_keys.json").read_text())
+    res, info = {}, {}
+    for tag, mode, wire in (("none", None, None), ("ar32", "allreduce", None), ("ar16", "allreduce", torch.bfloat16), ("rsag", "rs_ag", None)):
+        eng = _build(fx, shapes)
+        af = eng.configure_adafactor(scale_parameter=True, relative_step=False, warmup_init=False, lr=1e-3)
+        dp = None
+        if mode is not None:
+            dp = FlatDataParallel(eng.model.diffusion_model, eng.store, wire_dtype=wire, mode=mode)
+            dp.attach_optimizer(af)
+            dp.reducer.take_counts()
+        for _ in range(4):                      # eager chain, graph capture, two replays
+            _loss(eng, fx, slice(0, 2)).mean().backward()
+            scale = dp.finish() if dp is not None else 1.0
+            eng.optimizer_step(grad_scale=scale, dp=dp)
+        eng.join_optimizer()
+        if dp is not None:
+            dp.sync_masters()
+            info[tag] = dict(collectives=dp.reducer.take_counts()[0], sharded=dp.sharded, active=dp.reducer.active, scale=scale)
+        torch.cuda.synchronize()
+        graphs = eng.model.diffusion_model._nk_graphs
+        info.setdefault(tag, {})["replayed"] = graphs is not None and int(graphs.ticks) == 3
+        res[tag] = (eng.store.master.cpu().clone(), eng.store.shadow.float().cpu())
+        eng.model.diffusion_model.grad_ready_hook = None
+        del eng, dp, af
+        torch.cuda.empty_cache()
+    ref, ref_sh = res["none"]
+    start = _build(fx, shapes).store.master.cpu()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    out["info"] = info
+    out["moved"] = rel(ref, start)
+    out["diff"] = {k: (rel(v[0], ref), rel(v[1], ref_sh)) for k, v in res.items() if k != "none"}
+    out["backend"] = dist.get_backend()
+    out["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_executes_the_exchange_at_world_1():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_rccl_world1, args=(1, _free_port(), out), nprocs=1, join=True)
+    print("RCCL world-1 exchange:", dict(out))
+    assert out["backend"] == "nccl" and out["moved"] > 1e-5
+    for tag in ("ar32", "ar16", "rsag"):
+        i = out["info"][tag]
+        assert i["active"] and i["collectives"] > 0 and i["scale"] == 1.0 and i["replayed"], (tag, i)
+        assert i["sharded"] == (tag == "rsag")
+        dm, dsh = out["diff"][tag]
+        # identity exchange: the distance to the run without one is the run-to-run noise (fp32 wire) or bf16 rounding of the gradients (bf16 wire)
+        assert dm <= (0.08 if tag == "ar16" else 0.02) * out["moved"] and dsh <= 1e-2, (tag, out["diff"], out["moved"])
+
+
 def test_engine_accumulate_helper_overwrites_then_adds():
     """DiffusionEngine.accumulate(i): micro-batch 0 overwrites the flat gradient buffer (no zero-fill between steps), later
     ones add; optimizer_step() resets the mode."""
