@@ -612,8 +612,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
 #pragma unroll
   for (int u = 0; u < BPW; ++u) accb[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-  opa.start(kbeg, p.ga);      // running source pointers, as in the ring and stream-K kernels
-  opb.start(kbeg, p.gb);
+  // rotated k order (OpG2::rotate in gemm_g2.h has the why): XCD x walks slabs s0, ..., nk - 1, 0, ..., s0 - 1 of its k range, s0 = x nk / 8
+  // (forward / input-gradient instantiations only: their B operand is the weight matrix every XCD reads in full; weight gradients keep the plain order)
+  constexpr bool CAN_ROT = AMODE == OP_KC || AMODE == OP_KCG;
+  const int s0 = CAN_ROT && p.k_rotate ? (xcd * nk) >> 3 : 0;
+  opa.start(kbeg + s0 * BK, p.ga);      // running source pointers, as in the ring and stream-K kernels
+  opb.start(kbeg + s0 * BK, p.gb);
   if (nk > 0) {
     opa.issue_next(kend, smem, p.ga, p.tw);
     opb.issue_next(kend, smem + V2_OPND_BYTES, p.gb, p.tw);
@@ -640,6 +644,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * V2_STAGE_BYTES;
+      if constexpr (CAN_ROT) {
+        if (kt + 1 == nk - s0) {            // the rotated order wraps to the start of the k range
+          opa.start(kbeg, p.ga);
+          opb.start(kbeg, p.gb);
+        }
+      }
       opa.issue_next(kend, nxt, p.ga, p.tw);
       opb.issue_next(kend, nxt + V2_OPND_BYTES, p.gb, p.tw);
     }
@@ -1272,7 +1282,23 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
     b0.init(p.B, p.ldb, p.N, n0, tid, p.gb);
     b1.init(p.B, p.ldb, p.N, n0 + 128, tid, p.gb);
   }
-  a0.start(0); a1.start(0); b0.start(0); b1.start(0);
+  // rotated k order (OpG2::rotate in gemm_g2.h has the why): XCD x walks slabs s0, ..., nk - 1, 0, ..., s0 - 1, s0 = x nk / 8.  Every operand
+  // counts the slabs it has handed out: after nk - s0 of them it restarts at k = 0 with s0 slabs to go, after nk it yields the zero page.
+  const int s0 = p.k_rotate ? (xcd * nk) >> 3 : 0;
+  const int wrap_at = nk - s0;
+  int na0 = 0, na1 = 0, nb0 = 0, nb1 = 0, ka0 = kend, ka1 = kend, kb0 = kend, kb1 = kend;
+  a0.start(s0 * BK); a1.start(s0 * BK); b0.start(s0 * BK); b1.start(s0 * BK);
+#define X2_NEXT(op, src, g, cnt, ke)                        \
+  do {                                                      \
+    op.next_sources(ke, src, g, p.tw);                      \
+    if (++cnt == wrap_at) { op.start(0); ke = s0 * BK; }    \
+  } while (0)
+#define X2_ISSUE(op, img, g, cnt, ke)                       \
+  do {                                                      \
+    const bf16_t* s_[2];                                    \
+    X2_NEXT(op, s_, g, cnt, ke);                            \
+    op.fire(0, s_[0], img); op.fire(1, s_[1], img);         \
+  } while (0)
   float4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -1311,15 +1337,15 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
   const bf16_t* sb0[2];
   const bf16_t* sb1[2];
   if (nk > 0) {
-    a0.issue_next(kend, smem, p.ga, p.tw);
-    a1.issue_next(kend, smem + 16384, p.ga, p.tw);
-    b0.issue_next(kend, smem + 32768, p.gb, p.tw);
-    b1.issue_next(kend, smem + 49152, p.gb, p.tw);
-    b0.issue_next(kend, smem + XL_STAGE_BYTES + 32768, p.gb, p.tw);     // B of slab 1 (past the end: the zero page, never read)
-    b1.issue_next(kend, smem + XL_STAGE_BYTES + 49152, p.gb, p.tw);
+    X2_ISSUE(a0, smem, p.ga, na0, ka0);
+    X2_ISSUE(a1, smem + 16384, p.ga, na1, ka1);
+    X2_ISSUE(b0, smem + 32768, p.gb, nb0, kb0);
+    X2_ISSUE(b1, smem + 49152, p.gb, nb1, kb1);
+    X2_ISSUE(b0, smem + XL_STAGE_BYTES + 32768, p.gb, nb0, kb0);        // B of slab 1 (past the end: the zero page, never read)
+    X2_ISSUE(b1, smem + XL_STAGE_BYTES + 49152, p.gb, nb1, kb1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   }
-  a1.next_sources(kend, sa1, p.ga, p.tw);                               // A1 of slab 1, fired in phase 0 of slab 0
+  X2_NEXT(a1, sa1, p.ga, na1, ka1);                                     // A1 of slab 1, fired in phase 0 of slab 0
   X2_BAR();
   if (wm == 1) { X2_BAR(); }               // the second group runs one barrier behind
   for (int t = 0; t < nk; ++t) {
@@ -1334,7 +1360,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
     a1.fire(0, sa1[0], oth + 16384);       // A1(t+1)
     a1.fire(1, sa1[1], oth + 16384);
     X2_BAR();
-    X2_MM(0, 0, bc0, a0.next_sources(kend, sa0, p.ga, p.tw));
+    X2_MM(0, 0, bc0, X2_NEXT(a0, sa0, p.ga, na0, ka0));
     X2_BAR();
     // phase 1: rows 0-63 x columns 32-63
     X2_RDB(bc1, 1);
@@ -1346,7 +1372,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
     // phase 2: rows 64-127 x columns 32-63
     X2_RDA(1);
     X2_BAR();
-    X2_MM(4, 2, bc1, (b0.next_sources(kend, sb0, p.gb, p.tw), b1.next_sources(kend, sb1, p.gb, p.tw)));
+    X2_MM(4, 2, bc1, X2_NEXT(b0, sb0, p.gb, nb0, kb0); X2_NEXT(b1, sb1, p.gb, nb1, kb1));
     X2_BAR();
     // phase 3: rows 64-127 x columns 0-31; B of slab t + 2 goes into THIS slab's stage (its B reads retired two phases ago)
     b0.fire(0, sb0[0], cur + 32768);
@@ -1355,11 +1381,13 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
     b1.fire(1, sb1[1], cur + 49152);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // all but those four pieces: slab t + 1 is complete (this wave's share)
     X2_BAR();
-    X2_MM(4, 0, bc0, a1.next_sources(kend, sa1, p.ga, p.tw));
+    X2_MM(4, 0, bc0, X2_NEXT(a1, sa1, p.ga, na1, ka1));
     X2_BAR();
   }
   if (wm == 0) { X2_BAR(); }               // ... and the first group waits for it here
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the past-the-end zero-page pieces
+#undef X2_NEXT
+#undef X2_ISSUE
 #undef X2_RD1
 #undef X2_RDA
 #undef X2_RDB
@@ -1439,25 +1467,23 @@ static int launch_xl_as(const NkGemmParams& p, hipStream_t stream) {
   return nk_check_launch("nk_gemm_xl_kernel");
 }
 template <int AMODE>
-static int launch_xl(const NkGemmParams& p, hipStream_t stream) {
+static int launch_xl(const NkGemmParams& p_in, hipStream_t stream) {
   // by operand mode: dense k-contiguous A -> the two-group phased kernel (+3..6 % on the Linear shapes); gathered A -> the 16-wave kernel
   // (the gather's address arithmetic would sit in the phased kernel's read phases, where only one wave per SIMD is there to absorb it:
   // conv forward 781-785 vs 835-840 TFLOP/s)
   if (AMODE == OP_KC) {
-    static bool gattr = false;
     auto kern = nk_gemm_xl2g_kernel<OP_KC, 0>;
     auto kerng = nk_gemm_xl2g_kernel<OP_KC, 1>;
-    if (!gattr) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES);
-      (void)hipFuncSetAttribute((const void*)kerng, hipFuncAttributeMaxDynamicSharedMemorySize, XL_SMEM_BYTES);
-      gattr = true;
-    }
+    nk_optin_lds((const void*)kern, XL_SMEM_BYTES);
+    nk_optin_lds((const void*)kerng, XL_SMEM_BYTES);
+    NkGemmParams p = p_in;
+    p.k_rotate = k_rotate_on(p.K) ? 1 : 0;
     dim3 grid(((p.M + XL_BM - 1) / XL_BM) * ((p.N + XL_BN - 1) / XL_BN), 1, 1);
     if (p.geglu_h) hipLaunchKernelGGL(kerng, grid, dim3(512), XL_SMEM_BYTES, stream, p);
     else hipLaunchKernelGGL(kern, grid, dim3(512), XL_SMEM_BYTES, stream, p);
     return nk_check_launch("nk_gemm_xl2g_kernel");
   }
-  return launch_xl_as<AMODE, 64, 64>(p, stream);
+  return launch_xl_as<AMODE, 64, 64>(p_in, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1479,6 +1505,7 @@ static int launch(const NkGemmParams& p_in, int splitk, hipStream_t stream) {
     while ((g + 1) * (g + 1) <= per_xcd) ++g;
     p2.group_m = g > GROUP_M ? GROUP_M : g;
   }
+  p2.k_rotate = k_rotate_on(splitk > 1 ? p.ksplit_len : p.K) ? 1 : 0;      // (nk_gemm_dma_kernel; the ring kernel walks k in order)
   // under-filled grids (at most one workgroup per CU): the four-stage ring.  (The ring on LARGE grids was measured too: 723 vs 830 TFLOP/s
   // at 65536 x 1280 x 1280 -- three slabs in flight do not make up for two waves per SIMD meeting at a barrier every k-step.)
   if (!p.nbatch && (long)ntm * ntn * splitk <= 256) {

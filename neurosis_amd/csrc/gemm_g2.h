@@ -58,6 +58,8 @@ struct OpG2 {
   bool ok[NPW];                                        // row / r-chunk in range
   long step;                                           // pointer advance per slab
   int kcur;
+  int left = 0x7fffffff, kwrap = 0x7fffffff;           // slabs still to hand out; k at which the rotated order wraps to 0 (rotate())
+  long wrap = 0;                                       // pointer rewind at the wrap
   int pn[NPW], pbh[NPW], pbw[NPW];                     // KCG: pixel of the piece's row (image, top-left input row / column of its window);
                                                        // for plain windows pn is the element offset of (n, bh, bw, the lane's chunk) instead
   long cofs[NPW];                                      // MCT: r-chunk offset of the piece
@@ -116,9 +118,25 @@ struct OpG2 {
       }
     }
   }
+  // Rotated k order: hand out slabs s0, s0 + 1, ..., nk - 1, 0, ..., s0 - 1 (then the zero page).  Every XCD of a launch reads the WHOLE of the
+  // operand its tiles share (the weights of a forward / input-gradient GEMM), and with all eight walking k in step each line of it is missed by
+  // eight L2s at the same moment: cold weights cost a 20-k-step GEMM 10-20 % (tools/bench_cold.py).  Started an eighth of K apart, one XCD's miss
+  // has filled the Infinity Cache by the time the next XCD asks.  (Sums the k-slabs in a different order per XCD: deterministic, not bit-equal to the
+  // unrotated order.)
+  __device__ __forceinline__ void rotate(int nk, int s0) {
+    left = nk;
+    kwrap = nk * BK;
+    wrap = (long)nk * step;
+    kcur = s0 * BK;
+    if constexpr (MODE == OP_KC || MODE == OP_MC) {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) rp[i] += (long)s0 * step;
+    }
+  }
   // sources of the next slab (advances the running state); past K or out of range: the zero page
-  __device__ __forceinline__ void next_sources(int K, const bf16_t* (&src)[NPW]) {
+  __device__ __forceinline__ void next_sources(int K_, const bf16_t* (&src)[NPW]) {
     const bf16_t* zp = (const bf16_t*)nk_zero_page;
+    const int K = left > 0 ? K_ : 0;                  // (every slab handed out: the zero page from here on)
     if constexpr (MODE == OP_KCG) {
       // (channel counts here are multiples of 64 -- use_g2() asks for it -- so a 64-deep slab lies inside ONE tap: the tap
       // decode is wave-uniform scalar work, and only the window's bounds test and the address are per lane)
@@ -161,6 +179,14 @@ struct OpG2 {
       }
     }
     kcur += BK;
+    --left;
+    if (kcur >= kwrap) {
+      kcur = 0;
+      if constexpr (MODE == OP_KC || MODE == OP_MC) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) rp[i] -= wrap;
+      }
+    }
   }
   __device__ __forceinline__ void fire(const bf16_t* const (&src)[NPW], char* img, int wave) const {
 #pragma unroll
@@ -322,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_g2_kernel(const NkGemmParams p
   OpG2<BMODE, BN_> ob;
   oa.init(Ap, p.lda, p.M, m0, wave, lane, &p.ga, &p.tw);
   ob.init(Bp, p.ldb, p.N, n0, wave, lane, &p.gb, &p.tw);
+  if (p.k_rotate) { oa.rotate(nk, (xcd * nk) >> 3); ob.rotate(nk, (xcd * nk) >> 3); }
   typedef __attribute__((address_space(3))) const char* lds_c;
   const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
   FragG2<AF, 128, 2> fa;
@@ -479,6 +506,7 @@ __global__ __launch_bounds__(768, 1) void nk_gemm_g2p_kernel(const NkGemmParams 
     OpG2<BMODE, BN_, 4> ob;
     oa.init(Ap, p.lda, p.M, m0, pw, lane, &p.ga, &p.tw);
     ob.init(Bp, p.ldb, p.N, n0, pw, lane, &p.gb, &p.tw);
+    if (p.k_rotate) { oa.rotate(nk, (xcd * nk) >> 3); ob.rotate(nk, (xcd * nk) >> 3); }
     static_assert(OpG2<AMODE, 128, 4>::NPC % 4 == 0 && OpG2<BMODE, BN_, 4>::NPC % 4 == 0, "every producer issues the same number of pieces");
     constexpr int PPS = OpG2<AMODE, 128, 4>::NPW + OpG2<BMODE, BN_, 4>::NPW;      // pieces per slab and producer: 8 or 9
     const bf16_t* sa[OpG2<AMODE, 128, 4>::NPW];
@@ -638,8 +666,16 @@ static bool use_g2(const NkGemmParams& p, int amode, int bmode, int out_f32, int
   return rounds <= 2 || (rounds <= 4 && nk >= 40);
 }
 
+// NK_GEMM_KROT: 1 (default) = rotated k order per XCD (OpG2::rotate; the two-group, 128 x 128 double-buffer and 256 x 256 two-group kernels) in launches of at least eight slabs; 0 = every XCD starts at k = 0 (A/B runs)
+static bool k_rotate_on(int k_len) {
+  const char* e = getenv("NK_GEMM_KROT");
+  return (!e || atoi(e) != 0) && (k_len + BK - 1) / BK >= 8;
+}
+
 template <int AMODE, int BMODE, int OUT_F32, int BN_>
-static int launch_g2_as(const NkGemmParams& p, hipStream_t stream) {
+static int launch_g2_as(const NkGemmParams& p_in, hipStream_t stream) {
+  NkGemmParams p = p_in;
+  p.k_rotate = k_rotate_on(p.K) ? 1 : 0;
   dim3 grid(((p.M + G2_BM - 1) / G2_BM) * ((p.N + BN_ - 1) / BN_), 1, p.nbatch ? p.nbatch : 1);
   if (g2p_enabled()) {
     auto kp = nk_gemm_g2p_kernel<AMODE, BMODE, OUT_F32, BN_>;

@@ -519,7 +519,7 @@ def test_colsum_batched_and_linear_fwd_batched(ops):
 
 
 @pytest.mark.parametrize("shape", [(4096, 5120, 1280), (16384, 2560, 640), (1000, 384, 256)])
-def test_feedforward_projection_with_fused_geglu_forward(ops, shape):
+def test_feedforward_projection_with_fused_geglu_forward(ops, shape, monkeypatch):
     """FeedForward.net[0] (modules/attention.py:50-57): the GEGLU in the projection's epilogue (nk_linear_fwd_geglu, the two SDXL widths at batch 4)
     gives bit for bit what the projection followed by the GEGLU kernel gives -- u, the saved pre-activation, and h -- and both agree with torch;
     a shape the 256 x 256 kernel does not take (the third) falls back to the two launches behind the same call."""
@@ -534,10 +534,17 @@ def test_feedforward_projection_with_fused_geglu_forward(ops, shape):
     bp = torch.nn.Parameter(b.cuda())
     fused = bool(query("nk_linear_fwd_geglu_ok", M, I, K))
     assert fused is (M >= 4096)
+    # bit for bit with every XCD walking k from 0: under the default rotated order (NK_GEMM_KROT, gemm_g2.h OpG2::rotate) the k-slabs of an output
+    # element are summed in an order that depends on the XCD its tile lands on, and the fused kernel's column tiles are not the plain one's
+    monkeypatch.setenv("NK_GEMM_KROT", "0")
     u, h, bwd = ops.linear_geglu_fwd(dev(x), wp, bp)
     u2, _ = ops.linear_fwd(dev(x), wp, bp)
     h2 = ops.geglu_fwd(u2)[0]
     assert torch.equal(u, u2) and torch.equal(h, h2)
+    monkeypatch.delenv("NK_GEMM_KROT")
+    u, h, bwd = ops.linear_geglu_fwd(dev(x), wp, bp)          # the default order: same values up to the summation order
+    assert_close(u, u2.float().cpu(), 1e-2, "geglu projection u, rotated k order")
+    assert torch.equal(h, ops.geglu_fwd(u)[0])
     ur = F.linear(x.float(), w.float(), b)
     assert_close(u, ur, 2e-2, "geglu projection u")
     uq = u.float().cpu()
