@@ -35,7 +35,31 @@ struct AttnParams {
   int causal;           // forward: key j is visible to query i iff j <= i
   int qsplit;           // dK/dV kernel: workgroups per key block along the query range (partials in dkv_part)
   float* dkv_part;      // [qsplit][2][B][Lk][H*D] fp32 partial dK / dV when qsplit > 1
+  int gx;               // > 0: the launch is a 1-D grid of gx * H * B workgroups and attn_wg() maps it XCD-aware; 0: the 3-D grid (x, head, batch)
 };
+
+// Which (x block, head, batch item) this workgroup is.  Workgroups go to the eight XCDs round-robin in launch order.  With the plain 3-D grid
+// (x fastest) the query blocks of ONE head -- which all stream that head's K and V (the key blocks of the dK / dV kernel: its Q' and dO) --
+// land on eight different XCDs: eight L2s each fetch their own copy over the fabric, at the same moment, from the same memory channels
+// (profiles/r04_pmc_summary.csv: the forward fetched 89 MB per launch for 31 MB of operands, the dQ kernel 249 MB).  The 1-D launch gives every
+// XCD a CONTIGUOUS range of the (batch, head, x) order instead, so a head's blocks share one L2.
+__device__ __forceinline__ void attn_wg(const AttnParams& p, int& bx, int& hd, int& b) {
+  if (p.gx == 0) { bx = blockIdx.x; hd = blockIdx.y; b = blockIdx.z; return; }
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int t = w / p.gx;
+  bx = w - t * p.gx;
+  b = t / p.H;
+  hd = t - b * p.H;
+}
+// the grid to launch for the 3-D extent `g` (sets p.gx); NK_ATTN_XCD=0 keeps the 3-D grid (A/B runs)
+static dim3 attn_grid(AttnParams& p, dim3 g) {
+  const char* e = getenv("NK_ATTN_XCD");
+  if (e && e[0] == '0') { p.gx = 0; return g; }
+  p.gx = (int)g.x;
+  return dim3(g.x * g.y * g.z, 1, 1);
+}
 
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1.0e30f)
@@ -121,8 +145,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel(const AttnParams p
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K,V][64][RS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, ql = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  int bx, hd, b;
+  attn_wg(p, bx, hd, b);
+  const int q0 = bx * (NW * 32) + wave * 32;
   const float c = p.scale * LOG2E;
 
   const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * p.D;
@@ -474,8 +499,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [3 stages][K, V][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, ql = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  int bx, hd, b;
+  attn_wg(p, bx, hd, b);
+  const int q0 = bx * (NW * 32) + wave * 32;
   const float c = p.scale * LOG2E;
 
   const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * 64;
@@ -698,8 +724,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dq_kernel(const AttnPar
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, ql = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  int bx, hd, b;
+  attn_wg(p, bx, hd, b);
+  const int q0 = bx * (NW * 32) + wave * 32;
   const int q = q0 + ql;
   const float c = p.scale * LOG2E;
 
@@ -861,8 +888,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dkdv_kernel(const AttnP
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, kl = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int kb = blockIdx.x / p.qsplit, qs = blockIdx.x - kb * p.qsplit;
+  int bx, hd, b;
+  attn_wg(p, bx, hd, b);
+  const int kb = bx / p.qsplit, qs = bx - kb * p.qsplit;
   const int k0 = kb * (NW * 32) + wave * 32;
 
   const Attn64Ws ws = Attn64Ws::make(p.B, p.H, p.Lq);
@@ -1074,7 +1102,8 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_small_kernel(const AttnPara
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // [K image][3 stages][2 dS^T buffers]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h5 = lane >> 5, kl = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y, qs = blockIdx.x;
+  int qs, hd, b;
+  attn_wg(p, qs, hd, b);
   const float c = p.scale * LOG2E;
   const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * 64;
   const bf16_t* Kb = p.K + (long)b * p.bk + (long)hd * 64;
@@ -1326,8 +1355,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dkdv_kernel(const AttnPar
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, kl = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int kb = blockIdx.x / p.qsplit, qs = blockIdx.x - kb * p.qsplit;
+  int bx, hd, b;
+  attn_wg(p, bx, hd, b);
+  const int kb = bx / p.qsplit, qs = bx - kb * p.qsplit;
   const int k0 = kb * (NW * 32) + wave * 32;
   const float c = p.scale * LOG2E;
 
@@ -1525,8 +1555,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParam
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, ql = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  int bx, hd, b;
+  attn_wg(p, bx, hd, b);
+  const int q0 = bx * (NW * 32) + wave * 32;
   const int q = q0 + ql;
   const float c = p.scale * LOG2E;
 
@@ -1703,13 +1734,14 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
   NK_CHECK_ARG(!d->causal || d->Lq == d->Lk);
   constexpr int nw = ATTN_NW;
   dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
+  const dim3 lgrid = attn_grid(p, grid);       // 1-D, XCD-aware (attn_wg)
   if (d->D == 512 || (d->D == 64 && attn64_enabled())) NK_CHECK_ARG(((uintptr_t)o & 15) == 0);      // 16-byte output stores
   if (d->D == 512) {
     // the VAE mid block's single head: one workgroup per CU, 512 registers per lane, all 160 KiB of LDS (attn512.h); lse may be null
     NK_CHECK_ARG(!d->causal);
     const int smem512 = 5 * 32 * 1024;
     set_smem(attn512_fwd_kernel, smem512);
-    hipLaunchKernelGGL(attn512_fwd_kernel, grid, dim3(256), smem512, stream, p);
+    hipLaunchKernelGGL(attn512_fwd_kernel, lgrid, dim3(256), smem512, stream, p);
     return nk_check_launch("attn512_fwd_kernel");
   }
   const int dp = attn_dp(d->D);
@@ -1717,12 +1749,12 @@ extern "C" int nk_attention_fwd(const NkAttnDesc* d, const void* q, const void* 
 #define FWD_CASE(DP_)                                                                          \
   if (dp == DP_) {                                                                             \
     set_smem(attn_fwd_kernel<DP_, ATTN_NW>, smem);                                                \
-    hipLaunchKernelGGL((attn_fwd_kernel<DP_, ATTN_NW>), grid, dim3(ATTN_NW * 64), smem, stream, p); \
+    hipLaunchKernelGGL((attn_fwd_kernel<DP_, ATTN_NW>), lgrid, dim3(ATTN_NW * 64), smem, stream, p); \
   }
   if (d->D == 64 && attn64_enabled()) {
     const int smem64 = 3 * 2 * 64 * 128;
     set_smem(attn64_fwd_kernel<ATTN_NW>, smem64);
-    hipLaunchKernelGGL((attn64_fwd_kernel<ATTN_NW>), grid, dim3(ATTN_NW * 64), smem64, stream, p);
+    hipLaunchKernelGGL((attn64_fwd_kernel<ATTN_NW>), lgrid, dim3(ATTN_NW * 64), smem64, stream, p);
     return nk_check_launch("attn64_fwd_kernel");
   }
   FWD_CASE(64) FWD_CASE(96) FWD_CASE(160)
@@ -1790,7 +1822,8 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
     p.dkv_part = p.qsplit > 1 ? delta_ws + w.part : nullptr;
     const int smem = 96 * 128 + 3 * (3 * 32 * 128 + 256 + 1024) + 2 * 96 * SMALL_DSROW;
     set_smem(attn64_bwd_small_kernel, smem);
-    hipLaunchKernelGGL(attn64_bwd_small_kernel, dim3(p.qsplit, d->H, d->B), dim3(256), smem, stream, p);
+    const dim3 lgrid = attn_grid(p, dim3(p.qsplit, d->H, d->B));
+    hipLaunchKernelGGL(attn64_bwd_small_kernel, lgrid, dim3(256), smem, stream, p);
     if (int e = nk_check_launch("attn64_bwd_small_kernel")) return e;
     if (p.qsplit > 1) {
       long total = (long)d->B * d->Lk * ((long)d->H * d->D / 4);
@@ -1808,18 +1841,20 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
     constexpr int nw = ATTN_NW;
     {
       dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
+      const dim3 lgrid = attn_grid(p, grid);       // 1-D, XCD-aware (attn_wg)
       const int smem = 3 * 2 * 64 * 128;
       set_smem(attn64_bwd_dq_kernel<ATTN_NW>, smem);
-      hipLaunchKernelGGL((attn64_bwd_dq_kernel<ATTN_NW>), grid, dim3(nw * 64), smem, stream, p);
+      hipLaunchKernelGGL((attn64_bwd_dq_kernel<ATTN_NW>), lgrid, dim3(nw * 64), smem, stream, p);
       if (int e = nk_check_launch("attn64_bwd_dq_kernel")) return e;
     }
     p.qsplit = attn_qsplit(d);
     p.dkv_part = p.qsplit > 1 ? delta_ws + w.part : nullptr;
     {
       dim3 grid(((d->Lk + nw * 32 - 1) / (nw * 32)) * p.qsplit, d->H, d->B);
+      const dim3 lgrid = attn_grid(p, grid);       // 1-D, XCD-aware (attn_wg)
       const int smem = 3 * (2 * 32 * 128 + 256);
       set_smem(attn64_bwd_dkdv_kernel<ATTN_NW>, smem);
-      hipLaunchKernelGGL((attn64_bwd_dkdv_kernel<ATTN_NW>), grid, dim3(nw * 64), smem, stream, p);
+      hipLaunchKernelGGL((attn64_bwd_dkdv_kernel<ATTN_NW>), lgrid, dim3(nw * 64), smem, stream, p);
       if (int e = nk_check_launch("attn64_bwd_dkdv_kernel")) return e;
     }
     if (p.qsplit > 1) {
@@ -1836,11 +1871,12 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   {
     constexpr int nw = ATTN_NW;
     dim3 grid((d->Lq + nw * 32 - 1) / (nw * 32), d->H, d->B);
+    const dim3 lgrid = attn_grid(p, grid);       // 1-D, XCD-aware (attn_wg)
     const int smem = 2 * 2 * 64 * (dp * 2 + 16);
 #define Q_CASE(DP_)                                                                          \
   if (dp == DP_) {                                                                             \
     set_smem(attn_bwd_dq_kernel<DP_, ATTN_NW>, smem);                                                \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP_, ATTN_NW>), grid, dim3(ATTN_NW * 64), smem, stream, p); \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP_, ATTN_NW>), lgrid, dim3(ATTN_NW * 64), smem, stream, p); \
   }
     Q_CASE(64) Q_CASE(96) Q_CASE(160)
 #undef Q_CASE
@@ -1851,11 +1887,12 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   {
     constexpr int nw = ATTN_NW;
     dim3 grid(((d->Lk + nw * 32 - 1) / (nw * 32)) * p.qsplit, d->H, d->B);
+    const dim3 lgrid = attn_grid(p, grid);       // 1-D, XCD-aware (attn_wg)
     const int smem = 2 * (2 * 32 * (dp * 2 + 16) + 256);
 #define KV_CASE(DP_)                                                                          \
   if (dp == DP_) {                                                                             \
     set_smem(attn_bwd_dkdv_kernel<DP_, ATTN_NW>, smem);                                                \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DP_, ATTN_NW>), grid, dim3(ATTN_NW * 64), smem, stream, p); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DP_, ATTN_NW>), lgrid, dim3(ATTN_NW * 64), smem, stream, p); \
   }
     KV_CASE(64) KV_CASE(96) KV_CASE(160)
 #undef KV_CASE

@@ -111,8 +111,9 @@ __global__ __launch_bounds__(256, 1) void attn512_fwd_kernel(const AttnParams p)
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // K stages 0-2, V stages 0-1: 160 KiB, all of the CU's LDS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h5 = lane >> 5, ql = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int bx, hd, b;
+  attn_wg(p, bx, hd, b);
+  const int q0 = bx * 128 + wave * 32;
   const float c = p.scale * LOG2E;
 
   const bf16_t* Qb = p.Q + (long)b * p.bq + (long)hd * 512;

@@ -138,11 +138,17 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   HaloWeights<BN_> wb;
   wb.init(p.B, p.ldb, Cout, n0, wave, lane);
   const long adv_tap = Cin, adv_slab = 64 - 8l * Cin;
+  // rotated slab order (OpG2::rotate in gemm_g2.h has the why: every XCD reads the whole weight tensor -- 29.5 MB for 1280 -> 1280): XCD x walks
+  // the channel slabs s0, ..., nslab - 1, 0, ..., s0 - 1, s0 = x nslab / 8; the taps of a slab keep their order
+  const int s0 = p.k_rotate ? (xcd * nslab) >> 3 : 0;
+  const long adv_wrap = 64 - 9l * Cin;               // from (last slab, tap 8) back to (slab 0, tap 0)
+#pragma unroll
+  for (int i = 0; i < HaloWeights<BN_>::NPW; ++i) wb.rp[i] += s0 * 64;
 
   // ---- prologue loads go out first: halo of slab 0, weights of k-steps 0 and 1 ----
   if (hwave) {
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) fire_halo(i, 0, smem);
+    for (int i = 0; i < HPW; ++i) fire_halo(i, s0, smem);
   } else {
     wb.fire_next(true, adv_tap, ring, wave);
     wb.fire_next(nk > 1, adv_tap, ring + CH_BSTAGE, wave);
@@ -179,10 +185,13 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
 
   unsigned so = 0, sn = 2 * CH_BSTAGE;                     // ring stage of k-step t / of k-step t + 2
   int t = 0;
+  int sl = s0;                                             // the channel slab of loop iteration s
   for (int s = 0; s < nslab; ++s) {
     const unsigned hcur = lds0 + (unsigned)(s & 1) * HBUF;
     char* const hnext = smem + ((s + 1) & 1) * HBUF;
     const bool more = s + 1 < nslab;
+    const int sln = sl + 1 == nslab ? 0 : sl + 1;
+    const long adv_end = sl + 1 == nslab ? adv_wrap : adv_slab;
     auto step = [&](auto tapc) {
       constexpr int tap = decltype(tapc)::value;
       constexpr int dy = tap / 3, dx = tap % 3;
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
         if (more) {
           constexpr int cnt = ch_count(HPW, HLAST, tap), st = ch_start(HPW, HLAST, tap);
 #pragma unroll
-          for (int i = 0; i < cnt; ++i) fire_halo(st + i, s + 1, hnext);
+          for (int i = 0; i < cnt; ++i) fire_halo(st + i, sln, hnext);
         }
         // the next slab's halo has landed (this wave's share): before the barrier that precedes its first use
         if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
       if (!hwave) {
         // weights of k-step t + 2; the pointer then moves on to k-step t + 3: the next tap, unless t + 2 is a slab's last tap
         constexpr int tap2 = (tap + 2) % 9;
-        wb.fire_next(t + 2 < nk, tap2 == 8 ? adv_slab : adv_tap, ring + sn, wave);
+        wb.fire_next(t + 2 < nk, tap2 == 8 ? adv_end : adv_tap, ring + sn, wave);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -238,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
     step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    sl = sln;
   }
   if (grp == 0) { CH_BAR(); }                              // ... and the first group waits for it here
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the past-the-end zero-page pieces must land before the LDS is given up
@@ -456,7 +466,9 @@ static bool use_halo(const NkGemmParams& p, int amode, int bmode, int out_f32) {
 }
 
 template <int BN_, int MI, int STATS>
-static int launch_halo_as(const NkGemmParams& p, hipStream_t stream) {
+static int launch_halo_as(const NkGemmParams& p_in, hipStream_t stream) {
+  NkGemmParams p = p_in;
+  p.k_rotate = k_rotate_on(p.ga.C) ? 1 : 0;          // (channel slabs, not k-steps: 512 input channels and up)
   auto kern = nk_conv3x3_halo_kernel<BN_, MI, STATS>;
   nk_optin_lds((const void*)kern, HaloGeom<MI>::SMEM);
   const NkGather& g = p.ga;

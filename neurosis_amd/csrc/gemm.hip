@@ -613,8 +613,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void nk_gemm_dma_kernel(const NkGe
   for (int u = 0; u < BPW; ++u) accb[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   // rotated k order (OpG2::rotate in gemm_g2.h has the why): XCD x walks slabs s0, ..., nk - 1, 0, ..., s0 - 1 of its k range, s0 = x nk / 8
-  // (forward / input-gradient instantiations only: their B operand is the weight matrix every XCD reads in full; weight gradients keep the plain order)
-  constexpr bool CAN_ROT = AMODE == OP_KC || AMODE == OP_KCG;
+  // (not the gathered weight-gradient instantiations: the restart costs them registers they do not have)
+  constexpr bool CAN_ROT = AMODE == OP_KC || AMODE == OP_KCG || (AMODE == OP_MC && BMODE == OP_MC);
   const int s0 = CAN_ROT && p.k_rotate ? (xcd * nk) >> 3 : 0;
   opa.start(kbeg + s0 * BK, p.ga);      // running source pointers, as in the ring and stream-K kernels
   opb.start(kbeg + s0 * BK, p.gb);

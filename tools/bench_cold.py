@@ -25,3 +25,30 @@ for M, N, K in [(4096, 1280, 1280), (4096, 3840, 1280), (4096, 1280, 5120), (163
             coldw = min(timed([mk(0, j) for j in range(R)], 192) for _ in range(2))
             cold = min(timed([mk(j, j) for j in range(R)], 192) for _ in range(2))
             print(f"{kind:5s} {M} x {N} x {K} krot={krot}:  same buffers {hot:6.1f} us ({fl/hot/1e6:5.0f} TF/s) | weights rotating {coldw:6.1f} ({fl/coldw/1e6:5.0f}) | everything rotating {cold:6.1f} ({fl/cold/1e6:5.0f})", flush=True)
+
+# Linear weight gradients dW[N, K] = dy[M, N]^T x[M, K] (128 x 128 double-buffer kernel): both operands are activations, every tile walks the tokens
+for M, N, K in [(4096, 10240, 1280), (4096, 1280, 5120), (4096, 3840, 1280)]:
+    R = 24
+    xs, dys = [rb(M, K) for _ in range(R)], [rb(M, N) for _ in range(R)]
+    dw = torch.zeros(N, K, device="cuda")
+    fl = 2.0 * M * N * K
+    for krot in ("0", "1"):
+        os.environ["NK_GEMM_KROT"] = krot
+        hot = min(timed([lambda: ops.gemm_tn_f32(dys[0], xs[0], dw, False)], 96) for _ in range(2))
+        cold = min(timed([(lambda j=j: ops.gemm_tn_f32(dys[j], xs[j], dw, False)) for j in range(R)], 96) for _ in range(2))
+        print(f"wgrad {M} x {N} x {K} krot={krot}:  same buffers {hot:6.1f} us ({fl/hot/1e6:5.0f} TF/s) | activations rotating {cold:6.1f} ({fl/cold/1e6:5.0f})", flush=True)
+
+# 3 x 3 convolutions of the UNet's 32^2 / 64^2 levels (halo-tile kernel, conv_halo.h): weights of 7-59 MB, rotating over 12 buffers
+from neurosis_amd.ops import Img
+for (N, H, W, Ci, Co) in [(4, 32, 32, 1280, 1280), (4, 32, 32, 2560, 1280), (4, 64, 64, 640, 640), (4, 64, 64, 1280, 640)]:
+    R = 12
+    x = Img(rb(N * H * W, Ci), N, H, W)
+    ws = [torch.nn.Parameter(ops.conv_weight_param(Co, Ci, 3, 3).data.normal_(0, (9 * Ci) ** -0.5).cuda(), requires_grad=False) for _ in range(R)]
+    bias = torch.randn(Co, device="cuda")
+    fl = 2.0 * N * H * W * Ci * Co * 9
+    for w in ws: ops.conv2d_fwd(x, w, bias, need_dx=False)        # (bf16 shadows made here, outside the timing)
+    for krot in ("0", "1"):
+        os.environ["NK_GEMM_KROT"] = krot
+        hot = min(timed([lambda: ops.conv2d_fwd(x, ws[0], bias, need_dx=False)], 48) for _ in range(2))
+        cold = min(timed([(lambda w=w: ops.conv2d_fwd(x, w, bias, need_dx=False)) for w in ws], 48) for _ in range(2))
+        print(f"conv  {N} x {H}x{W} {Ci} -> {Co} krot={krot}:  same weights {hot:6.1f} us ({fl/hot/1e6:5.0f} TF/s) | weights rotating {cold:6.1f} ({fl/cold/1e6:5.0f})", flush=True)
