@@ -88,12 +88,45 @@ class GeneralConditioner(nn.Module):
         keep = torch.bernoulli(torch.full((emb.shape[0],), 1.0 - rate, device=emb.device))
         return emb * keep.reshape((-1,) + (1,) * (emb.dim() - 1)).to(emb.dtype)
 
+    def _run_embedders(self, batch: dict) -> list:
+        """Every embedder's output, in order.  The frozen text towers are chains of small launches (308 rows: a few dozen tiles each) that
+        leave most of the chip idle, and they do not depend on each other: with NK_TE_OVERLAP != 0 (default) every second frozen embedder that has
+        weights runs on a side stream beside the previous one and is joined before the outputs are routed."""
+        import os
+
+        heavy = [i for i, m in enumerate(self.embedders) if not m.is_trainable and any(p.is_cuda for p in m.parameters())]
+        from ...graphs import graphs_enabled
+
+        # (not when the towers are replayed from hipGraphs, NK_GRAPH=1 / "te": a replay belongs to the stream it was captured on)
+        on_side = set(heavy[0::2]) if len(heavy) >= 2 and os.environ.get("NK_TE_OVERLAP", "1") != "0" and not graphs_enabled("te") else set()
+        outs, side = [], None
+        if on_side:
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(torch.cuda.current_stream())
+        for i, model in enumerate(self.embedders):
+            args = self._gather(model, batch)
+            with model.context():
+                if i in on_side:
+                    with torch.cuda.stream(side):
+                        produced = model(*args)
+                else:
+                    produced = model(*args)
+            outs.append(produced)
+        if on_side:
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            for i in on_side:
+                for t in ((outs[i],) if torch.is_tensor(outs[i]) else outs[i]):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)         # allocated on the side stream, consumed on this one
+        return outs
+
     def forward(self, batch: dict, force_zero_embeddings: Optional[list] = None) -> dict:
         zeroed = set(force_zero_embeddings or ())
         cond: dict[str, Tensor] = {}
-        for model in self.embedders:
-            with model.context():
-                produced = model(*self._gather(model, batch))
+        for model, produced in zip(self.embedders, self._run_embedders(batch)):
             if torch.is_tensor(produced):
                 produced = (produced,)
             elif not isinstance(produced, (list, tuple)):
