@@ -142,21 +142,14 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_wgrad_halo_kernel(const NkG
   }
   const wh_lds sm = (wh_lds)smem;
 
-  // rotated pixel order (OpG2::rotate in gemm_g2.h has the why): every workgroup of a pixel range walks the same tiles, the blocks that share a
-  // dy or an x slice sit on different XCDs -- started an eighth of the range apart per XCD they stop asking for the same lines at the same moment
-  const int nt = t1 - t0;
-  const int r0 = (p.k_rotate && nt >= 8) ? (int)(((blockIdx.x & 7) * (unsigned)nt) >> 3) : 0;
   WhStager stg;
-  stg.init(p, t0 < t1 ? t0 + r0 : 0, txn, tyn, lane);
+  stg.init(p, t0 < t1 ? t0 : 0, txn, tyn, lane);
   if (t0 < t1) stg.issue(p, smem, txn, tyn, cb, ib, wave, lane);
-  for (int i = 0; i < nt; ++i) {
-    const int st = i & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the current tile have landed ...
+  for (int t = t0; t < t1; ++t) {
+    const int st = (t - t0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile t have landed ...
     __syncthreads();                                      // ... everyone's have, and everyone is done reading the other stage
-    if (i + 1 < nt) {
-      if (i + 1 == nt - r0) stg.init(p, t0, txn, tyn, lane);      // the rotated order wraps to the start of the range
-      stg.issue(p, smem + (st ^ 1) * WH_STAGE, txn, tyn, cb, ib, wave, lane);
-    }
+    if (t + 1 < t1) stg.issue(p, smem + (st ^ 1) * WH_STAGE, txn, tyn, cb, ib, wave, lane);
     const wh_lds base = sm + st * WH_STAGE;
 #pragma unroll
     for (int kg = 0; kg < 8; ++kg) {                      // k-group: 16 pixels of tile row kg >> 1, columns 16 (kg & 1) ..
@@ -263,7 +256,6 @@ static int launch_wgrad_halo(NkGemmParams& p, hipStream_t stream) {
   }
   p.accumulate = p.accumulate == 1 ? 1 : 0;      // (kernel: 1 = add to what is there; with S > 1 it adds anyway)
   p.ksplit_len = per;
-  p.k_rotate = k_rotate_on(8 * BK) ? 1 : 0;      // (NK_GEMM_KROT; the kernel rotates ranges of at least eight pixel tiles)
   auto kern = p.dbias ? nk_conv3x3_wgrad_halo_kernel<1> : nk_conv3x3_wgrad_halo_kernel<0>;
   nk_optin_lds((const void*)kern, WH_SMEM);
   hipLaunchKernelGGL(kern, dim3((unsigned)(nblk * S)), dim3(512), WH_SMEM, stream, p);
