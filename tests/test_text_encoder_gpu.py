@@ -144,6 +144,30 @@ def test_text_embedders_inside_general_conditioner():
     assert torch.equal(zero["crossattn"][..., :64], out["crossattn"][..., :64])
 
 
+def test_text_towers_on_two_streams_give_the_in_line_result(monkeypatch):
+    """GeneralConditioner runs every second frozen embedder with weights on a side stream (NK_TE_OVERLAP, default on): same kernels on the same
+    data, so the outputs equal the in-line order's bit for bit -- repeatedly, with the consumer reading them right behind the join."""
+    from neurosis_amd.models.text_encoder import FrozenCLIPEmbedder, FrozenOpenCLIPEmbedder2
+    from neurosis_amd.modules.encoders import ConcatTimestepEmbedderND, GeneralConditioner
+
+    fx, hf_sd, oc_sd = _fx()
+    clip_l = FrozenCLIPEmbedder(layer="hidden", layer_idx=3, config=fx["hf_cfg"], input_key="ids_l")
+    clip_l.transformer.load_state_dict(hf_sd)
+    big_g = FrozenOpenCLIPEmbedder2(layer="penultimate", always_return_pooled=True, config=fx["openclip_cfg"], input_key="ids_g")
+    big_g.model.load_state_dict(oc_sd)
+    cond = GeneralConditioner([clip_l, big_g, ConcatTimestepEmbedderND(outdim=32, input_key="original_size_as_tuple")]).cuda()
+    ids = fx["ids"].cuda()
+    batch = {"ids_l": ids, "ids_g": ids, "original_size_as_tuple": torch.tensor([[1024.0, 1024.0]] * 3).cuda()}
+    monkeypatch.setenv("NK_TE_OVERLAP", "0")
+    ref = {k: v.clone() for k, v in cond(batch).items()}
+    assert getattr(cond, "_side_stream", None) is None
+    monkeypatch.setenv("NK_TE_OVERLAP", "1")
+    for _ in range(5):
+        got = {k: v.clone() for k, v in cond(batch).items()}          # (read on the consumer stream right behind the join)
+        assert all(torch.equal(got[k], ref[k]) for k in ref), {k: float((got[k].float() - ref[k].float()).abs().max()) for k in ref}
+    assert cond._side_stream is not None
+
+
 def test_text_without_a_tokenizer_fails_loudly():
     from neurosis_amd.models.text_encoder import FrozenCLIPEmbedder
 
