@@ -94,7 +94,7 @@ class GeneralConditioner(nn.Module):
         weights runs on a side stream beside the previous one and is joined before the outputs are routed."""
         import os
 
-        heavy = [i for i, m in enumerate(self.embedders) if not m.is_trainable and any(p.is_cuda for p in m.parameters())]
+        heavy = [i for i, m in enumerate(self.embedders) if not m.is_trainable and (p0 := next(m.parameters(), None)) is not None and p0.is_cuda]
         from ...graphs import graphs_enabled
 
         # (not when the towers are replayed from hipGraphs, NK_GRAPH=1 / "te": a replay belongs to the stream it was captured on)
