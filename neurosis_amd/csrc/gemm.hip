@@ -833,6 +833,138 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_ring_kernel(const NkGemmParams
   nk_gemm_epilogue<OUT_F32, BM, 512, NJ>(p, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Few-row Linear forward (M <= 512: the frozen text towers' 308 rows, the UNet's time / label embeddings): 64 x 64 tiles, EIGHT-stage ring.
+// Such a launch is a weight-streaming problem run by a few dozen workgroups, and a workgroup's fetch rate is latency x bytes in flight: a
+// 128 x 128 tile moves (128 + 128) x K x 2 bytes through one CU with three 32-KiB slabs in flight (~45 GB/s: 15 us at K = 1280, whatever N is).
+// A 64 x 64 tile halves the bytes per workgroup, quadruples the workgroups (308 x 1280: 100 instead of 30) and, at 16 KiB per slab, keeps SEVEN
+// slabs in flight in the same LDS.  k-contiguous dense operands, bf16 output with the fused bias / row vector / residual; 8 waves as 2 x 4, 32 x 16
+// per wave.  Column tiles are the slow index of the tile order, so the row tiles that share a weight panel are neighbours on one XCD.
+// ---------------------------------------------------------------------------------------------
+#define R64_NS 8
+#define R64_OPND 8192
+#define R64_STAGE (2 * R64_OPND)
+#define R64_SMEM (R64_NS * R64_STAGE)      // 131072
+#define R64_CS_LD 68
+__global__ __launch_bounds__(512, 2) void nk_gemm_ring64_kernel(const NkGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntm = (p.M + 63) >> 6;
+  const int nt = wg / ntm, mt = wg - nt * ntm;
+  const int m0 = mt * 64, n0 = nt * 64;
+  const int kend = p.K, nk = (p.K + BK - 1) / BK;
+
+  OperandDMA<OP_KC, 1> opa, opb;        // 8 waves x 1 piece x 8 rows = 64 rows each
+  opa.init(p.A, p.lda, p.M, m0, tid, p.ga);
+  opb.init(p.B, p.ldb, p.N, n0, tid, p.gb);
+  float4_t acc[2] = {(float4_t){0.f, 0.f, 0.f, 0.f}, (float4_t){0.f, 0.f, 0.f, 0.f}};
+  opa.start(0);
+  opb.start(0);
+#pragma unroll
+  for (int t = 0; t < R64_NS - 1; ++t)
+    if (t < nk) {
+      opa.issue_next(kend, smem + t * R64_STAGE, p.ga, p.tw);
+      opb.issue_next(kend, smem + t * R64_STAGE + R64_OPND, p.gb, p.tw);
+    }
+  int cur_stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // every wave issued 2 pieces per slab, in order: slab kt has landed once at most the pieces of the later slabs remain
+    switch (min(nk - 1 - kt, R64_NS - 2)) {
+      case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();   // slab kt is in LDS for every wave; every wave is done reading stage (kt - 1) % NS
+    const char* cur = smem + cur_stage * R64_STAGE;
+    bf16x8_t af[2][2], bfr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[ks][i] = ring_frag<OP_KC>(cur, wm * 32 + i * 16, ks, lane);
+      bfr[ks] = ring_frag<OP_KC>(cur + R64_OPND, wn * 16, ks, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + R64_NS - 1 < nk) {
+      int ns = cur_stage + R64_NS - 1; if (ns >= R64_NS) ns -= R64_NS;
+      opa.issue_next(kend, smem + ns * R64_STAGE, p.ga, p.tw);
+      opb.issue_next(kend, smem + ns * R64_STAGE + R64_OPND, p.gb, p.tw);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bfr[0]), "+v"(bfr[1]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks], acc[i], 0, 0, 0);
+    if (++cur_stage == R64_NS) cur_stage = 0;
+  }
+  __syncthreads();
+  // ---- epilogue: accumulators -> LDS (fp32, [64][R64_CS_LD]) -> one 16-byte store per thread ----
+  float* cs = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[(wm * 32 + i * 16 + (lane >> 4) * 4 + r) * R64_CS_LD + wn * 16 + (lane & 15)] = acc[i][r];
+  __syncthreads();
+  const int row = tid >> 3, cc = tid & 7;
+  const int m = m0 + row, n = n0 + cc * 8;
+  if (m >= p.M || n >= p.N) return;
+  bf16_t* C = (bf16_t*)p.C;
+  const float4_t c0 = *(const float4_t*)(cs + row * R64_CS_LD + cc * 8), c1 = *(const float4_t*)(cs + row * R64_CS_LD + cc * 8 + 4);
+  float v[8] = {c0[0] * p.alpha, c0[1] * p.alpha, c0[2] * p.alpha, c0[3] * p.alpha, c1[0] * p.alpha, c1[1] * p.alpha, c1[2] * p.alpha, c1[3] * p.alpha};
+  if ((p.N & 7) == 0) {
+    if (p.bias) {
+      const float4_t b0 = *(const float4_t*)(p.bias + n), b1 = *(const float4_t*)(p.bias + n + 4);
+      v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
+      v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
+    }
+    if (p.rowvec) {
+      float t[8];
+      unpack8(*(const uint4_t*)(p.rowvec + (long)fdiv((unsigned)m, p.fRowsPerBatch) * p.ld_rowvec + n), t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += t[e];
+    }
+    if (p.residual) {
+      float t[8];
+      unpack8(*(const uint4_t*)(p.residual + (long)m * p.ldr + n), t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += t[e];
+    }
+    *(uint4_t*)(C + (long)m * p.ldc + n) = pack8(v);
+  } else {
+    for (int e = 0; e < 8 && n + e < p.N; ++e) {
+      float x = v[e];
+      if (p.bias) x += p.bias[n + e];
+      if (p.rowvec) x += bf2f(p.rowvec[(long)fdiv((unsigned)m, p.fRowsPerBatch) * p.ld_rowvec + n + e]);
+      if (p.residual) x += bf2f(p.residual[(long)m * p.ldr + n + e]);
+      C[(long)m * p.ldc + n + e] = f2bf(x);
+    }
+  }
+}
+// NK_GEMM_R64: 0 = never (A/B runs).  Dense k-contiguous bf16-output launches of at most 512 rows whose 128 x 128 grid would leave most CUs idle.
+static bool use_ring64(const NkGemmParams& p, int amode, int bmode, int out_f32) {
+  if (amode != OP_KC || bmode != OP_KC || out_f32 || p.nbatch || p.geglu_u || p.geglu_h || p.stats_part) return false;
+  if (const char* e = getenv("NK_GEMM_R64")) if (e[0] == '0') return false;
+  if (p.M > 512 || p.K < 4 * BK) return false;
+  // one round at one workgroup per CU (the ring takes 128 KiB of LDS): 308 x 1280 -> 100 tiles, x 3072 -> 240; at 308 x 3840 / 5120 (300 / 400
+  // tiles: two rounds) the 128 x 128 kernels are faster again (16.8 / 17.1 against 19.2 / 19.9 us, tools/bench_skinny.py)
+  const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+  return t64 <= 256;
+}
+static int launch_ring64(const NkGemmParams& p, hipStream_t stream) {
+  nk_optin_lds((const void*)nk_gemm_ring64_kernel, R64_SMEM);
+  const unsigned tiles = (unsigned)(((p.M + 63) >> 6) * ((p.N + 63) >> 6));
+  hipLaunchKernelGGL(nk_gemm_ring64_kernel, dim3(tiles), dim3(512), R64_SMEM, stream, p);
+  return nk_check_launch("nk_gemm_ring64_kernel");
+}
+
 // =============================================================================================
 // stream-K main kernel (default).  Measured on the 128x128 data-parallel kernel above: a k-step costs 0.94 us per
 // round of 512 tiles, but every round also pays ~4.5 us of fixed cost (first loads from a cold pipeline, LDS-staged
@@ -1695,6 +1827,7 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
 
   // two-group staggered ring at one workgroup per CU (gemm_g2.h): Linear forward / dgrad / wgrad shapes whose 128 x 160 (or
   // 128 x 128) tiles come out in whole rounds of 256
+  if (use_ring64(p, amode, bmode, out_f32)) return launch_ring64(p, stream);
   if ((!p.nbatch || p.nbatch <= NK_MAX_BATCH) && use_g2(p, amode, bmode, out_f32, 1) && (g2_mode() == 2 || !use_xl(p, amode, bmode, out_f32, 1))) {
     if (p.accumulate == 2) p.accumulate = 0;       // no K split here: "destination known zero" means plain stores
     if (amode == OP_KC && bmode == OP_KC) return out_f32 ? launch_g2<OP_KC, OP_KC, 1>(p, stream) : launch_g2<OP_KC, OP_KC, 0>(p, stream);
