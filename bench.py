@@ -322,7 +322,7 @@ def pmc_traffic():
         return None, None
     n = b = 0.0
     for r in rows:
-        if r[0].startswith("void nk_gemm") or r[0].startswith("void nk_conv3x3_halo"):      # the tile engine's kernel families
+        if r[0].startswith(("void nk_gemm", "nk_gemm", "void nk_conv3x3_halo")):      # the tile engine's kernel families
             n += float(r[1])
             b += float(r[1]) * (float(r[2]) + float(r[3]))
     return (round(b / n), "profiles/" + os.path.basename(path)) if n else (None, None)

@@ -24,6 +24,6 @@ with open(os.path.join(P, f"{R}_pmc_summary.csv"), "w", newline="") as fo:
         o.writerow([k, n, f"{f:.4g}", f"{w:.4g}", f"{d:.0f}" if d else "", f"{(f + w) / d:.0f}" if d else "", f"{u:.3f}" if u is not None else ""])
 for k, n, f, w, d, u in rows[:26]:
     print(f"{k[:58]:58s} n={n:5d} rd={f/1e6:9.1f}MB wr={w/1e6:8.1f}MB dur={(d or 0)/1e3:8.1f}us {((f+w)/d if d else 0):6.0f} GB/s mfma={u if u is not None else -1:.3f}")
-te = lambda r: r[0].startswith("void nk_gemm") or r[0].startswith("void nk_conv3x3_halo")
+te = lambda r: r[0].startswith(("void nk_gemm", "nk_gemm", "void nk_conv3x3_halo"))
 tn = sum(r[1] for r in rows if te(r)); tb = sum(r[1] * (r[2] + r[3]) for r in rows if te(r))
 print("tile engine: launches", tn, "avg HBM bytes/launch %.1f MB" % (tb / tn / 1e6))
