@@ -347,6 +347,23 @@ def test_attention(ops, B, H, Lq, Lk, D):
     assert_close(dv, vr.grad, TOL_BF16, "attn dv")
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,D", [(3, 7, 1000, 1000, 64), (2, 5, 260, 77, 64), (4, 20, 1024, 1024, 64), (2, 3, 130, 300, 40), (1, 11, 200, 200, 160)])
+def test_attention_workgroup_order_is_only_an_order(ops, B, H, Lq, Lk, D, monkeypatch):
+    """The attention launches are 1-D grids mapped XCD-aware (csrc/attention.hip attn_wg: every XCD owns a contiguous range of (batch, head,
+    block), so that the blocks of a head share one L2); NK_ATTN_XCD=0 keeps the 3-D grid.  Every workgroup computes what it computed before:
+    forward and all three gradients agree BIT FOR BIT between the two orders -- grids that are and are not multiples of eight, ragged last
+    blocks, the one-kernel cross-attention backward, the generic head dims."""
+    q, k, v, do = rnd(B * Lq, H * D), rnd(B * Lk, H * D, seed=5), rnd(B * Lk, H * D, seed=6), rnd(B * Lq, H * D, seed=9)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NK_ATTN_XCD", mode)          # read per launch
+        o, bwd = ops.attention_fwd(dev(q), dev(k), dev(v), B, H, D)
+        res[mode] = (o.clone(),) + tuple(t.clone() for t in bwd(dev(do)))
+    for a, b, name in zip(res["1"], res["0"], ("o", "dq", "dk", "dv")):      # (the query splits of the dK / dV kernel meet in a fixed-order reduce)
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+    assert_close(res["1"][0], _attn_ref(q, k, v, B, H, D), TOL_BF16, "attn fwd, XCD-aware order")
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 64, 16), (2, 3, 96, 96), (1, 4, 520, 77), (2, 2, 33, 3), (4, 20, 1024, 77), (1, 1, 4100, 80)])
 def test_attention_backward_in_one_kernel_for_few_keys(ops, B, H, Lq, Lk, monkeypatch):
     """Head dim 64 with at most 96 keys (the UNet's cross-attention: 77 tokens) runs its whole backward in one kernel (csrc/attention.hip,
