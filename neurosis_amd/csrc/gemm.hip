@@ -1002,11 +1002,26 @@ __device__ __forceinline__ void sk_decode(const NkGemmParams& p, int t, int ntm,
   n0 = nt * BN;
 }
 
+// The residual's chunks a lane will add in reg_epilogue_64x32 (same row / column arithmetic), fetched BEFORE the k loop by kernels whose waves
+// have the registers: the epilogue of a 20-k-step launch otherwise starts with a round trip to memory (bf16 output, N % 8 == 0 only).
+template <int MI>
+__device__ __forceinline__ void residual_prefetch_64x32(const NkGemmParams& p, uint4_t (&r)[MI], int mbase, int nbase, int lane) {
+  const int g = lane >> 4;
+  const int n = nbase + (g & 1) * 16 + (g >> 1) * 8;
+  const int mrow = mbase + (lane & 15);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mrow + i * 16;
+    r[i] = (n < p.N && m < p.M) ? *(const uint4_t*)(p.residual + (long)m * p.ldr + n) : (uint4_t){0u, 0u, 0u, 0u};
+  }
+}
+
 // accumulators -> global, fused bias / rowvec / residual.  acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)]
 //                                                                           [n0 + wn*32 + j*16 + (lane>>4)*4 + r]
 template <int OUT_F32, int MI = 4>     // MI 16-row blocks x one pair of 16-column blocks
 __device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI][2], int mbase, int nbase, int lane,
-                                                   int mlimit = -1) {   // mlimit >= 0: rows at or past it are not stored (instead of p.M)
+                                                   int mlimit,          // mlimit >= 0: rows at or past it are not stored (instead of p.M)
+                                                   const uint4_t (&pre_res)[MI], bool use_pre) {   // use_pre (wave-uniform): the residual's chunks were fetched by the caller (residual_prefetch_64x32)
   const int Mrows = mlimit >= 0 ? mlimit : p.M;
   const int g = lane >> 4;
   // after the row swap: lanes g=0 hold columns 0-7 of the wave's 32, g=1 16-23, g=2 8-15, g=3 24-31
@@ -1064,7 +1079,7 @@ __device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* 
         }
         if (p.residual) {
           float t[8];
-          unpack8(*(const uint4_t*)(p.residual + (long)m * p.ldr + n), t);
+          unpack8(use_pre ? pre_res[i] : *(const uint4_t*)(p.residual + (long)m * p.ldr + n), t);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t[e];
         }
@@ -1079,6 +1094,12 @@ __device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* 
       }
     }
   }
+}
+template <int OUT_F32, int MI = 4>
+__device__ __forceinline__ void reg_epilogue_64x32(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI][2], int mbase, int nbase, int lane,
+                                                   int mlimit = -1) {
+  const uint4_t none[MI] = {};
+  reg_epilogue_64x32<OUT_F32, MI>(p, Cv, acc, mbase, nbase, lane, mlimit, none, false);
 }
 template <int OUT_F32>
 __device__ __forceinline__ void sk_epilogue(const NkGemmParams& p, void* Cv, float4_t (&acc)[4][2], int m0, int n0, int lane,

@@ -261,10 +261,20 @@ __device__ __forceinline__ void g2_read(bf16x8_t (&f)[2 * NF], const FragG2<MODE
   }
 }
 
+template <int MI>
+__device__ __forceinline__ void residual_prefetch_col16(const NkGemmParams& p, uint2_t (&r)[MI], int mbase, int nbase, int lane) {
+  const int n = nbase + (lane >> 4) * 4;
+  const int mrow = mbase + (lane & 15);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mrow + i * 16;
+    r[i] = (n < p.N && m < p.M) ? *(const uint2_t*)(p.residual + (long)m * p.ldr + n) : (uint2_t){0u, 0u};
+  }
+}
 // a lone 16-column block of the wave tile (the fifth of the 80-column half): the lane holds 4 consecutive columns of one row
 template <int OUT_F32, int MI>
 __device__ __forceinline__ void reg_epilogue_col16(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI], int mbase, int nbase, int lane,
-                                                   int mlimit = -1) {
+                                                   int mlimit, const uint2_t (&pre_res)[MI], bool use_pre) {      // pre_res: residual_prefetch_col16
   const int Mrows = mlimit >= 0 ? mlimit : p.M;
   const int n = nbase + (lane >> 4) * 4;
   const int mrow = mbase + (lane & 15);
@@ -294,7 +304,7 @@ __device__ __forceinline__ void reg_epilogue_col16(const NkGemmParams& p, void* 
         }
         if (p.residual) {
           float t[4];
-          unpack4(*(const uint2_t*)(p.residual + (long)m * p.ldr + n), t);
+          unpack4(use_pre ? pre_res[i] : *(const uint2_t*)(p.residual + (long)m * p.ldr + n), t);
           v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
         }
         uint2_t o;
@@ -312,6 +322,11 @@ __device__ __forceinline__ void reg_epilogue_col16(const NkGemmParams& p, void* 
       }
     }
   }
+}
+template <int OUT_F32, int MI>
+__device__ __forceinline__ void reg_epilogue_col16(const NkGemmParams& p, void* Cv, float4_t (&acc)[MI], int mbase, int nbase, int lane, int mlimit = -1) {
+  const uint2_t none[MI] = {};
+  reg_epilogue_col16<OUT_F32, MI>(p, Cv, acc, mbase, nbase, lane, mlimit, none, false);
 }
 
 template <int AMODE, int BMODE, int OUT_F32, int BN_>
@@ -558,6 +573,20 @@ __global__ __launch_bounds__(768, 1) void nk_gemm_g2p_kernel(const NkGemmParams 
   const bool do_bias = CAN_BIAS && dbias != nullptr && nt == 0;
   float4_t accb = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+  // the residual of the epilogue (attention / FeedForward output projections, gradient joins) is fetched here, under the whole k loop: the compute
+  // waves issue no other global loads, and the epilogue of a 20-k-step launch would otherwise begin with a round trip to memory
+  const int mb = m0 + wq * 32, nb = n0 + grp * HN;
+  uint4_t pre_r[NJ / 2][2];
+  uint2_t pre_r16[2];
+  const bool pre = !OUT_F32 && p.residual != nullptr && (p.N & 7) == 0 && (p.ldr & 7) == 0 && !p.nbatch;
+  if constexpr (!OUT_F32) {
+    if (pre) {
+#pragma unroll
+      for (int half = 0; half < NJ / 2; ++half) residual_prefetch_64x32<2>(p, pre_r[half], mb, nb + half * 32, lane);
+      if constexpr (NJ & 1) residual_prefetch_col16<2>(p, pre_r16, mb, nb + (NJ - 1) * 16, lane);
+    }
+  }
+
   G2_BAR();
   if (grp == 1) { G2_BAR(); }                                       // the second group runs one barrier behind
   unsigned so = 0;
@@ -596,7 +625,6 @@ __global__ __launch_bounds__(768, 1) void nk_gemm_g2p_kernel(const NkGemmParams 
   if (grp == 0) { G2_BAR(); }
 #undef G2_BAR
 
-  const int mb = m0 + wq * 32, nb = n0 + grp * HN;
   if constexpr (CAN_BIAS) {
     if (do_bias && lane < 16) {
       const int m = mb + grp * 16 + lane;
@@ -608,11 +636,11 @@ __global__ __launch_bounds__(768, 1) void nk_gemm_g2p_kernel(const NkGemmParams 
     float4_t pair[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { pair[i][0] = acc[i][2 * half]; pair[i][1] = acc[i][2 * half + 1]; }
-    reg_epilogue_64x32<OUT_F32, 2>(p, Cp, pair, mb, nb + half * 32, lane);
+    reg_epilogue_64x32<OUT_F32, 2>(p, Cp, pair, mb, nb + half * 32, lane, -1, pre_r[half], pre);
   }
   if constexpr (NJ & 1) {
     float4_t last[2] = {acc[0][NJ - 1], acc[1][NJ - 1]};
-    reg_epilogue_col16<OUT_F32, 2>(p, Cp, last, mb, nb + (NJ - 1) * 16, lane);
+    reg_epilogue_col16<OUT_F32, 2>(p, Cp, last, mb, nb + (NJ - 1) * 16, lane, -1, pre_r16, pre);
   }
 }
 
