@@ -262,15 +262,33 @@ class DiffusionEngine(nn.Module):
 
     def training_step(self, batch: dict, batch_idx: int = 0, **inject) -> Tensor:
         """models/diffusion.py:205-233.  `inject` may carry sigmas= / noise=.
-        (Measured: issuing the frozen conditioner on a second stream beside the VAE encoder does not shorten the step -- its
-        ~480 dependent launches take as long squeezed between the encoder's full-chip grids as they do alone, 5 ms -- and a
-        high-priority stream makes the encoder slower by more than that; it runs in line.  Round 3: running it BEFORE the encoder, so that the
-        previous step's optimizer overlaps a launch-bound stretch instead of the encoder's convolutions, does not move the step either:
-        170.3 vs 170.5 ms.)"""
+        The frozen conditioner runs on a side stream BESIDE the frozen VAE encoder and is joined before the UNet (NK_COND_OVERLAP=0: in line,
+        as the reference orders them): its towers are chains of small launches that leave most of the chip idle.  Steady-state step -1.0 ms
+        (p50 152.9 vs 153.9, two alternating pairs on one box).  Round 3 had measured nothing for the same idea -- then the towers ran one
+        after the other (5 ms of dependent launches squeezed between the encoder's grids); now they run beside each other as well
+        (GeneralConditioner, NK_TE_OVERLAP) and the chain is short enough to hide.  Not when the towers or the encoder are replayed from
+        hipGraphs (a replay belongs to the stream it was captured on)."""
         inputs = self.get_input(batch)
-        latents = self.encode_first_stage(inputs)
+        cond = None
+        from ..graphs import graphs_enabled
+
+        if os.environ.get("NK_COND_OVERLAP", "1") != "0" and inputs.is_cuda and not (graphs_enabled("te") or graphs_enabled("vae")):
+            main = torch.cuda.current_stream()
+            if getattr(self, "_cond_stream", None) is None:
+                self._cond_stream = torch.cuda.Stream(device=inputs.device)
+            side = self._cond_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cond = self.conditioner(batch)
+            latents = self.encode_first_stage(inputs)
+            main.wait_stream(side)
+            for t in cond.values():
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+        else:
+            latents = self.encode_first_stage(inputs)
         batch["global_step"] = self.global_step
-        loss = self(latents, batch, return_dict=False, **inject)
+        loss = self(latents, batch, return_dict=False, cond=cond, **inject)
         self.last_log = {"train/loss": loss.detach().mean(), "train/loss_s0": loss.detach()[0]}
         return loss.mean()
 

@@ -98,6 +98,26 @@ def test_engine_methods_match_the_reference_engine():
     check_grad_cosines("reference engine training_step", named, e["grads"], floor_matrix=0.996, floor_vector=0.996, keep=lambda k, g: float(g.norm()) > 1e-6)
 
 
+def test_conditioner_beside_the_vae_encoder_gives_the_in_line_loss(monkeypatch):
+    """training_step runs the frozen conditioner on a side stream beside the frozen VAE encoder (NK_COND_OVERLAP, default on) and joins it before
+    the UNet: same kernels on the same data -- the loss and every gradient equal the in-line order's bit for bit, step after step."""
+    e = load_fixture("engine_tiny")
+    batch = lambda: {"image": e["image"].cuda(), "crossattn": e["crossattn"].cuda(), "vector": e["vector"].cuda()}
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NK_COND_OVERLAP", mode)
+        eng = _engine()
+        losses = []
+        for _ in range(3):
+            loss = eng.training_step(batch(), 0, sigmas=e["sigma"].cuda(), noise=e["noise"].cuda())
+            loss.backward()
+            torch.cuda.synchronize()
+            losses.append(loss.detach().clone())
+        res[mode] = (losses, eng.store.grad.clone())
+        assert (getattr(eng, "_cond_stream", None) is not None) == (mode == "1")
+    assert all(torch.equal(a, b) for a, b in zip(res["0"][0], res["1"][0])) and torch.equal(res["0"][1], res["1"][1])
+
+
 def test_optimizer_and_ema_state_survive_a_checkpoint_round_trip():
     """Adafactor's factored second moments / step count and the EMA shadow are training state.  Two steps, save
     (engine.state_dict + optimizer.state_dict), load into a fresh engine, third step on both: bitwise equal parameters,
