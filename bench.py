@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- SDXL training-step throughput on MI355X (BASELINE.json metric: train images/sec).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts N fresh rank processes itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): SDXL-base UNet (2.567 B parameters, random init), 1024x1024 synthetic
@@ -328,7 +328,31 @@ def pmc_traffic():
     return (round(b / n), "profiles/" + os.path.basename(path)) if n else (None, None)
 
 
-def main():
+def launch_ranks(args, argv, runner=None):
+    """`python bench.py --gpus N` from a bare shell (N > 1, no WORLD_SIZE in the environment): start N FRESH child processes, one rank per
+    GPU, through torch.distributed.run on 127.0.0.1 and return their exit code; rank 0's JSON line reaches stdout through the inherited pipe.
+    Runs BEFORE this process makes any GPU call (a process that has initialised HIP must never be replaced or forked into ranks), and the
+    children are ordinary subprocesses, not an exec.  Returns None when this process is itself a rank (or N = 1).
+    Replaces the Lightning launcher of the reference's `trainer: devices: N` (/root/reference/configs/sdxl/sdxl.example.yaml:3-15)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    assert not torch.cuda.is_initialized(), "the rank launcher must run before any GPU call"
+    import socket
+    import subprocess
+
+    with socket.socket() as s:      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return (runner or subprocess.run)(cmd, env=env).returncode
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -364,13 +388,21 @@ def main():
                     help="N > 1: allreduce = flat all-reduce of every gradient slice, the whole optimizer on every rank (default, what Lightning DDP does); "
                          "rs_ag = every slice reduce-scattered into tensor-aligned parts, optimizer on the owned parts, bf16 shadows all-gathered (neurosis_amd/dp.py)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    rc = launch_ranks(args, argv)
+    if rc is not None:
+        raise SystemExit(rc)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one process per GPU (python bench.py --gpus N does it itself)")
     if args.share_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -589,23 +621,27 @@ def main():
     if world > 1:
         dist.barrier()
 
+    steady_peak = torch.cuda.max_memory_allocated()
+    if world > 1 or forced:
+        # every collective is behind us: the group is taken down BEFORE rank 0 spends ~10 s on the CPU baseline, so that no rank sits in a
+        # collective (or its watchdog) while another one is busy on the host
+        dist.destroy_process_group()
     if rank == 0:
-        cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline()
+        cpu = None if args.no_cpu_baseline else cpu_baseline()
         out = {
             "metric": "train images/sec (node) SDXL 1024^2", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SDXL-base {'mixed-res buckets (~1024^2 pixels)' if args.mixed_res else str(args.res) + '^2'} bf16, batch/GPU={args.batch}, UNet fwd+bwd + frozen VAE encode + {'Adafactor' if args.optimizer == 'adafactor' else 'AdamW'} step, {'frozen TE outputs synthetic' if args.precomputed_te else 'frozen CLIP-L + OpenCLIP-bigG conditioner on synthetic token ids'}",
                        "global_batch": args.batch * world * args.accumulate, "parallelism": f"dp{world}" + (" (exchange forced through RCCL at world 1: NK_DP_FORCE)" if forced else ""), "allreduce_dtype": args.wire_dtype, "activation_checkpointing": False if args.recompute == "none" else f"selective ({args.recompute})", "accumulate_grad_batches": args.accumulate},
-            "loss": round(loss_val, 5), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "max_mem_setup_gb": round(setup_peak / 2**30, 1),
+            "loss": round(loss_val, 5), "max_mem_gb": round(max(steady_peak, setup_peak) / 2**30, 1), "max_mem_steady_gb": round(steady_peak / 2**30, 1),
+            "max_mem_setup_gb": round(setup_peak / 2**30, 1),
             "step_ms_p50": round(pct(0.5), 2), "step_ms_p90": round(pct(0.9), 2), "step_ms_in_order": [round(t, 1) for t in in_order], "comm": comm,
             "host": {"unet_chain": "hipGraph replay" if priming else "eager launches", "graph_priming_steps": priming},
             "stream_k_fixup_timeouts": lib.query("nk_gemm_sk_status"),   # 0: every K-split tile was joined (gemm.hip)
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1 or forced:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

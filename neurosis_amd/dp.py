@@ -157,7 +157,11 @@ class SlicePlan:
             else:
                 lo_cap = mid + 1
         idx = fill(lo_cap)
-        idx += [len(spans)] * (world + 1 - len(idx))       # ranks past the last run own nothing of this slice
+        # ranks past the last run own nothing of this slice.  That only happens for slices with fewer tensors than ranks -- SDXL's time_embed,
+        # label_emb, input_blocks.0 and out heads: 14 tensors, 10 M of 2 567 M elements -- so the low ranks' extra optimizer work is < 0.4 %;
+        # every other block has hundreds of tensors and min-max parts.  (Rotating the first owner per slice would cost the equal-parts fast
+        # path of _reduce_scatter / after_optimizer_step, which needs part r in row r.)
+        idx += [len(spans)] * (world + 1 - len(idx))
         self.lo, self.hi = lo, hi
         self.tcuts = [t0 + i for i in idx]
         self.cuts = [ends[i] for i in idx]
@@ -207,10 +211,11 @@ class FlatDataParallel:
         self.world = self.reducer.world
         self.rank = self.reducer.rank
         self.sync = True
+        self.masters_whole = True           # rs_ag: False from the first sharded update until sync_masters() has run on every rank
         self._optimizers = []
         self._health = None
         if broadcast_params and self.reducer.active:
-            dist.broadcast(store.master, src=0, group=group)
+            dist.broadcast(store.master, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             store.refresh()
         unet.grad_ready_hook = self._on_block_done
         try:
@@ -256,7 +261,11 @@ class FlatDataParallel:
     def _staging(self, name: str, n: int, dtype) -> Tensor:
         buf = self._stage.get(name)
         if buf is None or buf.numel() < n or buf.dtype != dtype:
-            grow = max(n, max((pl.row for pl in self.plans.values()), default=0) * (self.world if name.endswith("_all") else 1))
+            # the slice staging rows (rs_* / ag_*) are sized once for the largest slice; the master-vector gather (vec_*) is ~0.1 % of the
+            # elements and is sized by what it holds (it used to inherit the > 1 GB slice size)
+            grow = n
+            if name.startswith(("rs_", "ag_")):
+                grow = max(n, max((pl.row for pl in self.plans.values()), default=0) * (self.world if name.endswith("_all") else 1))
             buf = self._stage[name] = torch.empty(grow, dtype=dtype, device=self.store.grad.device)
         return buf[:n]
 
@@ -351,6 +360,7 @@ class FlatDataParallel:
         the CURRENT stream: call it where the optimizer kernels were issued (DiffusionEngine.optimizer_step does, on its optimizer stream)."""
         if not self.sharded:
             return
+        self.masters_whole = self.world == 1
         sh, W, me = self.store.shadow, self.world, self.rank
         for plan in self.plans.values():
             row = plan.row
@@ -396,6 +406,7 @@ class FlatDataParallel:
                         dist.broadcast(o.state[sa:sb], src=src, group=self.group)
         for o in self.store.listeners:
             o.masters_changed()
+        self.masters_whole = True
 
 
 def _top_block_ranges(unet, store) -> list:

@@ -293,7 +293,11 @@ class ChainGraphs:
         side = st.wgrad_stream
         main = torch.cuda.current_stream()
         hook = self.hook()
-        balance = side is not None and hook is None and os.environ.get("NK_TAIL_BALANCE", "1") != "0"
+        # (the stream-K workspace -- flags, tile counter, partial tiles -- is keyed by the launch stream AT CAPTURE TIME and baked into the W
+        # graphs: two of them replayed at once would share it.  The default NK_GEMM_SK=4 never gives an fp32 weight gradient to stream-K; under
+        # the A/B settings 1 / 2 / 3 it may, so those run without tail balancing: ADVICE round 4)
+        balance = (side is not None and hook is None and os.environ.get("NK_TAIL_BALANCE", "1") != "0"
+                   and os.environ.get("NK_GEMM_SK", "4") in ("0", "4"))
         pair.bwd_replays += 1
         if balance and pair.tail is None and pair.cal is not None and pair.cal["done"].query():
             pair.tail = self._plan_tail(pair.cal)

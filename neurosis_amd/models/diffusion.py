@@ -385,13 +385,23 @@ class DiffusionEngine(nn.Module):
 
     def state_dict(self, *args, **kwargs):
         """Parameters as the reference's keys name them.  Under the sharded data-parallel exchange (dp.FlatDataParallel, mode rs_ag) the
-        fp32 masters of the other ranks' parts are stale between checkpoints: they (and the optimizer statistics) are gathered HERE, before
-        the tensors are collected -- a collective, so every rank must call state_dict() together (Lightning's dump_checkpoint does)."""
+        fp32 masters of the other ranks' parts are stale between checkpoints.  Gathering them is a COLLECTIVE (dp.sync_masters()), and a
+        state_dict() call is often rank-local (`if rank == 0: torch.save(engine.state_dict())`, EMA / log_images tooling): an implicit
+        collective here would deadlock those.  So this never communicates: it raises unless the masters are whole --
+        call `engine.sync_masters()` on EVERY rank first (trainer.lightning's on_save_checkpoint does)."""
+        self.join_optimizer()
+        dp = getattr(getattr(self, "store", None), "dp", None)
+        if dp is not None and dp.sharded and not dp.masters_whole:
+            raise RuntimeError("DiffusionEngine.state_dict(): the fp32 masters are sharded over the ranks (NK_DP_MODE=rs_ag) and stale for foreign "
+                               "parts; call engine.sync_masters() on every rank before any rank reads the state dict")
+        return super().state_dict(*args, **kwargs)
+
+    def sync_masters(self) -> None:
+        """rs_ag: make every rank's fp32 masters and optimizer statistics whole (a collective: all ranks).  No-op otherwise."""
         self.join_optimizer()
         dp = getattr(getattr(self, "store", None), "dp", None)
         if dp is not None and dp.sharded:
             dp.sync_masters()
-        return super().state_dict(*args, **kwargs)
 
     # -- sampling (SURVEY 8(f) N4) -------------------------------------------------------------------
     @contextmanager

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import weakref
 from dataclasses import dataclass
 from typing import Callable, Optional
@@ -113,21 +114,24 @@ def wgrad_mode(p=None) -> int:
 # Whether the forward now running will be followed by a backward (its closures are kept).  torch.is_grad_enabled() cannot answer that
 # inside the autograd bridge: torch.autograd.Function.forward always runs with grad mode off.  nn.NkFunction.forward raises the flag around
 # `run`; the activation-dropping policies (ResBlock.use_checkpoint, BasicTransformerBlock.checkpoint / .recompute) read it.
-_recording = 0
+# The flag is per THREAD: a validation or data-loader thread that runs a forward of its own must not see the training thread's.
+# Callers that drive `module.fwd(...)` and the returned closure themselves (outside nn.NkFunction) and want the checkpoint / recompute
+# policies honoured wrap the forward in `with ops.recording_backward():` -- without it the blocks keep their activations (correct, not lean).
+_recording = threading.local()
 
 
 class recording_backward:
+    """`with ops.recording_backward():` -- the forward launched inside will be followed by a backward through its closure."""
+
     def __enter__(self):
-        global _recording
-        _recording += 1
+        _recording.depth = getattr(_recording, "depth", 0) + 1
 
     def __exit__(self, *exc):
-        global _recording
-        _recording -= 1
+        _recording.depth -= 1
 
 
 def recording() -> bool:
-    return _recording > 0
+    return getattr(_recording, "depth", 0) > 0
 
 
 def on_wgrad_stream(fn: Callable[[], None], *reads: Tensor, owner=None) -> None:

@@ -130,9 +130,16 @@ class DiffusionEngineMI355X(_Base):
         return None
 
     # -- checkpoints: the reference's state_dict keys live under `engine.`; optimizer state rides along ------------------
+    def state_dict(self, *args, **kwargs):
+        """Lightning's dump_checkpoint calls this on EVERY rank (only rank 0 writes the file), which is what makes the collective safe here
+        and nowhere deeper: under rs_ag the sharded masters / optimizer statistics are made whole first (engine.state_dict() itself never
+        communicates)."""
+        self.engine.sync_masters()
+        return super().state_dict(*args, **kwargs)
+
     def on_save_checkpoint(self, checkpoint: dict) -> None:
         self.engine.join_optimizer()
-        # (rs_ag: DiffusionEngine.state_dict() has already made every rank's masters and optimizer statistics whole -- Lightning builds the
+        # (rs_ag: state_dict() above has already made every rank's masters and optimizer statistics whole -- Lightning builds the
         # module's state_dict before this hook runs -- so what is saved below is complete whether or not the tensors alias the flat buffers)
         opt = self.engine._torch_optimizer
         if opt is not None:

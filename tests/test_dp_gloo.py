@@ -162,7 +162,11 @@ def _worker_sharded(rank, world, port, out):
         shadows_before_sync = store.shadow.clone()
         # the 1-D parameters, which kernels read as fp32 masters, must be current on every rank BEFORE any sync_masters()
         vec_before_sync = torch.cat([store.master[offsets[t]:offsets[t] + sizes[t]] for t in vectors]).clone()
+        # masters_whole: what DiffusionEngine.state_dict() consults instead of communicating (a rank-local state_dict() must not deadlock)
+        whole_flags = [dp.masters_whole]
         dp.sync_masters()
+        whole_flags.append(dp.masters_whole)
+        ok_plan = ok_plan and whole_flags == ([False, True] if mode == "rs_ag" else [True, True])
         results[mode] = (store.master.clone(), shadows_before_sync, dp.sharded, dp.reducer.take_counts(), opt.state.clone(), vec_before_sync, owned)
     # (two ranks: a + b has one order -> bit-equal; three: the ring all-reduce and the reduce-scatter add in different orders -> fp32 rounding)
     same = torch.equal if world == 2 else (lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-6))

@@ -374,3 +374,24 @@ def test_health_word_is_merged_over_the_ranks():
     mp.spawn(_worker_health, args=(world, _free_port(), out), nprocs=world, join=True)
     for r in range(world):
         assert out[r]["status"] == 1 and out[r]["unchanged"], (r, out[r])
+
+
+def test_bench_two_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver starts the scaling bench): the parent starts two fresh
+    rank processes before it touches the GPU, rank 0's line comes back with comm.world_size 2 AND the cpu_baseline object (rounds 1-4
+    dropped it at N > 1), exit code 0.  Both ranks share cuda:0 over gloo -- the control flow of the metric's command at a reduced image size
+    (the UNet is the benchmark's own 2.57 B-parameter network)."""
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "0",
+                        "--res", "512", "--batch", "1", "--precomputed-te", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["comm"]["world_size"] == 2 and out["config"]["global_batch"] == 2
+    assert out["cpu_baseline"] is not None and out["cpu_baseline"]["value"], out["cpu_baseline"]
+    assert out["value"] > 0 and out["scaling"] == "weak"

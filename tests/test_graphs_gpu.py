@@ -92,10 +92,15 @@ def test_graph_replay_reproduces_the_eager_chain_bit_for_bit():
     assert torch.equal(got, want) and torch.equal(got_e, want), (got.tolist(), got_e.tolist(), want.tolist())
 
 
-def test_tail_weight_gradient_graphs_may_replay_on_the_main_stream():
+@pytest.mark.parametrize("sk", [None, "2"])
+def test_tail_weight_gradient_graphs_may_replay_on_the_main_stream(sk, monkeypatch):
     """ChainGraphs._replay_backward shares the W graphs that start behind the end of the main chain out between both streams (measured once,
     by events).  Here the plan is FORCED to every W graph of the second half of the backward: same kernels, same arguments, so the gradients
-    must equal the eager chain's, and the W graphs have pools of their own (two of them run at once)."""
+    must equal the eager chain's, and the W graphs have pools of their own (two of them run at once).
+    sk = "2" (ADVICE round 4): NK_GEMM_SK=2 sends fp32 weight gradients to the stream-K kernel, whose workspace is keyed by the capture
+    stream -- two W graphs at once would share it, so the replay must IGNORE the plan under that switch; the gradients stay right."""
+    if sk is not None:
+        monkeypatch.setenv("NK_GEMM_SK", sk)
     batches = _batches(6)
     _, loss_e, grad_e = _steps(batches, graph=False)
     os.environ["NK_GRAPH"] = "1"

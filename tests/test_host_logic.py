@@ -156,3 +156,22 @@ def test_sharded_exchange_plan_on_the_full_size_unet():
           f"largest / smallest share of the optimizer = {max(per_rank) / total:.4f} / {min(per_rank) / total:.4f}")
     assert staged <= 1.16 * total, staged / total
     assert max(per_rank) <= 1.15 * total / world, max(per_rank) * world / total
+
+
+def test_state_dict_never_communicates_under_the_sharded_exchange():
+    """`if rank == 0: torch.save(engine.state_dict())` must not hang in a hidden collective.  With sharded (rs_ag) masters
+    that are not whole the call raises and names the fix; sync_masters() is the explicit, all-rank collective."""
+    from types import SimpleNamespace
+
+    import pytest
+
+    from neurosis_amd.models.diffusion import DiffusionEngine
+
+    calls = []
+    dp = SimpleNamespace(sharded=True, masters_whole=False, sync_masters=lambda: calls.append("sync"))
+    eng = SimpleNamespace(join_optimizer=lambda: calls.append("join"), store=SimpleNamespace(dp=dp))
+    with pytest.raises(RuntimeError, match="sync_masters"):
+        DiffusionEngine.state_dict(eng)
+    assert "sync" not in calls
+    DiffusionEngine.sync_masters(eng)
+    assert calls[-1] == "sync"
