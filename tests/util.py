@@ -16,8 +16,9 @@ def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
 
 
 def cosine(got: torch.Tensor, ref: torch.Tensor) -> float:
-    got = got.detach().float().cpu().reshape(-1)
-    ref = ref.detach().float().cpu().reshape(-1)
+    # fp64: an fp32 dot / norm over 10^7 elements is itself off by ~1e-3 (the full-depth SDXL test read cosines of 1.0019)
+    got = got.detach().cpu().reshape(-1).double()
+    ref = ref.detach().cpu().reshape(-1).double()
     return float(torch.dot(got, ref) / (got.norm() * ref.norm()).clamp_min(1e-30))
 
 
