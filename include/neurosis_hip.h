@@ -195,6 +195,24 @@ int nk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
 long nk_layernorm_ws_floats(int M, int C);
 int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                      const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws, int M, int C, int accumulate, void* stream);
+/* The one-pass form in its two halves (round 5: what the transformer blocks use): _rows writes dx and nk_layernorm_part_rows(M) partial rows
+ * [rows][2][C] (sum dy * xhat | sum dy over the rows each workgroup walked) into `part`; nk_colpart_reduce_batch sums the partial rows of up to
+ * NK_COLPART_MAX such launches into their dgamma / dbeta in ONE launch, on any stream, any time later (the three LayerNorms of a
+ * BasicTransformerBlock, attention.py:487-511, are reduced behind the block's batched weight gradients). */
+#define NK_COLPART_MAX 32
+typedef struct NkColpartBatch {
+  const float* part[NK_COLPART_MAX];
+  float* dgamma[NK_COLPART_MAX];
+  float* dbeta[NK_COLPART_MAX];
+  int nrows[NK_COLPART_MAX];
+  int C[NK_COLPART_MAX];
+  int accumulate[NK_COLPART_MAX];     /* 0: overwrite dgamma / dbeta, 1: add to them */
+  int n;
+} NkColpartBatch;
+long nk_layernorm_part_rows(int M);
+int nk_layernorm_bwd_rows(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                          const void* dx_add, void* dx, float* part, int M, int C, void* stream);
+int nk_colpart_reduce_batch(const NkColpartBatch* b, void* stream);
 /* The same in two parts, so the caller can run the parameter gradients (off the critical path of backward) on another
  * stream: _dx needs no workspace; _params reads dy, x and the saved statistics only. */
 int nk_layernorm_bwd_dx(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,

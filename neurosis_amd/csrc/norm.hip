@@ -662,24 +662,26 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const bf16_t* __restr
 
 static int ln_param_split(int M) { return (M + LNP_ROWS - 1) / LNP_ROWS; }
 
-// LayerNorm backward in ONE pass over x and dy: dx as in ln_bwd_dx_kernel, and -- from the same registers -- this wave's column
-// partials of dgamma (sum dy*xhat) and dbeta (sum dy), combined over the block's 8 waves in LDS in a fixed order and written as
-// one partial row per block (<= 512 rows for colpart_reduce_kernel: 5 MB at C = 1280 against the 21 MB the separate parameter
-// kernel re-read).  Algorithmic traffic 6 B/elem (+2 with dx_add); the two-kernel form moved 10.
-#define LNF_WAVES 8
-#define LNF_SLOTS 2
-#define LNF_MAX_BLOCKS 512      // x 8 waves = one row per wave at M = 4096 (these 10 MB tensors are latency-bound: rows in flight matter more than bytes)
+// LayerNorm backward in ONE pass over x and dy (round 5; replaces the round-2 one-row-per-wave fused kernel, whose per-wave LDS fold cost
+// more than the row it had processed).  A wave walks SEVERAL rows (row = wave, wave + nwaves, ...: 4 at M = 4096, 8 at M = 16384), the next
+// row's x / dy / residual-gradient loads are issued before the current row's reductions (two rows in flight per wave: these 10-40 MB
+// tensors are latency-bound), dx is produced as in ln_bwd_dx_kernel, and -- from the same registers -- the wave keeps column partials of
+// dgamma (sum dy * xhat) and dbeta (sum dy) over ITS rows.  At the end the block's four waves fold through two LDS slots in a fixed order
+// ((w0 + w2) + (w1 + w3): bit-reproducible) into ONE partial row per block: <= 512 rows, 1.3-2.6 MB, against the 21 MB the separate
+// parameter kernel re-read.  colpart_reduce_kernel / colpart_reduce_batch_kernel sum the partial rows (single writer per channel).
+// Algorithmic traffic 6 B/elem (+2 with dx_add); the three-kernel form moved 10 (+2) and took three launches.
+#define LNR_WAVES 4      // (8 waves x 2 rows: 10.2 vs 11.1 us alone at 4096 x 1280, 20.5 vs 18.0 at 16384 x 640, and the smaller A/B gain in the step)
+#define LNR_MAX_BLOCKS 512
 template <int NCH>
-__global__ __launch_bounds__(LNF_WAVES * 64) void ln_bwd_fused_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                        const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
-                                                                        bf16_t* __restrict__ dx, float* __restrict__ part, int M, int C) {
+__global__ __launch_bounds__(LNR_WAVES * 64) void ln_bwd_rows_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd, const bf16_t* __restrict__ dx_add,
+                                                                       bf16_t* __restrict__ dx, float* __restrict__ part, int M, int C) {
   extern __shared__ __attribute__((aligned(16))) char ln_smem[];
-  float* red = (float*)ln_smem;                     // [LNF_SLOTS][2][C]: the 8 waves fold into 2 slots in 4 rounds (20 KB at C = 1280, not 80:
-                                                    // a block that needs half a CU's LDS cannot slip in beside the GEMMs of the other stream)
+  float* red = (float*)ln_smem;                     // [2 slots][2][C]: 20 KB at C = 1280
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wave = blockIdx.x * LNF_WAVES + wv;
-  const int nwaves = gridDim.x * LNF_WAVES;
+  const int wave = blockIdx.x * LNR_WAVES + wv;
+  const int nwaves = gridDim.x * LNR_WAVES;
   const int cpr = C >> 3;
   const float invC = 1.0f / (float)C;
   float gm[NCH][8], sg[NCH][8], sb[NCH][8];
@@ -694,19 +696,29 @@ __global__ __launch_bounds__(LNF_WAVES * 64) void ln_bwd_fused_kernel(const bf16
       for (int e = 0; e < 4; ++e) { gm[j][e] = g0[e]; gm[j][4 + e] = g1[e]; }
     }
   }
-  for (int row = wave; row < M; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
-    uint4_t rx[NCH], rd[NCH], ra[NCH];
+  uint4_t rx[NCH], rd[NCH], ra[NCH];
+  float mu = 0.f, rs = 0.f;
+  auto fetch = [&](int row, uint4_t (&fx)[NCH], uint4_t (&fd)[NCH], uint4_t (&fa)[NCH], float& fmu, float& frs) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-      int ch = lane + 64 * j;
-      rx[j] = rd[j] = ra[j] = (uint4_t){0u, 0u, 0u, 0u};
-      if (ch < cpr) {
-        rx[j] = *(const uint4_t*)(x + (long)row * C + ch * 8);
-        rd[j] = *(const uint4_t*)(dy + (long)row * C + ch * 8);
-        if (dx_add) ra[j] = *(const uint4_t*)(dx_add + (long)row * C + ch * 8);
+      const int ch = lane + 64 * j;
+      fx[j] = fd[j] = fa[j] = (uint4_t){0u, 0u, 0u, 0u};
+      if (row < M && ch < cpr) {
+        fx[j] = *(const uint4_t*)(x + (long)row * C + ch * 8);
+        fd[j] = *(const uint4_t*)(dy + (long)row * C + ch * 8);
+        if (dx_add) fa[j] = *(const uint4_t*)(dx_add + (long)row * C + ch * 8);
       }
     }
+    fmu = row < M ? mean[row] : 0.f;
+    frs = row < M ? rstd[row] : 0.f;
+  };
+  constexpr bool AHEAD = NCH < 4;      // (C > 1536 -- no SDXL / SD1.5 LayerNorm -- would spill with two rows in registers: one row at a time)
+  if (AHEAD) fetch(wave, rx, rd, ra, mu, rs);
+  for (int row = wave; row < M; row += nwaves) {
+    uint4_t nx[NCH], nd[NCH], na[NCH];
+    float nmu = 0.f, nrs = 0.f;
+    if (AHEAD) fetch(row + nwaves, nx, nd, na, nmu, nrs);        // the next row's loads are in flight under this row's arithmetic
+    else fetch(row, rx, rd, ra, mu, rs);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -738,13 +750,18 @@ __global__ __launch_bounds__(LNF_WAVES * 64) void ln_bwd_fused_kernel(const bf16
         *(uint4_t*)(dx + (long)row * C + ch * 8) = pack8(o);
       }
     }
-  }
-  // this wave's column partials -> LDS -> one row per block.  Waves 2r and 2r+1 write (round 0) or add (rounds 1..3) into slots 0
-  // and 1, always in the same order, so the sums are bitwise reproducible.
+    if (AHEAD) {
 #pragma unroll
-  for (int round = 0; round < LNF_WAVES / LNF_SLOTS; ++round) {
-    if ((wv / LNF_SLOTS) == round) {
-      float* gbase = red + ((long)(wv % LNF_SLOTS) * 2) * C;
+      for (int j = 0; j < NCH; ++j) { rx[j] = nx[j]; rd[j] = nd[j]; ra[j] = na[j]; }
+      mu = nmu;
+      rs = nrs;
+    }
+  }
+  // this wave's column partials -> LDS -> one row per block.  Waves 0, 1 write slots 0, 1; waves 2, 3 add into them; then slot 0 + slot 1.
+#pragma unroll
+  for (int round = 0; round < LNR_WAVES / 2; ++round) {
+    if ((wv >> 1) == round) {
+      float* gbase = red + ((long)(wv & 1) * 2) * C;
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
         int ch = lane + 64 * j;
@@ -763,11 +780,54 @@ __global__ __launch_bounds__(LNF_WAVES * 64) void ln_bwd_fused_kernel(const bf16
     __syncthreads();
   }
   float* out = part + (long)blockIdx.x * 2 * C;
-  for (int c = threadIdx.x; c < 2 * C; c += LNF_WAVES * 64) out[c] = red[c] + red[2 * C + c];
+  for (int c = threadIdx.x; c < 2 * C; c += LNR_WAVES * 64) out[c] = red[c] + red[2 * C + c];
 }
-static int ln_fused_blocks(int M) {
-  int b = (M + LNF_WAVES - 1) / LNF_WAVES;
-  return b < 1 ? 1 : (b > LNF_MAX_BLOCKS ? LNF_MAX_BLOCKS : b);
+// one block per 16 rows (four per wave), at most 512 blocks (two per CU; 8 rows per wave at M = 16384)
+static int ln_rows_blocks(int M) {
+  int b = (M + 4 * LNR_WAVES - 1) / (4 * LNR_WAVES);
+  return b < 1 ? 1 : (b > LNR_MAX_BLOCKS ? LNR_MAX_BLOCKS : b);
+}
+
+// Several column-partial reductions in ONE launch (blockIdx.y = entry): the three LayerNorms of a transformer block hand their partial
+// rows to the weight-gradient queue, which reduces them behind the block's batched weight gradients (ops.WgradQueue).
+__global__ __launch_bounds__(1024) void colpart_reduce_batch_kernel(const NkColpartBatch b) {
+  __shared__ float sa[16][64], sb[16][64];
+  const int z = blockIdx.y;
+  const int C = b.C[z], nrows = b.nrows[z];
+  if ((int)blockIdx.x * 64 >= C) return;
+  const float* __restrict__ part = b.part[z];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float a = 0.f, v = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = ty; r < nrows; r += 16) {
+      a += part[(long)r * 2 * C + c];
+      v += part[(long)r * 2 * C + C + c];
+    }
+  }
+  sa[ty][tx] = a;
+  sb[ty][tx] = v;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) { a += sa[j][tx]; v += sb[j][tx]; }
+    float* dgamma = b.dgamma[z];
+    float* dbeta = b.dbeta[z];
+    dgamma[c] = b.accumulate[z] ? dgamma[c] + a : a;
+    dbeta[c] = b.accumulate[z] ? dbeta[c] + v : v;
+  }
+}
+
+extern "C" int nk_colpart_reduce_batch(const NkColpartBatch* b, void* stream_) {
+  NK_CHECK_ARG(b && b->n > 0 && b->n <= NK_COLPART_MAX);
+  int maxC = 0;
+  for (int z = 0; z < b->n; ++z) {
+    NK_CHECK_ARG(b->part[z] && b->dgamma[z] && b->dbeta[z] && b->nrows[z] > 0 && b->C[z] > 0);
+    maxC = b->C[z] > maxC ? b->C[z] : maxC;
+  }
+  hipLaunchKernelGGL(colpart_reduce_batch_kernel, dim3((maxC + 63) / 64, b->n), dim3(1024), 0, (hipStream_t)stream_, *b);
+  return nk_check_launch("colpart_reduce_batch_kernel");
 }
 
 extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
@@ -783,9 +843,11 @@ extern "C" int nk_layernorm_fwd(const void* x, const float* gamma, const float* 
 }
 
 extern "C" long nk_layernorm_ws_floats(int M, int C) {
-  const long a = (long)ln_param_split(M), b = LNF_MAX_BLOCKS;
+  const long a = (long)ln_param_split(M), b = LNR_MAX_BLOCKS;
   return (a > b ? a : b) * 2 * C + 64;
 }
+
+extern "C" long nk_layernorm_part_rows(int M) { return ln_rows_blocks(M); }
 
 extern "C" int nk_layernorm_bwd_dx(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                    const void* dx_add, void* dx, int M, int C, void* stream_) {
@@ -816,6 +878,31 @@ extern "C" int nk_layernorm_bwd_params(const void* dy, const void* x, const floa
   return nk_check_launch("colpart_reduce_kernel");
 }
 
+static int launch_ln_rows(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dx_add,
+                          void* dx, float* part, int M, int C, hipStream_t stream) {
+  const int blocks = ln_rows_blocks(M);
+  const int nch = ((C >> 3) + 63) / 64;
+  const int smem = 2 * 2 * C * (int)sizeof(float);
+#define NK_LN_ROWS(NCH_)                                                                                                       \
+  do {                                                                                                                          \
+    nk_optin_lds((const void*)ln_bwd_rows_kernel<NCH_>, 2 * 2 * 2048 * 4);                                                      \
+    hipLaunchKernelGGL(ln_bwd_rows_kernel<NCH_>, dim3(blocks), dim3(LNR_WAVES * 64), smem, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,   \
+                       (const bf16_t*)dx_add, (bf16_t*)dx, part, M, C);                                                        \
+  } while (0)
+  if (nch <= 2) NK_LN_ROWS(2); else if (nch == 3) NK_LN_ROWS(3); else NK_LN_ROWS(4);
+#undef NK_LN_ROWS
+  return nk_check_launch("ln_bwd_rows_kernel");
+}
+
+/* dx and nk_layernorm_part_rows(M) partial rows [rows][2][C] (dgamma partials, dbeta partials) in one pass; the caller reduces the rows with
+ * nk_colpart_reduce_batch (any stream, any later time: `part` is the only state) */
+extern "C" int nk_layernorm_bwd_rows(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                     const void* dx_add, void* dx, float* part, int M, int C, void* stream_) {
+  NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
+  NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && part);
+  return launch_ln_rows(dy, x, gamma, mean, rstd, dx_add, dx, part, M, C, (hipStream_t)stream_);
+}
+
 extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, const void* dx_add, void* dx, float* dgamma, float* dbeta, float* ws,
                                 int M, int C, int accumulate, void* stream_) {
@@ -823,19 +910,7 @@ extern "C" int nk_layernorm_bwd(const void* dy, const void* x, const float* gamm
   hipStream_t stream = (hipStream_t)stream_;
   NK_CHECK_ARG(M > 0 && C > 0 && (C & 7) == 0 && (C >> 3) <= 64 * LN_MAXCH);
   NK_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws);
-  const int blocks = ln_fused_blocks(M);
-  const int nch = ((C >> 3) + 63) / 64;
-  const int smem = LNF_SLOTS * 2 * C * (int)sizeof(float);
-#define NK_LN_FUSED(NCH_)                                                                                                      \
-  do {                                                                                                                          \
-    static bool attr = false;                                                                                                   \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ln_bwd_fused_kernel<NCH_>, hipFuncAttributeMaxDynamicSharedMemorySize, LNF_SLOTS * 2 * 2048 * 4); attr = true; } \
-    hipLaunchKernelGGL(ln_bwd_fused_kernel<NCH_>, dim3(blocks), dim3(LNF_WAVES * 64), smem, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,   \
-                       (const bf16_t*)dx_add, (bf16_t*)dx, ws, M, C);                                                          \
-  } while (0)
-  if (nch <= 2) NK_LN_FUSED(2); else if (nch == 3) NK_LN_FUSED(3); else NK_LN_FUSED(4);
-#undef NK_LN_FUSED
-  if (int e = nk_check_launch("ln_bwd_fused_kernel")) return e;
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, ws, dgamma, dbeta, blocks, C, accumulate);
+  if (int e = launch_ln_rows(dy, x, gamma, mean, rstd, dx_add, dx, ws, M, C, stream)) return e;
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, ws, dgamma, dbeta, ln_rows_blocks(M), C, accumulate);
   return nk_check_launch("colpart_reduce_kernel");
 }

@@ -30,6 +30,14 @@ class NkAttnDesc(C.Structure):
     )
 
 
+NK_COLPART_MAX = 32
+
+
+class NkColpartBatch(C.Structure):
+    _fields_ = [("part", vp * NK_COLPART_MAX), ("dgamma", vp * NK_COLPART_MAX), ("dbeta", vp * NK_COLPART_MAX), ("nrows", i32 * NK_COLPART_MAX),
+                ("C", i32 * NK_COLPART_MAX), ("accumulate", i32 * NK_COLPART_MAX), ("n", i32)]
+
+
 cdp, adp = C.POINTER(NkConvDesc), C.POINTER(NkAttnDesc)
 
 # name -> argtypes; every entry point returns int (0 = ok).  Mirrors include/neurosis_hip.h one to one.
@@ -62,6 +70,8 @@ SIGNATURES: dict[str, list] = {
     "nk_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "nk_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "nk_layernorm_bwd_dx": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "nk_layernorm_bwd_rows": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "nk_colpart_reduce_batch": [C.POINTER(NkColpartBatch), vp],
     "nk_layernorm_bwd_params": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "nk_geglu_fwd": [vp, vp, i64, i32, vp],
     "nk_geglu_bwd": [vp, vp, vp, i64, i32, vp],
@@ -114,6 +124,7 @@ SIZE_QUERIES: dict[str, list] = {
     "nk_conv2d_dgrad_flipped_ok": [cdp],
     "nk_linear_fwd_geglu_ok": [i32, i32, i32],
     "nk_layernorm_ws_floats": [i32, i32],
+    "nk_layernorm_part_rows": [i32],
     "nk_colsum_ws_floats": [i64, i32],
     "nk_batchnorm_ws_floats": [i64, i32],
     "nk_lpips_layer_ws_floats": [i32, i32],

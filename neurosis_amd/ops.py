@@ -164,6 +164,7 @@ class WgradQueue:
 
     def __init__(self, owner=None):
         self.items = []  # (dy, x, dw2d)
+        self.colparts = []  # (part, dgamma, dbeta, nrows, C, accumulate)
         self.owner = owner
 
     MAX_ELEMS = 2 << 20     # weights up to 1280 x 1280: larger ones fill the chip alone and should not wait for the end of the block
@@ -176,7 +177,14 @@ class WgradQueue:
         """db: the layer's bias gradient [N] (fp32), summed from dy by the same launch"""
         self.items.append((dy, x, dw, db))
 
+    def add_colpart(self, part: Tensor, dgamma: Tensor, dbeta: Tensor, nrows: int, Cc: int, accumulate: bool) -> None:
+        """partial rows of a one-pass LayerNorm backward (nk_layernorm_bwd_rows): reduced with the block's other ones in one launch"""
+        self.colparts.append((part, dgamma, dbeta, nrows, Cc, accumulate))
+
     def flush(self) -> None:
+        colparts, self.colparts = self.colparts, []
+        if colparts:
+            on_wgrad_stream(lambda: colpart_reduce(colparts), *[c[0] for c in colparts], owner=self.owner)
         items, self.items = self.items, []
         if not items:
             return
@@ -201,6 +209,18 @@ class WgradQueue:
                          lddy, ldx, lddw, mode, _stream())
 
         on_wgrad_stream(run, *[t for it in items for t in it[:2]], owner=self.owner)
+
+
+def colpart_reduce(entries) -> None:
+    """dgamma / dbeta of several one-pass LayerNorm backwards from their partial rows, NK_COLPART_MAX per launch (current stream)"""
+    for i in range(0, len(entries), lib.NK_COLPART_MAX):
+        chunk = entries[i:i + lib.NK_COLPART_MAX]
+        b = lib.NkColpartBatch()
+        for z, (part, dgamma, dbeta, nrows, Cc, acc) in enumerate(chunk):
+            b.part[z], b.dgamma[z], b.dbeta[z] = part.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+            b.nrows[z], b.C[z], b.accumulate[z] = nrows, Cc, int(acc)
+        b.n = len(chunk)
+        call("nk_colpart_reduce_batch", C.byref(b), _stream())
 
 
 _wgrad_queue: Optional[WgradQueue] = None
@@ -702,11 +722,24 @@ def layernorm_fwd(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5):
 
     def bwd(dy: Tensor, dx_add: Optional[Tensor] = None):
         dx = torch.empty_like(x)
-        ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
         acc = state_of(weight).grad_accumulate
-        # (two kernels, not the one-pass nk_layernorm_bwd the C-ABI also offers: in the real step the fused form measured 180.6 vs 178.7 ms --
-        # these 10-20 MB tensors are latency-bound, the parameter kernel's second read of x, dy comes out of the Infinity Cache, and the fused
-        # kernel's 72 extra accumulator registers per lane cost it the waves that hide latency)
+        if os.environ.get("NK_LN_FUSED", "1") != "0":
+            # one pass over dy and x (round 5): dx and one row of dgamma / dbeta partials per workgroup; the rows are reduced later, off the
+            # critical path -- with the block's other LayerNorms in ONE launch behind its batched weight gradients when a WgradQueue is
+            # open (BasicTransformerBlock.bwd), else right away on the weight-gradient stream
+            rows = query("nk_layernorm_part_rows", M)
+            part = torch.empty(rows * 2 * Cc, dtype=torch.float32, device=dy.device)
+            call("nk_layernorm_bwd_rows", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
+                 dx.data_ptr(), part.data_ptr(), M, Cc, _stream())
+            entry = (part, grad_flat(weight), grad_flat(bias), rows, Cc, bool(acc))
+            if _wgrad_queue is not None:
+                _wgrad_queue.add_colpart(*entry)
+            else:
+                on_wgrad_stream(lambda: colpart_reduce([entry]), part, owner=weight)
+            return dx
+        # NK_LN_FUSED=0: the three-kernel form of rounds 2-4 (dx on the main chain; a second pass over dy, x for the parameter gradients and
+        # their column reduce on the weight-gradient stream)
+        ws = _ws(query("nk_layernorm_ws_floats", M, Cc), dy.device)
         call("nk_layernorm_bwd_dx", dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
              dx.data_ptr(), M, Cc, _stream())
 

@@ -256,8 +256,12 @@ def test_groupnorm(ops, N, H, W, C, silu, eps):
     assert_close(b.grad, br.grad, TOL_F32, "gn dbeta")
 
 
-@pytest.mark.parametrize("M,C", [(1000, 640), (512, 1280), (77, 320)])
-def test_layernorm(ops, M, C):
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("M,C", [(1000, 640), (512, 1280), (77, 320), (4100, 1280), (9000, 640), (8, 2048)])
+def test_layernorm(ops, M, C, fused, monkeypatch):
+    """fused = "1": the one-pass backward (nk_layernorm_bwd_rows + nk_colpart_reduce_batch; a wave walks several rows: 4100 rows = 257 blocks
+    with ragged last rows, 9000 rows = the 512-block cap, 8 rows = waves without a row); "0": the three-kernel form"""
+    monkeypatch.setenv("NK_LN_FUSED", fused)
     x = bf16_round(rnd(M, C) * 1.5 + 0.3).requires_grad_(True)
     gamma, beta = rnd(C) * 0.5 + 1, rnd(C) * 0.1
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
@@ -269,8 +273,38 @@ def test_layernorm(ops, M, C):
     assert_close(out, ref, TOL_BF16, "ln fwd")
     dx = bwd(dev(dy), dev(extra))
     assert_close(dx, x.grad + extra, TOL_BF16, "ln dx")
+    ops.join_wgrad_stream()
     assert_close(w.grad, gr.grad, TOL_F32, "ln dgamma")
     assert_close(b.grad, br.grad, TOL_F32, "ln dbeta")
+
+
+def test_layernorm_partial_rows_reduce_in_one_launch_and_reproducibly(ops):
+    """Three LayerNorm backwards hand their partial rows to one WgradQueue (what BasicTransformerBlock.bwd does): one
+    nk_colpart_reduce_batch launch writes all six parameter gradients; run twice, the results are bit-identical (fixed fold order), and the
+    accumulate flag adds instead of overwriting."""
+    M, C = 2048, 640
+    outs = []
+    for rep in range(2):
+        params, refs = [], []
+        with ops.batched_wgrads(None) as q:
+            for i in range(3):
+                x = bf16_round(rnd(M, C, seed=20 + i) + 0.1 * i).requires_grad_(True)
+                g0, b0 = (rnd(C, seed=30 + i) * 0.5 + 1).requires_grad_(True), (rnd(C, seed=40 + i) * 0.1).requires_grad_(True)
+                dy = rnd(M, C, seed=50 + i)
+                F.layer_norm(x, (C,), g0, b0, 1e-5).backward(dy)
+                w, b = torch.nn.Parameter(dev(g0.detach(), torch.float32)), torch.nn.Parameter(dev(b0.detach(), torch.float32))
+                _, bwd = ops.layernorm_fwd(dev(x.detach()), w, b, 1e-5)
+                bwd(dev(dy))
+                params.append((w, b))
+                refs.append((g0.grad, b0.grad))
+            assert q is None or len(q.colparts) == 3
+        ops.join_wgrad_stream()
+        for (w, b), (gr, br) in zip(params, refs):
+            assert_close(w.grad, gr, TOL_F32, "ln dgamma (batched reduce)")
+            assert_close(b.grad, br, TOL_F32, "ln dbeta (batched reduce)")
+        outs.append([t.grad.clone() for pair in params for t in pair])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("M,N,I", [(300, 320, 1280), (4096, 1280, 5120), (1000, 136, 264)])

@@ -31,8 +31,11 @@ for (M, C) in [(16384, 640), (4096, 1280)]:
     t = timeit(lambda: ops.layernorm_fwd(x, g, b))
     print(f"{'layernorm fwd':34s} {str((M,C)):22s} {t*1e3:9.1f} {4*n/t/1e6:8.0f}")
     out, bwd = ops.layernorm_fwd(x, g, b); dy = rb(M, C)
-    t = timeit(lambda: bwd(dy, dy))
-    print(f"{'layernorm bwd (+residual grad)':34s} {str((M,C)):22s} {t*1e3:9.1f} {8*n/t/1e6:8.0f}")
+    for fused in ("1", "0"):      # one-pass rows kernel + partial-row reduce  vs  dx | parameter pass | column reduce
+        os.environ["NK_LN_FUSED"] = fused
+        t = timeit(lambda: bwd(dy, dy))
+        print(f"{'layernorm bwd (+residual grad) ' + ('one pass' if fused == '1' else '3 kernels'):34s} {str((M,C)):22s} {t*1e3:9.1f} {8*n/t/1e6:8.0f}")
+    os.environ.pop("NK_LN_FUSED")
 for (M, I) in [(16384, 2560), (4096, 5120)]:
     u = rb(M, 2 * I); n = M * I
     t = timeit(lambda: ops.geglu_fwd(u))

@@ -15,11 +15,15 @@ from neurosis_amd import graphs, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--batch", type=int, default=4)
+ap.add_argument("--serialize", action="store_true", help="no weight-gradient side stream, optimizer in line (as bench.py --serialize)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 eng = bench.build_engine(dev, (1024, 1024), None)
 eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)      # as bench.py: configs/sdxl/sdxl.example.yaml:158-164
+if args.serialize:
+    eng.store.state.wgrad_stream = None
+    eng.overlap_optimizer = False
 graphs.stamps = st = graphs.Stamps(dev)
 gen = torch.Generator(device=dev).manual_seed(42)
 _opt, _enc, _join = eng.adafactor.step, eng.encode_first_stage, eng.join_optimizer
