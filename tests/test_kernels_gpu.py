@@ -593,6 +593,9 @@ def test_feedforward_projection_with_fused_geglu_forward(ops, shape, monkeypatch
     h2 = ops.geglu_fwd(u2)[0]
     assert torch.equal(u, u2) and torch.equal(h, h2)
     monkeypatch.delenv("NK_GEMM_KROT")
+    # NOTE: with NK_GEMM_KROT=0 above only the UNROTATED order is compared bit for bit.  The DEFAULT (rotated) order -- what the
+    # training step runs -- is checked against the oracle / torch at TOLERANCE only (here and in every parity test), plus the run-to-run stability
+    # screen of tools/race_screen_xl.py: two kernels with different tile maps legitimately differ in the last bits under it.
     u, h, bwd = ops.linear_geglu_fwd(dev(x), wp, bp)          # the default order: same values up to the summation order
     assert_close(u, u2.float().cpu(), 1e-2, "geglu projection u, rotated k order")
     assert torch.equal(h, ops.geglu_fwd(u)[0])
