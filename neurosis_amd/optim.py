@@ -69,7 +69,11 @@ class FlatAdafactor:
             # (one box, back to back) -- the cache-sized chunk still wins although it costs twice the launches.
             import os
 
-            chunk_bytes = int(os.environ.get("NK_AF_CHUNK_MB", "64")) << 20
+            # 128 MB (round 5; 64 before): alone on the chip the update takes 20.5 / 17.8 / 13.8 / 12.7 / 12.2 / 11.7 ms at 32 / 64 / 128 / 256 /
+            # 512 / 1024 MB chunks (tools/bench_optimizer.py) -- three dependent launches per chunk, each with its ramp and tail -- while the
+            # second and third read of a chunk's gradients only stay in the 256 MB Infinity Cache for small chunks; in the step 128 MB measured
+            # -0.5 ms against 64, 256 the same as 64, 512 +0.6 ms (profiles/r05_ab_notes.txt)
+            chunk_bytes = int(os.environ.get("NK_AF_CHUNK_MB", "128")) << 20
         # `boundaries`: tensor indices at which a new chunk must begin (the first parameter of every top-level UNet block), so
         # that a block's update can be issued as soon as that block's gradients are final, while backward is still running
         bounds = set(int(b) for b in (boundaries or ()))
