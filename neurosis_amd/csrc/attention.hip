@@ -1799,7 +1799,7 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   if (int e = attn_check(d)) return e;
   NK_CHECK_ARG(q && k && v && o && lse && d_o && dq && dk && dv && delta_ws);
   NK_CHECK_ARG(!d->causal);   // the causal variant serves the frozen text encoders: forward only
-  NK_CHECK_ARG(d->D <= 160);  // head dim 512 (VAE mid block): forward only here; its training path keeps the probabilities (ops.attention_unfused_fwd)
+  NK_CHECK_ARG(d->D <= 160);  // head dim 512 (VAE mid block): forward only here; its training path recomputes the probabilities chunk by chunk (ops.attention512_fwd)
   NK_CHECK_ARG((d->sdq & 7) == 0 && (d->sdk & 7) == 0 && (d->sdv & 7) == 0 && (d->sdo & 7) == 0);
   NK_CHECK_ARG((d->bdq & 7) == 0 && (d->bdk & 7) == 0 && (d->bdv & 7) == 0 && (d->bdo & 7) == 0);
   AttnParams p = {};

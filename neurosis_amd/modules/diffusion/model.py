@@ -138,8 +138,9 @@ class ResnetBlock(nn.Module):
 class AttnBlock(nn.Module):
     """model.py:144-243 (AttnBlock / MemoryEfficientAttnBlock / TorchSDPAttnBlock): single-head self-attention over
     H*W tokens with head dim = C.  C = 512 (the SD / SDXL VAE) runs the one-kernel flash forward of csrc/attn512.h -- no [L][L] score
-    matrix in HBM --, C <= 160 the flash kernels of the UNet (forward and backward); other widths, and the backward at C = 512
-    (autoencoder training keeps the probabilities), go through two MFMA GEMMs around a row softmax."""
+    matrix in HBM --, C <= 160 the flash kernels of the UNet (forward and backward); other widths (inference only) go through two MFMA
+    GEMMs around a row softmax.  The backward at C = 512 (autoencoder training) recomputes the probabilities per chunk of query rows
+    (ops.attention512_fwd): nothing of size L x L is kept between forward and backward."""
 
     def __init__(self, in_channels: int):
         super().__init__()
@@ -165,8 +166,10 @@ class AttnBlock(nn.Module):
         (q, b_q), (k, b_k), (v, b_v) = (m.fwd(hn) for m in (self.q, self.k, self.v))
         if self.in_channels <= 160:
             o, b_att = ops.attention_fwd(q.t, k.t, v.t, x.N, 1, self.in_channels)
+        elif self.in_channels == 512:
+            o, b_att = ops.attention512_fwd(q.t, k.t, v.t, x.N)       # flash forward; backward recomputes the probabilities chunk by chunk
         else:
-            o, b_att = ops.attention_unfused_fwd(q.t, k.t, v.t, x.N)
+            raise NotImplementedError(f"AttnBlock backward: {self.in_channels} channels (the SD / SDXL autoencoders use 512; <= 160 also has kernels)")
         y, b_p = self.proj_out.fwd(Img(o, x.N, x.H, x.W), residual=x.t)
 
         def bwd(dy: Tensor) -> Tensor:

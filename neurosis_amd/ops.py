@@ -927,7 +927,7 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head:
     def bwd(do: Tensor, dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None):
         _check2d(do, "do")
         if dim_head > 160:
-            raise NotImplementedError("attention backward: head dim <= 160 (head dim 512 is forward only; attention_unfused_fwd has a backward)")
+            raise NotImplementedError("attention backward: head dim <= 160 (head dim 512: attention512_fwd recomputes the probabilities chunk by chunk)")
         dq = torch.empty(B * Lq, HD, dtype=BF16, device=do.device) if dq is None else dq
         dk = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dk is None else dk
         dv = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dv is None else dv
@@ -956,32 +956,42 @@ def attention_unfused(q: Tensor, k: Tensor, v: Tensor, B: int) -> Tensor:
     return out
 
 
-def attention_unfused_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
-    """attention_unfused with a backward (the VAE mid block when the autoencoder is trained).  The probabilities are kept
-    ([B, L, L] bf16: 2 MB per sample at the 256^2 training resolution).  bwd(do) -> (dq, dk, dv), dense [B*L, D]."""
+ATTN512_BWD_CHUNK = 2048      # query rows per backward chunk: the recomputed score / probability block is [chunk, L] bf16 (64 MB at L = 16384)
+
+
+def attention512_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
+    """Single-head attention of head dim 512 WITH a backward (the VAE mid block when the autoencoder is trained: modules/diffusion/model.py:224-243,
+    models/autoencoder.py:280-293).  Forward: the one-kernel flash forward of csrc/attn512.h -- nothing of size L x L is kept.  Backward
+    (round 5; rounds 2-4 kept the [B, L, L] probabilities of a two-GEMM forward): per sample and per chunk of ATTN512_BWD_CHUNK query rows the
+    probabilities are RECOMPUTED (scores GEMM + row softmax, as the unfused forward computed them) and consumed at once by the four gradient
+    GEMMs -- dP = dO V^T, dV += P^T dO, dS = P o (dP - rowsum(P o dP)) / sqrt(D), dQ = dS K, dK += dS^T Q -- so the working set is
+    [chunk, L], not [L, L], and nothing quadratic lives between forward and backward.  A flash BACKWARD kernel for d = 512 (scores never in
+    HBM at all) is the known gap.  q / k / v dense [B*L, D]; bwd(do) -> (dq, dk, dv)."""
     L, D = q.shape[0] // B, q.shape[1]
+    if D != 512:
+        raise ValueError(f"attention512_fwd: head dim 512 only, got {D} (head dims <= 160: attention_fwd)")
     scale = float(D) ** -0.5
-    out = torch.empty_like(q)
-    probs = torch.empty(B, L, L, dtype=BF16, device=q.device)
-    for b in range(B):
-        sl = slice(b * L, (b + 1) * L)
-        gemm_nt(q[sl], k[sl], alpha=scale, out=probs[b])
-        call("nk_softmax_rows", probs[b].data_ptr(), L, L, _stream())
-        gemm_nn(probs[b], v[sl], out=out[sl])
+    out = attention_fwd(q, k, v, B, 1, D, need_lse=False)[0]
 
     def bwd(do: Tensor):
         _check2d(do, "do")
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        acc32 = torch.empty(L, D, dtype=torch.float32, device=q.device)
+        dk32 = torch.empty(L, D, dtype=torch.float32, device=q.device)
+        dv32 = torch.empty(L, D, dtype=torch.float32, device=q.device)
         for b in range(B):
-            sl = slice(b * L, (b + 1) * L)
-            dp = gemm_nt(do[sl], v[sl])                                    # dP = dO V^T
-            gemm_tn_f32(probs[b], do[sl], acc32, False)                    # dV = P^T dO
-            dv[sl].copy_(cast_bf16(acc32))
-            call("nk_softmax_rows_bwd", probs[b].data_ptr(), dp.data_ptr(), L, L, scale, _stream())    # dP -> dS (scaled)
-            gemm_nn(dp, k[sl], out=dq[sl])                                 # dQ = dS K
-            gemm_tn_f32(dp, q[sl], acc32, False)                           # dK = dS^T Q
-            dk[sl].copy_(cast_bf16(acc32))
+            for c0 in range(0, L, ATTN512_BWD_CHUNK):
+                rows = slice(b * L + c0, b * L + min(c0 + ATTN512_BWD_CHUNK, L))
+                keys = slice(b * L, (b + 1) * L)
+                n = rows.stop - rows.start
+                p = gemm_nt(q[rows], k[keys], alpha=scale)                         # scores [n, L] ...
+                call("nk_softmax_rows", p.data_ptr(), n, L, _stream())             # ... -> probabilities, as the forward's
+                dp = gemm_nt(do[rows], v[keys])                                     # dP = dO V^T
+                gemm_tn_f32(p, do[rows], dv32, c0 > 0)                              # dV (+)= P^T dO
+                call("nk_softmax_rows_bwd", p.data_ptr(), dp.data_ptr(), n, L, scale, _stream())    # dP -> dS (scaled), in place
+                gemm_nn(dp, k[keys], out=dq[rows])                                  # dQ = dS K
+                gemm_tn_f32(dp, q[rows], dk32, c0 > 0)                              # dK (+)= dS^T Q
+            dv[b * L:(b + 1) * L].copy_(cast_bf16(dv32))
+            dk[b * L:(b + 1) * L].copy_(cast_bf16(dk32))
         return dq, dk, dv
 
     return out, bwd

@@ -47,16 +47,21 @@ def test_softmax_rows_backward_kernel():
     assert rel_err(dp, want) <= 1e-2
 
 
-def test_unfused_attention_backward_vs_autograd():
+@pytest.mark.parametrize("chunk", [2048, 96])
+def test_attention512_backward_recomputes_chunk_by_chunk_vs_autograd(chunk, monkeypatch):
+    """ops.attention512_fwd: the head-dim-512 flash forward plus the round-5 backward that recomputes the probabilities per chunk of query
+    rows (nothing L x L kept): one chunk, and three ragged chunks (96 + 96 + 8 rows: the dK / dV accumulate path), against fp32 autograd of
+    softmax(q k^T / sqrt(512)) v (the reference's AttnBlock.attention, modules/diffusion/model.py:155-166,224-243)."""
     from neurosis_amd import ops
 
+    monkeypatch.setattr(ops, "ATTN512_BWD_CHUNK", chunk)
     g = torch.Generator().manual_seed(1)
-    B, L, D = 2, 64, 128
+    B, L, D = 2, 200, 512
     q, k, v, do = (torch.randn(B * L, D, generator=g).to(torch.bfloat16) for _ in range(4))
     qr, kr, vr = (t.float().reshape(B, L, D).requires_grad_(True) for t in (q, k, v))
     ref = ((qr @ kr.transpose(1, 2)) * D ** -0.5).softmax(-1) @ vr
     ref.backward(do.float().reshape(B, L, D))
-    o, bwd = ops.attention_unfused_fwd(q.cuda(), k.cuda(), v.cuda(), B)
+    o, bwd = ops.attention512_fwd(q.cuda(), k.cuda(), v.cuda(), B)
     assert rel_err(o, ref.reshape(B * L, D)) <= 2e-2
     for got, want in zip(bwd(do.cuda()), (qr.grad, kr.grad, vr.grad)):
         assert rel_err(got, want.reshape(B * L, D)) <= 3e-2 and cosine(got, want.reshape(B * L, D)) >= 0.999
