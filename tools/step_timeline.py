@@ -16,11 +16,28 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--serialize", action="store_true", help="no weight-gradient side stream, optimizer in line (as bench.py --serialize)")
+ap.add_argument("--drop-wgrads", action="store_true", help="TIMING ONLY (wrong gradients): nothing is issued on the weight-gradient stream -- how long the main chain takes alone")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 eng = bench.build_engine(dev, (1024, 1024), None)
 eng.configure_adafactor(scale_parameter=True, relative_step=True, warmup_init=True)      # as bench.py: configs/sdxl/sdxl.example.yaml:158-164
+if args.drop_wgrads:
+    from neurosis_amd import lib as _lib
+    import neurosis_amd.nn as _nn
+    import neurosis_amd.modules.diffusion.loss as _loss
+    _orig_call = _lib.call
+    _DROP = ("nk_linear_wgrad", "nk_linear_wgrad_bias", "nk_linear_wgrad_batched", "nk_conv2d_wgrad", "nk_conv2d_wgrad_bias", "nk_colpart_reduce_batch",
+             "nk_layernorm_bwd_params")
+
+    def _call(name, *a):
+        if name in _DROP:
+            return None
+        return _orig_call(name, *a)
+
+    for _m in (_lib, ops, _nn, _loss):
+        if hasattr(_m, "call"):
+            _m.call = _call
 if args.serialize:
     eng.store.state.wgrad_stream = None
     eng.overlap_optimizer = False
