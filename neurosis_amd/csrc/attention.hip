@@ -1694,11 +1694,12 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_kernel(const AttnParam
 // host
 // ================================================================================================
 #include "attn512.h"
+#include "attn512_bwd.h"
 
 static int attn_check(const NkAttnDesc* d) {
   NK_CHECK_ARG(d != nullptr);
   NK_CHECK_ARG(d->B > 0 && d->H > 0 && d->Lq > 0 && d->Lk > 0 && d->D > 0);
-  NK_CHECK_ARG((d->D & 7) == 0 && (d->D <= 160 || d->D == 512));     // 512: forward only (attn512.h)
+  NK_CHECK_ARG((d->D & 7) == 0 && (d->D <= 160 || d->D == 512));     // 512: attn512.h (forward), attn512_bwd.h (backward)
   NK_CHECK_ARG((d->sq & 7) == 0 && (d->sk & 7) == 0 && (d->sv & 7) == 0 && (d->so & 7) == 0);
   NK_CHECK_ARG((d->bq & 7) == 0 && (d->bk & 7) == 0 && (d->bv & 7) == 0 && (d->bo & 7) == 0);
   NK_CHECK_ARG(d->B <= 65535 && d->H <= 65535);
@@ -1799,7 +1800,6 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   if (int e = attn_check(d)) return e;
   NK_CHECK_ARG(q && k && v && o && lse && d_o && dq && dk && dv && delta_ws);
   NK_CHECK_ARG(!d->causal);   // the causal variant serves the frozen text encoders: forward only
-  NK_CHECK_ARG(d->D <= 160);  // head dim 512 (VAE mid block): forward only here; its training path recomputes the probabilities chunk by chunk (ops.attention512_fwd)
   NK_CHECK_ARG((d->sdq & 7) == 0 && (d->sdk & 7) == 0 && (d->sdv & 7) == 0 && (d->sdo & 7) == 0);
   NK_CHECK_ARG((d->bdq & 7) == 0 && (d->bdk & 7) == 0 && (d->bdv & 7) == 0 && (d->bdo & 7) == 0);
   AttnParams p = {};
@@ -1812,6 +1812,23 @@ extern "C" int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* 
   p.sdq = d->sdq; p.sdk = d->sdk; p.sdv = d->sdv; p.sdo = d->sdo;
   p.bdq = d->bdq; p.bdk = d->bdk; p.bdv = d->bdv; p.bdo = d->bdo;
   p.scale = d->scale;
+  if (d->D == 512) {
+    // head dim 512 (the VAE mid block under autoencoder training): delta = rowsum(dO o O), then the same kernel template twice --
+    // dQ per 32-query block, dK / dV per 32-key block -- recomputing the scores tile by tile from the forward's log-sum-exp (attn512_bwd.h)
+    NK_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)o & 15) == 0 && ((uintptr_t)d_o & 15) == 0);
+    {
+      const long rows = (long)d->B * d->H * d->Lq;
+      hipLaunchKernelGGL(attn512_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+      if (int e = nk_check_launch("attn512_delta_kernel")) return e;
+    }
+    set_smem(attn512_bwd_kernel<0>, A5B_SMEM);
+    set_smem(attn512_bwd_kernel<1>, A5B_SMEM);
+    hipLaunchKernelGGL(attn512_bwd_kernel<0>, dim3((d->Lq + A5B_ROWS - 1) / A5B_ROWS, d->H, d->B), dim3(256), A5B_SMEM, stream, p);
+    if (int e = nk_check_launch("attn512_bwd_kernel<0>")) return e;
+    hipLaunchKernelGGL(attn512_bwd_kernel<1>, dim3((d->Lk + A5B_ROWS - 1) / A5B_ROWS, d->H, d->B), dim3(256), A5B_SMEM, stream, p);
+    return nk_check_launch("attn512_bwd_kernel<1>");
+  }
+  NK_CHECK_ARG(d->D <= 160);
   if (d->D == 64 && attn64_enabled())      // 16-byte gradient stores
     NK_CHECK_ARG(((uintptr_t)dq & 15) == 0 && ((uintptr_t)dk & 15) == 0 && ((uintptr_t)dv & 15) == 0);
   if (d->D == 64 && d->Lk <= 96 && attn64_enabled() && attn64_small_enabled()) {

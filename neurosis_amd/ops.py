@@ -907,8 +907,8 @@ def cat_fwd(a: Img, b: Img):
 # ------------------------------------------------------------------------------------------------
 def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head: int, causal: bool = False, need_lse: bool = True):
     """softmax(q k^T / sqrt(d)) v.  q [B*Lq, H*D], k/v [B*Lk, H*D] token matrices (column slices allowed).
-    bwd(do) -> (dq, dk, dv) dense token matrices.  causal=True (frozen text transformers) is forward only, and so is
-    dim_head = 512 (the VAE mid block, csrc/attn512.h; need_lse=False skips the log-sum-exp output there)."""
+    bwd(do) -> (dq, dk, dv) dense token matrices.  causal=True (frozen text transformers) is forward only.
+    dim_head = 512 (the VAE mid block): csrc/attn512.h forward (need_lse=False skips the log-sum-exp output: inference), csrc/attn512_bwd.h backward."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _check2d(t, n)
     Lq, Lk = q.shape[0] // B, k.shape[0] // B
@@ -926,8 +926,10 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head:
 
     def bwd(do: Tensor, dq: Optional[Tensor] = None, dk: Optional[Tensor] = None, dv: Optional[Tensor] = None):
         _check2d(do, "do")
-        if dim_head > 160:
-            raise NotImplementedError("attention backward: head dim <= 160 (head dim 512: attention512_fwd recomputes the probabilities chunk by chunk)")
+        if dim_head > 160 and dim_head != 512:
+            raise NotImplementedError("attention backward: head dim <= 160, or 512 (csrc/attn512_bwd.h)")
+        if lse is None:
+            raise ValueError("attention backward needs the forward's log-sum-exp: call attention_fwd(..., need_lse=True)")
         dq = torch.empty(B * Lq, HD, dtype=BF16, device=do.device) if dq is None else dq
         dk = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dk is None else dk
         dv = torch.empty(B * Lk, HD, dtype=BF16, device=do.device) if dv is None else dv
@@ -956,21 +958,33 @@ def attention_unfused(q: Tensor, k: Tensor, v: Tensor, B: int) -> Tensor:
     return out
 
 
+ATTN512_FLASH_MAX_L = 2048    # tokens per sample up to which the flash backward kernels are the faster form (NK_ATTN512_BWD=auto)
 ATTN512_BWD_CHUNK = 2048      # query rows per backward chunk: the recomputed score / probability block is [chunk, L] bf16 (64 MB at L = 16384)
 
 
 def attention512_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
     """Single-head attention of head dim 512 WITH a backward (the VAE mid block when the autoencoder is trained: modules/diffusion/model.py:224-243,
-    models/autoencoder.py:280-293).  Forward: the one-kernel flash forward of csrc/attn512.h -- nothing of size L x L is kept.  Backward
-    (round 5; rounds 2-4 kept the [B, L, L] probabilities of a two-GEMM forward): per sample and per chunk of ATTN512_BWD_CHUNK query rows the
-    probabilities are RECOMPUTED (scores GEMM + row softmax, as the unfused forward computed them) and consumed at once by the four gradient
-    GEMMs -- dP = dO V^T, dV += P^T dO, dS = P o (dP - rowsum(P o dP)) / sqrt(D), dQ = dS K, dK += dS^T Q -- so the working set is
-    [chunk, L], not [L, L], and nothing quadratic lives between forward and backward.  A flash BACKWARD kernel for d = 512 (scores never in
-    HBM at all) is the known gap.  q / k / v dense [B*L, D]; bwd(do) -> (dq, dk, dv)."""
+    models/autoencoder.py:280-293).  Forward: the one-kernel flash forward of csrc/attn512.h -- nothing of size L x L is kept (rounds 2-4 kept
+    the [B, L, L] probabilities of a two-GEMM forward).  Backward, two forms (round 5):
+      flash     -- csrc/attn512_bwd.h: one kernel template for dQ (32 queries per workgroup) and dK / dV (32 keys per workgroup), the scores
+                   recomputed tile by tile in registers from the forward's log-sum-exp; nothing of size L x L anywhere;
+      recompute -- per sample and per chunk of ATTN512_BWD_CHUNK query rows the probabilities are rebuilt through HBM (scores GEMM + row
+                   softmax) and consumed at once by the four gradient GEMMs (dP = dO V^T, dV += P^T dO, dS = P o (dP - rowsum(P o dP)) / sqrt(D),
+                   dQ = dS K, dK += dS^T Q): working set [chunk, L].
+    q / k / v dense [B*L, D]; bwd(do) -> (dq, dk, dv)."""
     L, D = q.shape[0] // B, q.shape[1]
     if D != 512:
         raise ValueError(f"attention512_fwd: head dim 512 only, got {D} (head dims <= 160: attention_fwd)")
     scale = float(D) ** -0.5
+    # NK_ATTN512_BWD: "auto" (default) = the flash backward kernels (csrc/attn512_bwd.h: scores recomputed tile by tile in registers from the
+    # forward's log-sum-exp, nothing in HBM) up to ATTN512_FLASH_MAX_L tokens, the chunked recompute beyond; "1" / "0" force one or the other.
+    # Measured (tools/bench_attn512_bwd.py, batch 4): L = 1024 (config 5) 250 vs 449 us; L = 4096 1.71 vs 1.17 ms; L = 16384 (batch 1) 6.6 vs
+    # 2.8 ms -- the flash kernels are correct and lean, not tuned (one wave per SIMD, register-staged tiles): the tile engine's GEMMs win once
+    # the [chunk, L] scratch is large enough to run them at speed.
+    mode = os.environ.get("NK_ATTN512_BWD", "auto")
+    if mode == "1" or (mode == "auto" and L <= ATTN512_FLASH_MAX_L):
+        out, b_att = attention_fwd(q, k, v, B, 1, D, need_lse=True)
+        return out, (lambda do: b_att(do))
     out = attention_fwd(q, k, v, B, 1, D, need_lse=False)[0]
 
     def bwd(do: Tensor):

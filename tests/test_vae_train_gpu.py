@@ -47,24 +47,32 @@ def test_softmax_rows_backward_kernel():
     assert rel_err(dp, want) <= 1e-2
 
 
-@pytest.mark.parametrize("chunk", [2048, 96])
-def test_attention512_backward_recomputes_chunk_by_chunk_vs_autograd(chunk, monkeypatch):
-    """ops.attention512_fwd: the head-dim-512 flash forward plus the round-5 backward that recomputes the probabilities per chunk of query
-    rows (nothing L x L kept): one chunk, and three ragged chunks (96 + 96 + 8 rows: the dK / dV accumulate path), against fp32 autograd of
+@pytest.mark.parametrize("impl,chunk", [("flash", 0), ("recompute", 2048), ("recompute", 96)])
+@pytest.mark.parametrize("B,L", [(2, 200), (1, 1024), (3, 33)])
+def test_attention512_backward_vs_autograd(impl, chunk, B, L, monkeypatch):
+    """ops.attention512_fwd: the head-dim-512 flash forward with (flash) the flash backward of csrc/attn512_bwd.h -- one kernel template for
+    dQ (32 queries per workgroup) and dK / dV (32 keys per workgroup), scores recomputed tile by tile from the log-sum-exp: ragged lengths
+    (200 = 6.25 tiles, 33), config 5's L = 1024 -- and (recompute, NK_ATTN512_BWD=0) the chunked form that rebuilds the probabilities through
+    HBM (one chunk; three ragged chunks of 96 + 96 + 8 rows: the dK / dV accumulate path), against fp32 autograd of
     softmax(q k^T / sqrt(512)) v (the reference's AttnBlock.attention, modules/diffusion/model.py:155-166,224-243)."""
     from neurosis_amd import ops
 
-    monkeypatch.setattr(ops, "ATTN512_BWD_CHUNK", chunk)
+    if impl == "recompute" and L % 8:
+        pytest.skip("the recomputing form goes through nk_softmax_rows: row lengths in multiples of 8")
+    monkeypatch.setenv("NK_ATTN512_BWD", "1" if impl == "flash" else "0")          # (default "auto": flash up to 2 048 tokens per sample)
+    if chunk:
+        monkeypatch.setattr(ops, "ATTN512_BWD_CHUNK", chunk)
     g = torch.Generator().manual_seed(1)
-    B, L, D = 2, 200, 512
+    D = 512
     q, k, v, do = (torch.randn(B * L, D, generator=g).to(torch.bfloat16) for _ in range(4))
     qr, kr, vr = (t.float().reshape(B, L, D).requires_grad_(True) for t in (q, k, v))
     ref = ((qr @ kr.transpose(1, 2)) * D ** -0.5).softmax(-1) @ vr
     ref.backward(do.float().reshape(B, L, D))
     o, bwd = ops.attention512_fwd(q.cuda(), k.cuda(), v.cuda(), B)
     assert rel_err(o, ref.reshape(B * L, D)) <= 2e-2
-    for got, want in zip(bwd(do.cuda()), (qr.grad, kr.grad, vr.grad)):
-        assert rel_err(got, want.reshape(B * L, D)) <= 3e-2 and cosine(got, want.reshape(B * L, D)) >= 0.999
+    for name, got, want in zip("qkv", bwd(do.cuda()), (qr.grad, kr.grad, vr.grad)):
+        e, cs = rel_err(got, want.reshape(B * L, D)), cosine(got, want.reshape(B * L, D))
+        assert e <= 3e-2 and cs >= 0.999, (name, e, cs)
 
 
 @pytest.mark.parametrize("tag", ["rec_only", "rec_kl"])
