@@ -149,7 +149,7 @@ int nk_conv2d_wgrad_bias(const NkConvDesc* d, const void* dy, const void* x, flo
  * column slices of a fused projection buffer.  lse is [B][H][Lq] fp32 (saved for the backward).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct NkAttnDesc {
-  int B, H, Lq, Lk, D;          /* D % 8 == 0, D <= 160; forward only: D == 512 (the VAE mid block's single head, model.py:224-243; lse may be NULL) */
+  int B, H, Lq, Lk, D;          /* D % 8 == 0, D <= 160; or D == 512 (the VAE mid block's single head, model.py:224-243: forward attn512.h -- lse may be NULL when no backward follows --, backward attn512_bwd.h) */
   long sq, sk, sv, so;          /* row strides of q, k, v, o */
   long bq, bk, bv, bo;          /* batch strides */
   long sdq, sdk, sdv, sdo;      /* backward only: row strides of dq, dk, dv, do */
@@ -164,8 +164,8 @@ long nk_attention_bwd_ws_floats(const NkAttnDesc* d);
 int nk_attention_bwd(const NkAttnDesc* d, const void* q, const void* k, const void* v, const void* o,
                      const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* delta_ws, void* stream);
 /* in-place row softmax on bf16 [M][L]: unfused single-head attention = nk_linear_fwd (q k^T) -> nk_softmax_rows -> nk_linear_dgrad (p v).
- * Serves the VAE mid block (modules/diffusion/model.py:224-243) when the autoencoder is TRAINED (the probabilities are kept for the
- * backward) and head dims the flash kernels do not take; the frozen encoder's d = 512 forward is nk_attention_fwd. */
+ * Serves head dims the flash kernels do not take, and the chunked recomputing backward of the VAE mid block (d = 512) beyond 2 048 tokens per
+ * sample (ops.attention512_fwd; up to there nk_attention_bwd's flash kernels run); d = 512 forward and backward are nk_attention_fwd / _bwd. */
 int nk_softmax_rows(void* s, long M, int L, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
