@@ -328,6 +328,21 @@ def pmc_traffic():
     return (round(b / n), "profiles/" + os.path.basename(path)) if n else (None, None)
 
 
+def expected_exchange_ms(grad_elems: int, world: int, link_GBps: float = 153.0) -> dict:
+    """SURVEY section 5's price list for the gradient exchange on one node: 8 GPUs fully connected, 7 xGMI links x ~153 GB/s per GPU.
+    A ring all-reduce is bound by ONE link (2 (N-1)/N x S over it); a direct reduce-scatter + all-gather uses the N-1 links at once
+    (2 S / N per link); rs_ag sends fp32 gradients out and bf16 shadows back (S/N + S/2N per link)."""
+    if world < 2:
+        return {}
+    out = {}
+    for name, nbytes in (("fp32", grad_elems * 4), ("bf16", grad_elems * 2)):
+        out[f"ring_allreduce_{name}"] = round(2 * (world - 1) / world * nbytes / (link_GBps * 1e9) * 1e3, 1)
+        out[f"direct_rs_ag_{name}"] = round(2 * nbytes / world / (link_GBps * 1e9) * 1e3, 1)
+    out["direct_rs_fp32_ag_bf16"] = round(1.5 * grad_elems * 4 / world / (link_GBps * 1e9) * 1e3, 1)
+    out["assumes"] = f"{link_GBps:.0f} GB/s per xGMI link, {world - 1} links per GPU, no overlap with backward"
+    return out
+
+
 def launch_ranks(args, argv, runner=None):
     """`python bench.py --gpus N` from a bare shell (N > 1, no WORLD_SIZE in the environment): start N FRESH child processes, one rank per
     GPU, through torch.distributed.run on 127.0.0.1 and return their exit code; rank 0's JSON line reaches stdout through the inherited pipe.
@@ -388,6 +403,9 @@ def parse_args(argv=None):
                     help="N > 1: allreduce = flat all-reduce of every gradient slice, the whole optimizer on every rank (default, what Lightning DDP does); "
                          "rs_ag = every slice reduce-scattered into tensor-aligned parts, optimizer on the owned parts, bf16 shadows all-gathered (neurosis_amd/dp.py)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--alt-steps", type=int, default=5,
+                    help="N > 1: behind the timed steps, run this many steps in each of the OTHER exchange configurations (dp-mode x wire dtype) in the "
+                         "same process and report them as comm.alt (0 = off)")
     return ap.parse_args(argv)
 
 
@@ -525,32 +543,36 @@ def main(argv=None):
     in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)]
     per_step = sorted(in_order)
     pct = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]
+    def comm_summary(dp_, marks_, wire_dtype):
+        """what the gradient exchange of the steps just run did: collectives, bytes each rank sent, exposed time, bus bandwidth"""
+        exposed = [a.elapsed_time(b) for a, b, _, _ in marks_]
+        span = [f.elapsed_time(l) for _, _, f, l in marks_ if f is not None and l is not None]
+        ncoll, wire = dp_.reducer.take_counts()
+        nsteps_counted = max(len(marks_), 1)
+        sent = int(wire / nsteps_counted)
+        span_s = (sum(span) / len(span) * 1e-3) if span else None
+        return {"mode": dp_.mode, "wire_dtype": wire_dtype, "collectives_per_step": round(ncoll / nsteps_counted, 1),
+                "bytes_sent_per_rank_per_step": sent, "exposed_ms_mean": round(sum(exposed) / len(exposed), 2),
+                "first_to_last_collective_ms_mean": round(sum(span) / max(len(span), 1), 2) if span else None,
+                # bus bandwidth from the bytes the collectives actually moved (all-reduce: 2 (N-1)/N x payload; rs_ag: (N-1)/N x the padded
+                # staging rows of the reduce-scatters -- the all-gathers run behind the update, outside this span)
+                "busbw_GBps_over_span": round(sent / span_s / 1e9, 1) if span_s else None}
+
     comm = None
     if comm_marks:
-        exposed = [a.elapsed_time(b) for a, b, _, _ in comm_marks]
-        span = [f.elapsed_time(l) for _, _, f, l in comm_marks if f is not None and l is not None]
         nbytes = eng.store.grad.numel() * (2 if args.wire_dtype == "bf16" else eng.store.grad.element_size())
-        ncoll, wire = dp.reducer.take_counts()
-        nsteps_counted = max(len(comm_marks), 1)
         try:
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None
         except Exception:  # noqa: BLE001 - version query only
             rccl = None
         devices = [None] * world
         dist.all_gather_object(devices, f"{torch.cuda.get_device_name(device)} #{torch.cuda.current_device()} pid {os.getpid()}")
-        sent = int(wire / nsteps_counted)
-        span_s = (sum(span) / len(span) * 1e-3) if span else None
-        comm = {"world_size": world, "backend": dist.get_backend(), "rccl_version": rccl, "devices": devices, "mode": dp.mode,
-                "wire_dtype": args.wire_dtype, "collectives_per_step": round(ncoll / nsteps_counted, 1),
-                "bytes_sent_per_rank_per_step": sent,
-                "gradient_bytes": nbytes, "exposed_ms_mean": round(sum(exposed) / len(exposed), 2),
-                "first_to_last_collective_ms_mean": round(sum(span) / max(len(span), 1), 2) if span else None,
-                # bus bandwidth from the bytes the collectives actually moved (all-reduce: 2 (N-1)/N x payload; rs_ag: (N-1)/N x the padded
-                # staging rows of the reduce-scatters -- the all-gathers run behind the update, outside this span)
-                "busbw_GBps_over_span": round(sent / span_s / 1e9, 1) if span_s else None,
-                "max_chunk_elements": dp.reducer.max_chunk,
-                "nccl_env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_NCHANNELS_PER_NET_PEER", "RCCL_MSCCL_ENABLE") if k in os.environ},
-                "note": "exposed = compute stream stalled between end of backward and end of the gradient exchange; span = first to last collective of the gradient exchange (includes the backward it overlaps); rs_ag counts its all-gathers in bytes_sent but they run on the optimizer stream"}
+        comm = {"world_size": world, "backend": dist.get_backend(), "rccl_version": rccl, "devices": devices}
+        comm.update(comm_summary(dp, comm_marks, args.wire_dtype))
+        comm.update({"gradient_bytes": nbytes, "max_chunk_elements": dp.reducer.max_chunk,
+                     "nccl_env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_NCHANNELS_PER_NET_PEER", "RCCL_MSCCL_ENABLE") if k in os.environ},
+                     "expected_ms": expected_exchange_ms(eng.store.grad.numel(), world),
+                     "note": "exposed = compute stream stalled between end of backward and end of the gradient exchange; span = first to last collective of the gradient exchange (includes the backward it overlaps); rs_ag counts its all-gathers in bytes_sent but they run on the optimizer stream; alt = the OTHER exchange configurations run for a few steps in this same process behind the timed ones (ms_per_step = max over ranks, barrier to barrier), so that one multi-GPU run prices every mode"})
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -622,6 +644,40 @@ def main(argv=None):
         dist.barrier()
 
     steady_peak = torch.cuda.max_memory_allocated()
+    if comm is not None and args.alt_steps > 0:
+        # an 8-GPU node is scarce, so the run that measures the default exchange also prices the other ones -- a few
+        # steps each of {allreduce fp32, allreduce bf16 wire, rs_ag}, minus the configuration already timed.  rs_ag goes last (it leaves the
+        # foreign parts' fp32 masters stale); a default of rs_ag makes its masters and statistics whole first.
+        alts = [(m, w) for m, w in (("allreduce", "fp32"), ("allreduce", "bf16"), ("rs_ag", "fp32")) if (m, w) != (dp.mode, args.wire_dtype)]
+        if args.optimizer != "adafactor":
+            alts = [a for a in alts if a[0] != "rs_ag"]
+        comm["alt"] = []
+        for mode_, wire_ in alts:
+            if dp.sharded:
+                dp.sync_masters()
+                eng.adafactor.owned = None          # every rank runs the whole update again (chunks stay cut: no arithmetic changes)
+            dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if wire_ == "bf16" else None, mode=mode_, broadcast_params=False)
+            if dp.sharded:
+                dp.attach_optimizer(eng.adafactor)
+            step()                                  # one untimed step: staging buffers, communicator warm-up of this collective
+            dp.reducer.record_timing = True
+            dp.reducer.take_counts()
+            del comm_marks[:]
+            barrier()
+            ta = time.perf_counter()
+            for _ in range(args.alt_steps):
+                step(mark=True)
+            barrier()
+            dta = time.perf_counter() - ta
+            dp.reducer.record_timing = False
+            tm = torch.tensor([dta], device=device, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            entry = comm_summary(dp, comm_marks, wire_)
+            entry.update({"steps": args.alt_steps, "ms_per_step": round(float(tm.item()) / args.alt_steps * 1e3, 2)})
+            comm["alt"].append(entry)
+        if world > 1:
+            dist.barrier()
     if world > 1 or forced:
         # every collective is behind us: the group is taken down BEFORE rank 0 spends ~10 s on the CPU baseline, so that no rank sits in a
         # collective (or its watchdog) while another one is busy on the host

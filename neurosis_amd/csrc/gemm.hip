@@ -1596,6 +1596,7 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
 static bool use_xl(const NkGemmParams& p, int amode, int bmode, int out_f32, int splitk);
 __global__ void nk_zero_f32_kernel(float* __restrict__ dst, size_t n);
 #include "gemm_g2.h"
+#include "gemm_w160.h"
 #include "conv_halo.h"
 #include "conv_wgrad_halo.h"
 
@@ -1804,6 +1805,21 @@ static void set_split(NkGemmParams& p, int splitk) {
   p.ksplit_len = per * BK;
 }
 
+// split-K partials are summed with fp32 atomics, which need a zeroed destination (weight gradient and fused bias gradient)
+// (a kernel, not hipMemsetAsync: as a node of a captured hipGraph the memset of a multi-MB buffer was not ordered before the
+// kernel behind it on this ROCm -- replayed weight gradients of the 320/640-channel layers came out as garbage)
+static int zero_split_outputs(const NkGemmParams& p, hipStream_t stream) {
+  for (int z = 0; z < (p.nbatch ? p.nbatch : 1); ++z) {
+    const size_t n = (size_t)p.M * p.N;
+    float* dst = (float*)(p.nbatch ? p.Cb[z] : p.C);
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
+    hipLaunchKernelGGL(nk_zero_f32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, n);
+    float* db = p.nbatch ? p.dbias_b[z] : p.dbias;        // the fused bias gradient is summed by the same atomics
+    if (db) hipLaunchKernelGGL(nk_zero_f32_kernel, dim3(1), dim3(256), 0, stream, db, (size_t)p.M);
+  }
+  return hipGetLastError() != hipSuccess ? NK_ERR_LAUNCH : NK_OK;
+}
+
 int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int allow_splitk,
                      hipStream_t stream) {
   NK_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0);
@@ -1846,6 +1862,23 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
     return NK_ERR_ARG;
   }
 
+  // Linear weight gradients whose 160-row tiles come out in whole rounds of 256 workgroups (gemm_w160.h), the token range split where the
+  // weight alone is too small a grid (fp32 atomics: zeroed destination, as below)
+  {
+    const W160Plan wp = w160_plan(p, amode, bmode, out_f32, allow_splitk);
+    if (wp.bn) {
+      set_split(p, wp.splitk);
+      if (wp.splitk > 1 && p.accumulate == 0) {
+        NK_CHECK_ARG(p.ldc == p.N);
+        if (int rc = zero_split_outputs(p, stream)) return rc;
+        p.accumulate = 1;
+      } else if (p.accumulate == 2) {
+        p.accumulate = wp.splitk > 1 ? 1 : 0;
+      }
+      p.k_rotate = k_rotate_on(wp.splitk > 1 ? p.ksplit_len : p.K) ? 1 : 0;
+      return wp.bn == 160 ? launch_w160_as<160>(p, wp.splitk, stream) : launch_w160_as<128>(p, wp.splitk, stream);
+    }
+  }
   // two-group staggered ring at one workgroup per CU (gemm_g2.h): Linear forward / dgrad / wgrad shapes whose 128 x 160 (or
   // 128 x 128) tiles come out in whole rounds of 256
   if (use_ring64(p, amode, bmode, out_f32)) return launch_ring64(p, stream);
@@ -1886,17 +1919,7 @@ int nk_gemm_dispatch(NkGemmParams& p, int amode, int bmode, int out_f32, int all
   if (out_f32 && splitk > 1 && p.accumulate == 0) {
     // split-K partials are summed with fp32 atomics, which need a zeroed destination
     NK_CHECK_ARG(p.ldc == p.N);
-    // (a kernel, not hipMemsetAsync: as a node of a captured hipGraph the memset of a multi-MB buffer was not ordered before the
-    // kernel behind it on this ROCm -- replayed weight gradients of the 320/640-channel layers came out as garbage)
-    for (int z = 0; z < (p.nbatch ? p.nbatch : 1); ++z) {
-      const size_t n = (size_t)p.M * p.N;
-      float* dst = (float*)(p.nbatch ? p.Cb[z] : p.C);
-      const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
-      hipLaunchKernelGGL(nk_zero_f32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, n);
-      float* db = p.nbatch ? p.dbias_b[z] : p.dbias;        // the fused bias gradient is summed by the same atomics
-      if (db) hipLaunchKernelGGL(nk_zero_f32_kernel, dim3(1), dim3(256), 0, stream, db, (size_t)p.M);
-    }
-    if (hipGetLastError() != hipSuccess) return NK_ERR_LAUNCH;
+    if (int rc = zero_split_outputs(p, stream)) return rc;
     p.accumulate = 1;
   } else if (p.accumulate == 2) {
     p.accumulate = splitk > 1 ? 1 : 0;

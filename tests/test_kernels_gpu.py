@@ -93,6 +93,54 @@ def test_linear_wgrad_with_fused_bias_gradient(ops, M, N, K):
     assert_close(dw, 2 * (dy.t() @ x), TOL_F32, "wgrad accumulate")
 
 
+# (tokens M, out features N, in features K) -> the 160-row exact-round kernel (csrc/gemm_w160.h) by its shape rule: 256 tiles of 160 x 160,
+# 240 of 160 x 128, two whole rounds, and the 64^2-level weights with their token range split over 2 / 4 workgroups (fp32 atomics)
+@pytest.mark.parametrize("M,N,K", [(4096, 1280, 5120), (4096, 3840, 1280), (4096, 10240, 1280), (16384, 5120, 640), (16384, 640, 2560)])
+def test_linear_wgrad_exact_round_kernel(ops, M, N, K, monkeypatch):
+    """Weight gradient + fused bias gradient of the SDXL Linear shapes through nk_gemm_w160_kernel against fp32 on the CPU and against the
+    128 x 128 kernels (NK_GEMM_W160=0) -- overwrite, accumulate, and the bias gradient spread over the column tiles."""
+    dy, x = rnd(M, N, seed=M + N), rnd(M, K, seed=K + 1)
+    dyd, xd = dev(dy), dev(x)
+    ref, refb = dy.t() @ x, dy.sum(0)
+    dw, db = torch.full((N, K), 7.0, device="cuda"), torch.full((N,), -3.0, device="cuda")
+    ops.gemm_tn_f32(dyd, xd, dw, False, dbias=db)
+    assert_close(dw, ref, TOL_F32, "w160 wgrad (store)")
+    assert_close(db, refb, TOL_F32, "w160 bias gradient (store)")
+    ops.gemm_tn_f32(dyd, xd, dw, True, dbias=db)
+    assert_close(dw, 2 * ref, TOL_F32, "w160 wgrad (accumulate)")
+    assert_close(db, 2 * refb, TOL_F32, "w160 bias gradient (accumulate)")
+    monkeypatch.setenv("NK_GEMM_W160", "0")          # read per call by nk_gemm_dispatch
+    dw0 = torch.full((N, K), 7.0, device="cuda")
+    ops.gemm_tn_f32(dyd, xd, dw0, False)
+    monkeypatch.delenv("NK_GEMM_W160")
+    dw1 = torch.full((N, K), 7.0, device="cuda")
+    ops.gemm_tn_f32(dyd, xd, dw1, False)
+    # same bf16 products, fp32 sums in another order: the two kernels agree to fp32 rounding of a 4096-term sum
+    assert (dw1 - dw0).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,split", [(1000, 200, 320, 1), (300, 168, 136, 1), (2048, 320, 136, 1), (4096, 320, 640, 3), (1030, 488, 200, 2),
+                                         (64, 160, 160, 1), (8256, 176, 128, 4)])
+def test_linear_wgrad_exact_round_kernel_ragged(ops, M, N, K, split, monkeypatch):
+    """NK_GEMM_W160=2 sends EVERY Linear weight gradient to the 160-row kernel: ragged row / column tiles, token counts that are no multiple
+    of 64, one-slab reductions, both tile widths, K splits (NK_GEMM_W160_SPLIT: atomics into a zeroed destination) -- with the bias gradient."""
+    monkeypatch.setenv("NK_GEMM_W160", "2")
+    monkeypatch.setenv("NK_GEMM_W160_SPLIT", str(split))
+    dy, x = rnd(M, N, seed=3 * M + N), rnd(M, K, seed=K + 5)
+    dyd, xd = dev(dy), dev(x)
+    ref, refb = dy.t() @ x, dy.sum(0)
+    dw, db = torch.full((N, K), 7.0, device="cuda"), torch.full((N,), -3.0, device="cuda")
+    ops.gemm_tn_f32(dyd, xd, dw, False, dbias=db)
+    assert_close(dw, ref, TOL_F32, "w160 ragged wgrad (store)")
+    assert_close(db, refb, TOL_F32, "w160 ragged bias gradient (store)")
+    ops.gemm_tn_f32(dyd, xd, dw, True, dbias=db)
+    assert_close(dw, 2 * ref, TOL_F32, "w160 ragged wgrad (accumulate)")
+    assert_close(db, 2 * refb, TOL_F32, "w160 ragged bias gradient (accumulate)")
+    dw2 = torch.full((N, K), 7.0, device="cuda")
+    ops.gemm_tn_f32(dyd, xd, dw2, False)              # without the bias gradient
+    assert_close(dw2, ref, TOL_F32, "w160 ragged wgrad, no bias")
+
+
 @pytest.mark.parametrize("sk_mode", ["1", "2", "3"])
 def test_fused_bias_gradient_survives_the_stream_k_switch(ops, sk_mode, monkeypatch):
     """NK_GEMM_SK=1|2|3 routes fp32-output weight gradients to the stream-K kernel, which has no bias row sum: a launch that carries a
