@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 const char* nk_last_error(void);
-int nk_abi_version(void);
+int nk_abi_version(void);     /* 4 (round 6; bumped whenever entry points are added or change: round 5 added three without a bump) */
 
 /* ------------------------------------------------------------------------------------------------
  * nn.Linear  (modules/attention.py:53,65,70,204-209,283-290,618,639; modules/diffusion/openaimodel.py:273-279,

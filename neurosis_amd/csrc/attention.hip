@@ -555,41 +555,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
     constexpr bool FIRST = decltype(first_tag)::value, MASKED = decltype(masked_tag)::value;
     constexpr int ISSUE = decltype(issue_tag)::value;
     const bool more = ISSUE == 2 || t + 2 < nt;
-    if constexpr (ISSUE == 2) {
-      dk.issue_whole(Kb + (long)(t + 2) * 64 * p.sk, smem + sn, wave);
-      dv.issue_whole(Vb + (long)(t + 2) * 64 * p.sv, smem + sn + TILE, wave);
-    } else if (more) {
-      dk.issue(Kb, p.sk, (t + 2) * 64, p.Lk, smem + sn, wave, lane);
-      dv.issue(Vb, p.sv, (t + 2) * 64, p.Lk, smem + sn + TILE, wave, lane);
-    }
     const unsigned kt = smem_a + so, vt = kt + TILE;
     float16_t s[2];
-    // S'^T[key][q] = K Q'^T - m: all eight K fragments in one batch, one wait, eight MFMAs; the chains start from the -m block
-    auto scores = [&]() {
-      bf16x8_t kf[2][4];
-      const unsigned k0 = kt + kab[0], k1 = kt + kab[1], k2 = kt + kab[2], k3 = kt + kab[3];
-      A64_RD128(kf[0][0], k0, 0); A64_RD128(kf[0][1], k1, 0); A64_RD128(kf[0][2], k2, 0); A64_RD128(kf[0][3], k3, 0);
-      A64_RD128(kf[1][0], k0, 4096); A64_RD128(kf[1][1], k1, 4096); A64_RD128(kf[1][2], k2, 4096); A64_RD128(kf[1][3], k3, 4096);
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[hf][0], qf[0], negm, 0, 0, 0);
-#pragma unroll
-        for (int ks = 1; ks < 4; ++ks) s[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[hf][ks], qf[ks], s[hf], 0, 0, 0);
-      }
-      if constexpr (MASKED) {   // keys beyond Lk exist only in the last tile; the causal variant (text towers, L = 77) masks every tile
-        const int last = p.causal ? min(p.Lk - 1, q0 + ql) : p.Lk - 1;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[hf][r] = (t * 64 + hf * 32 + acc_row(r, h5)) <= last ? s[hf][r] : NEG_BIG;
-      }
-    };
-    scores();
-    // the V^T fragments of the first 32 keys are requested NOW: they do not depend on P, and the exponentials below cover their latency;
-    // those of the other 32 keys are requested behind them, in front of the first half's MFMAs (16 registers live at a time, not 32)
     short4_t vlo[2][2][2], vhi[2][2][2];
     const unsigned v00 = vt + vab[0][0], v01 = vt + vab[0][1], v10 = vt + vab[1][0], v11 = vt + vab[1][1];
 #define ATT_RDV(hf, s2)                                                                                                  \
@@ -599,7 +566,51 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
     asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                    \
                  : "+v"(vlo[hf][0][0]), "+v"(vlo[hf][0][1]), "+v"(vlo[hf][1][0]), "+v"(vlo[hf][1][1]), "+v"(vhi[hf][0][0]), "+v"(vhi[hf][0][1]), \
                    "+v"(vhi[hf][1][0]), "+v"(vhi[hf][1][1]))
-    ATT_RDV(0, 0); ATT_RDV(0, 1);
+    // S'^T[key][q] = K Q'^T - m: the chains start from the -m block.  Round 6: a wave's tile time was its own chain of exposed latencies (every
+    // LDS batch awaited right behind its issue, the tile DMA issued first of all, where all twelve waves of the CU ask the fill path at once),
+    // ~2 500 cycles for 584 cycles of issue (tools/attn_stamps.py).  FIRST PASS of a tile: the eight K fragments AND the V^T fragments of the
+    // first 32 keys are requested together (they do not depend on P; 80 transient registers at this point, within the 168), the DMA of tile
+    // t + 2 is issued UNDER that latency (its issue stalls on the fill path, not on the LDS), and the two chains start behind counted waits
+    // for their own four fragments.  The re-computation pass (maximum moved) reads K alone.
+    auto scores = [&](auto first_pass_tag) {
+      constexpr bool FP = decltype(first_pass_tag)::value;
+      bf16x8_t kf[2][4];
+      const unsigned k0 = kt + kab[0], k1 = kt + kab[1], k2 = kt + kab[2], k3 = kt + kab[3];
+      A64_RD128(kf[0][0], k0, 0); A64_RD128(kf[0][1], k1, 0); A64_RD128(kf[0][2], k2, 0); A64_RD128(kf[0][3], k3, 0);
+      A64_RD128(kf[1][0], k0, 4096); A64_RD128(kf[1][1], k1, 4096); A64_RD128(kf[1][2], k2, 4096); A64_RD128(kf[1][3], k3, 4096);
+      if constexpr (FP) {
+        ATT_RDV(0, 0); ATT_RDV(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ISSUE == 2) {
+          dk.issue_whole(Kb + (long)(t + 2) * 64 * p.sk, smem + sn, wave);
+          dv.issue_whole(Vb + (long)(t + 2) * 64 * p.sv, smem + sn + TILE, wave);
+        } else if (more) {
+          dk.issue(Kb, p.sk, (t + 2) * 64, p.Lk, smem + sn, wave, lane);
+          dv.issue(Vb, p.sv, (t + 2) * 64, p.Lk, smem + sn + TILE, wave, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][0], qf[0], negm, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[ks], s[0], 0, 0, 0);
+      if constexpr (FP) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][0], qf[0], negm, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][ks], qf[ks], s[1], 0, 0, 0);
+      if constexpr (MASKED) {   // keys beyond Lk exist only in the last tile; the causal variant (text towers, L = 77) masks every tile
+        const int last = p.causal ? min(p.Lk - 1, q0 + ql) : p.Lk - 1;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[hf][r] = (t * 64 + hf * 32 + acc_row(r, h5)) <= last ? s[hf][r] : NEG_BIG;
+      }
+    };
+    scores(std::true_type{});
     float lsum = 0.f;
     bool redo = FIRST;
     if constexpr (!FIRST) {
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_fwd_kernel(const AttnParams
           lsum += s[hf][r];
         }
       redo = __any(!(lsum <= RESCALE_SUM));
-      if (redo) scores();      // (the V fragments requested above simply arrive earlier)
+      if (redo) scores(std::false_type{});      // (the V fragments requested above simply arrive earlier: this pass's waits cover them too)
     }
     if (redo) {
       float mloc = s[0][0];
@@ -793,31 +804,36 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dq_kernel(const AttnPar
     constexpr bool MASKED = decltype(masked_tag)::value;
     constexpr int ISSUE = decltype(issue_tag)::value;
     const bool more = ISSUE == 2 || t + 2 < nt;
-    if constexpr (ISSUE == 2) {
-      dk_.issue_whole(Kb + (long)(t + 2) * 64 * p.sk, smem + sn, wave);
-      dv_.issue_whole(Vb + (long)(t + 2) * 64 * p.sv, smem + sn + TILE, wave);
-    } else if (more) {
-      dk_.issue(Kb, p.sk, (t + 2) * 64, p.Lk, smem + sn, wave, lane);
-      dv_.issue(Vb, p.sv, (t + 2) * 64, p.Lk, smem + sn + TILE, wave, lane);
-    }
     const unsigned kt = smem_a + so, vt = kt + TILE;
     const unsigned k0 = kt + kab[0], k1 = kt + kab[1], k2 = kt + kab[2], k3 = kt + kab[3];
     const unsigned v0 = vt + kab[0], v1 = vt + kab[1], v2 = vt + kab[2], v3 = vt + kab[3];
     const unsigned t00 = kt + ktb[0][0], t01 = kt + ktb[0][1], t10 = kt + ktb[1][0], t11 = kt + ktb[1][1];
     auto half = [&](auto hf_tag) {
       constexpr int hf = decltype(hf_tag)::value;
-      // register budget (168 at three waves per SIMD): at most 48 transient registers beside Q', dO, -lse2 and dQ -- the K rows die into S
-      // before the V rows are requested, the K^T fragments are requested once S is the only other tile alive
+      // register budget (168 at three waves per SIMD): at most 48 transient registers beside Q', dO, -lse2 and dQ.  Round 6: the K rows AND
+      // the V rows of the half are requested together (K, V, S = 48; dP starts once the K rows have died into S), the DMA of tile t + 2 is
+      // issued under that latency (first half), and each chain waits for its own four fragments only -- a wave's tile used to be a chain of
+      // six exposed LDS round trips behind a DMA issue that met all twelve waves of the CU at the fill path.
       bf16x8_t kf[4], vf[4];
       A64_RD128(kf[0], k0, hf * 4096); A64_RD128(kf[1], k1, hf * 4096); A64_RD128(kf[2], k2, hf * 4096); A64_RD128(kf[3], k3, hf * 4096);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
+      A64_RD128(vf[0], v0, hf * 4096); A64_RD128(vf[1], v1, hf * 4096); A64_RD128(vf[2], v2, hf * 4096); A64_RD128(vf[3], v3, hf * 4096);
+      if constexpr (hf == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ISSUE == 2) {
+          dk_.issue_whole(Kb + (long)(t + 2) * 64 * p.sk, smem + sn, wave);
+          dv_.issue_whole(Vb + (long)(t + 2) * 64 * p.sv, smem + sn + TILE, wave);
+        } else if (more) {
+          dk_.issue(Kb, p.sk, (t + 2) * 64, p.Lk, smem + sn, wave, lane);
+          dv_.issue(Vb, p.sv, (t + 2) * 64, p.Lk, smem + sn + TILE, wave, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
       __builtin_amdgcn_sched_barrier(0);
       float16_t s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negl, 0, 0, 0);
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
-      A64_PIN(s);
       __builtin_amdgcn_sched_barrier(0);
-      A64_RD128(vf[0], v0, hf * 4096); A64_RD128(vf[1], v1, hf * 4096); A64_RD128(vf[2], v2, hf * 4096); A64_RD128(vf[3], v3, hf * 4096);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
       __builtin_amdgcn_sched_barrier(0);
       float16_t dp;
@@ -959,36 +975,37 @@ __global__ __launch_bounds__(NW * 64, 3) void attn64_bwd_dkdv_kernel(const AttnP
     constexpr bool MASKED = decltype(masked_tag)::value;
     constexpr int ISSUE = decltype(issue_tag)::value;
     const bool more = ISSUE == 2 || t + 2 < nt;
-    if constexpr (ISSUE == 2) issue_tile((t_lo + t + 2) * 32, smem + sn, true);
-    else if (more) issue_tile((t_lo + t + 2) * 32, smem + sn, false);
     const unsigned qt = smem_a + so, dot = qt + TILE, st = qt + stat_a;
-    // register budget (168 at three waves per SIMD): K, V, dK, dV take 96; at most 48 transient registers at any point
+    // register budget (168 at three waves per SIMD): K, V, dK, dV take 96; at most 48 transient registers at any point.  Round 6: the row
+    // constants of BOTH chains and the Q' rows are requested together (48), the DMA of tile t + 2 is issued under the S chain's four MFMAs,
+    // the dO rows are requested behind it, and every chain waits for its own operands only.
     float16_t s, dp;
     {
-      float4_t c0, c1, c2, c3;
-      bf16x8_t qr[4];
+      float4_t c0, c1, c2, c3, e0, e1, e2, e3;
+      bf16x8_t qr[4], dr[4];
       A64_RD128(c0, st, 0); A64_RD128(c1, st, 32); A64_RD128(c2, st, 64); A64_RD128(c3, st, 96);
       A64_RD128(qr[0], qt + rab[0], 0); A64_RD128(qr[1], qt + rab[1], 0); A64_RD128(qr[2], qt + rab[2], 0); A64_RD128(qr[3], qt + rab[3], 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      A64_RD128(e0, st, 128); A64_RD128(e1, st, 160); A64_RD128(e2, st, 192); A64_RD128(e3, st, 224);
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(qr[0]), "+v"(qr[1]), "+v"(qr[2]), "+v"(qr[3]));
       __builtin_amdgcn_sched_barrier(0);
       s = __builtin_shufflevector(__builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(c2, c3, 0, 1, 2, 3, 4, 5, 6, 7),
                                   0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[ks], kf[ks], s, 0, 0, 0);
-      A64_PIN(s);
       __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-      float4_t e0, e1, e2, e3;
-      bf16x8_t dr[4];
-      A64_RD128(e0, st, 128); A64_RD128(e1, st, 160); A64_RD128(e2, st, 192); A64_RD128(e3, st, 224);
+      // (the DMA here, where the Q' rows are dead: issued in front of the chain, beside 48 live transient registers, its address arithmetic
+      // pushed the V fragments into scratch)
+      if constexpr (ISSUE == 2) issue_tile((t_lo + t + 2) * 32, smem + sn, true);
+      else if (more) issue_tile((t_lo + t + 2) * 32, smem + sn, false);
+      __builtin_amdgcn_sched_barrier(0);
       A64_RD128(dr[0], dot + rab[0], 0); A64_RD128(dr[1], dot + rab[1], 0); A64_RD128(dr[2], dot + rab[2], 0); A64_RD128(dr[3], dot + rab[3], 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(dr[0]), "+v"(dr[1]), "+v"(dr[2]), "+v"(dr[3]));
       __builtin_amdgcn_sched_barrier(0);
       dp = __builtin_shufflevector(__builtin_shufflevector(e0, e1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(e2, e3, 0, 1, 2, 3, 4, 5, 6, 7),
                                    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dr[ks], vf[ks], dp, 0, 0, 0);
+      A64_PIN(s);
       A64_PIN(dp);
       __builtin_amdgcn_sched_barrier(0);
     }

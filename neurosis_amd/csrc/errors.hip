@@ -19,7 +19,8 @@ int nk_check_launch(const char* what) {
 }
 
 extern "C" const char* nk_last_error(void) { return g_err; }
-extern "C" int nk_abi_version(void) { return 3; }
+// 4: round 5 added nk_layernorm_bwd_rows / nk_colpart_reduce_batch / nk_layernorm_part_rows without a bump; round 6 adds none
+extern "C" int nk_abi_version(void) { return 4; }
 
 // ---- backward-health word ---------------------------------------------------------------------------------------------
 #include <mutex>

@@ -477,6 +477,72 @@ extern "C" int nk_debug_g2_stamps(unsigned long long* host_out, int nwg) {
 #endif
 
 
+// Lean DMA sources of a DENSE operand (OP_KC / OP_MC) for a producer wave (round 6): OpG2::next_sources spends ~10 vector instructions per
+// piece and slab on bounds selects that are loop-invariant for all but the ragged last slab -- ~100 instructions per slab in a wave that shares
+// its SIMD's issue port with two compute waves whose MFMAs hold it half the time.  Here a piece whose rows are out of range points at the zero
+// page with a step of zero: a whole slab costs one 64-bit add per piece; the ragged last slab and the past-the-end slabs take wave-uniform
+// side branches.  Same pieces, same LDS images, same rotated k order as OpG2.
+template <int MODE, int ROWS, int NSW>
+struct LeanSrcG2 {
+  static_assert(MODE == OP_KC || MODE == OP_MC, "dense operands only");
+  static constexpr int NPC = ROWS / 8, NPW = NPC / NSW, CH = ROWS / 8;
+  static_assert(NPW * NSW == NPC, "every staging wave issues the same number of pieces");
+  const bf16_t* rp[NPW];      // this lane's 16 bytes of the piece in the NEXT slab (the zero page for rows past the operand's end)
+  long st[NPW];               // elements per slab (0 for zero-page pieces)
+  int kk[NPW];                // KC: k offset of the lane's chunk; MC: k-row of the piece inside a slab
+  int nk, klen, kslab, handed;
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int R, int r0, int pw, int lane, int K, int first_slab) {
+    klen = K; nk = (K + BK - 1) / BK; kslab = first_slab; handed = 0;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int pc = pw + NSW * i;
+      bool ok;
+      const bf16_t* src;
+      if constexpr (MODE == OP_KC) {
+        const int row = pc * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (lane >> 3);
+        ok = r0 + row < R;
+        kk[i] = chunk * 8;
+        src = P + (long)(r0 + row) * ld + chunk * 8;
+        st[i] = ok ? (long)BK : 0;
+      } else {
+        const int S = 64 * pc + lane;
+        const int k = S / CH, c = S - k * CH;
+        const int sc = CH == 16 ? (c ^ mc_swz(k)) : (c ^ (((k >> 3) & 1) << 1));
+        ok = r0 + sc * 8 < R;
+        kk[i] = k;
+        src = P + (long)k * ld + r0 + sc * 8;
+        st[i] = ok ? (long)BK * ld : 0;
+      }
+      rp[i] = ok ? src + (long)first_slab * st[i] : (const bf16_t*)nk_zero_page;
+    }
+  }
+  // fire the next slab of the rotated order into `img`, then advance
+  __device__ __forceinline__ void fire_next(char* img, int pw) {
+    const bf16_t* zp = (const bf16_t*)nk_zero_page;
+    if (handed >= nk) {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) __builtin_amdgcn_global_load_lds((nk_gptr)zp, (nk_lptr)(img + (pw + NSW * i) * 1024), 16, 0, 0);
+    } else if (kslab * BK + BK <= klen) {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) __builtin_amdgcn_global_load_lds((nk_gptr)rp[i], (nk_lptr)(img + (pw + NSW * i) * 1024), 16, 0, 0);
+    } else {
+      const int kbase = kslab * BK;
+#pragma unroll
+      for (int i = 0; i < NPW; ++i)
+        __builtin_amdgcn_global_load_lds((nk_gptr)(kbase + kk[i] < klen ? rp[i] : zp), (nk_lptr)(img + (pw + NSW * i) * 1024), 16, 0, 0);
+    }
+    ++handed; ++kslab;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) rp[i] += st[i];
+    if (kslab == nk) {
+      kslab = 0;
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) rp[i] -= (long)nk * st[i];
+    }
+  }
+};
+
 // ---- producer-wave variant (round 4, this session) ---------------------------------------------------------------------------------
 // What the loop above waits for (tools/g2_stamps.py: 1 117 cycles per k-step at 4096 x 1280 x 1280 against an MFMA floor of 640): a wave
 // issues IN ORDER, and an LDS-DMA instruction does not issue until the 64 B / clk / CU fill path takes it.  A slab is 36 KiB = 562 cycles of
@@ -517,6 +583,32 @@ __global__ __launch_bounds__(768, 1) void nk_gemm_g2p_kernel(const NkGemmParams 
   if (wave >= 8) {
     // ================= producer: the tile DMA of all 128 + BN_ rows, pieces pw + 4 i =================
     const int pw = wave - 8;
+    if constexpr ((AMODE == OP_KC || AMODE == OP_MC) && (BMODE == OP_KC || BMODE == OP_MC)) {
+      if (p.lean_src) {     // NK_GEMM_LEAN (default 1): dense operands through LeanSrcG2
+        LeanSrcG2<AMODE, 128, 4> la;
+        LeanSrcG2<BMODE, BN_, 4> lb;
+        const int s0 = p.k_rotate ? (xcd * nk) >> 3 : 0;
+        la.init(Ap, p.lda, p.M, m0, pw, lane, p.K, s0);
+        lb.init(Bp, p.ldb, p.N, n0, pw, lane, p.K, s0);
+        constexpr int PPS = LeanSrcG2<AMODE, 128, 4>::NPW + LeanSrcG2<BMODE, BN_, 4>::NPW;
+        la.fire_next(smem, pw); lb.fire_next(smem + 16384, pw);
+        la.fire_next(smem + G2_STAGE_BYTES, pw); lb.fire_next(smem + G2_STAGE_BYTES + 16384, pw);
+        if constexpr (PPS == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // slab 0 landed
+        G2_BAR();
+        unsigned sn = 2 * G2_STAGE_BYTES;                                // stage of slab t + 2
+        for (int t = 0; t < nk; ++t) {
+          la.fire_next(smem + sn, pw);
+          G2_BAR();                                                      // 2t
+          lb.fire_next(smem + sn + 16384, pw);
+          if constexpr (PPS == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // slab t + 1 landed
+          G2_BAR();                                                      // 2t + 1
+          sn += G2_STAGE_BYTES; if (sn == G2_NS * G2_STAGE_BYTES) sn = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G2_BAR();
+        return;
+      }
+    }
     OpG2<AMODE, 128, 4> oa;
     OpG2<BMODE, BN_, 4> ob;
     oa.init(Ap, p.lda, p.M, m0, pw, lane, &p.ga, &p.tw);
@@ -706,6 +798,7 @@ static int launch_g2_as(const NkGemmParams& p_in, hipStream_t stream) {
   p.k_rotate = k_rotate_on(p.K) ? 1 : 0;
   dim3 grid(((p.M + G2_BM - 1) / G2_BM) * ((p.N + BN_ - 1) / BN_), 1, p.nbatch ? p.nbatch : 1);
   if (g2p_enabled()) {
+    { const char* e = getenv("NK_GEMM_LEAN"); p.lean_src = (!e || atoi(e) != 0) ? 1 : 0; }
     auto kp = nk_gemm_g2p_kernel<AMODE, BMODE, OUT_F32, BN_>;
     nk_optin_lds((const void*)kp, G2_SMEM_BYTES);
     hipLaunchKernelGGL(kp, grid, dim3(768), G2_SMEM_BYTES, stream, p);

@@ -41,6 +41,7 @@ struct NkGemmParams {
   int ksplit_len;
   int group_m;              // rows of the XCD-local tile patch (nk_gemm_dma_kernel / nk_gemm_ring_kernel), set by the launcher
   int accumulate;           // fp32 output: 0 = store, 1 = atomic add
+  int lean_src;             // producer-wave two-group kernel: dense operands through LeanSrcG2 (gemm_g2.h), set by the launcher
   int k_rotate;             // two-group kernels: XCD x starts its k loop x / 8 of the way through K and wraps (OpG2::rotate), set by the launcher
   // batched launch: blockIdx.z selects one of nbatch (<= NK_MAX_BATCH) problems of identical shape
   int nbatch;

@@ -89,7 +89,7 @@ def _mark(label: str) -> None:
 
 
 class _Pair:
-    __slots__ = ("g_f", "segments", "static_in", "out", "closure", "dout", "dx", "gen", "warm", "bwd_replays", "tail", "cal")
+    __slots__ = ("g_f", "segments", "static_in", "out", "closure", "dout", "dx", "gen", "warm", "bwd_replays", "tail", "cal", "sk_fp32")
 
     def __init__(self):
         self.g_f = None
@@ -103,6 +103,27 @@ class _Pair:
         self.bwd_replays = 0
         self.tail = None            # indices of the segments whose W_k replays on the MAIN stream behind the last M (see _replay_backward)
         self.cal = None             # events of the calibration replay
+        self.sk_fp32 = False        # stream-K was eligible for fp32 weight gradients WHEN THE W GRAPHS WERE CAPTURED (no tail balancing then)
+
+
+def _stream_k_may_take_fp32() -> bool:
+    """NK_GEMM_SK as gemm.hip reads it (atoi on every call): 0 = never, 4 (default) = bf16 outputs only; 1 / 2 / 3 may hand an fp32 weight
+    gradient to the stream-K kernel, whose per-stream workspace two concurrently replayed W graphs would share"""
+    raw = os.environ.get("NK_GEMM_SK", "4").strip()
+    try:
+        v = int(raw)
+    except ValueError:      # atoi semantics: leading digits, else 0
+        digits = ""
+        for ch in raw:
+            if ch.isdigit() or (ch in "+-" and not digits):
+                digits += ch
+            else:
+                break
+        try:
+            v = int(digits)
+        except ValueError:
+            v = 0
+    return v not in (0, 4)
 
 
 def _sig(t: Optional[Tensor]):
@@ -283,6 +304,7 @@ class ChainGraphs:
         del closure
         held.clear()
         pair.segments = segments
+        pair.sk_fp32 = _stream_k_may_take_fp32()      # the workspace is baked into the graphs now: what the variable says later is irrelevant
 
     def _replay_backward(self, pair: _Pair) -> None:
         """M_0, W_0 | M_1, W_1 | ...: M_k on the main stream, W_k on the side stream behind it.  The main chain ends before the side stream does
@@ -296,8 +318,9 @@ class ChainGraphs:
         # (the stream-K workspace -- flags, tile counter, partial tiles -- is keyed by the launch stream AT CAPTURE TIME and baked into the W
         # graphs: two of them replayed at once would share it.  The default NK_GEMM_SK=4 never gives an fp32 weight gradient to stream-K; under
         # the A/B settings 1 / 2 / 3 it may, so those run without tail balancing: ADVICE round 4)
-        balance = (side is not None and hook is None and os.environ.get("NK_TAIL_BALANCE", "1") != "0"
-                   and os.environ.get("NK_GEMM_SK", "4") in ("0", "4"))
+        # (decided by what held at CAPTURE time -- pair.sk_fp32 -- not by the live variable: tools flip NK_GEMM_SK in-process, and
+        # graphs captured under 1 / 2 / 3 must never be balanced after it goes back to 4)
+        balance = side is not None and hook is None and os.environ.get("NK_TAIL_BALANCE", "1") != "0" and not pair.sk_fp32
         pair.bwd_replays += 1
         if balance and pair.tail is None and pair.cal is not None and pair.cal["done"].query():
             pair.tail = self._plan_tail(pair.cal)

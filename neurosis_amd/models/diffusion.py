@@ -388,7 +388,8 @@ class DiffusionEngine(nn.Module):
         fp32 masters of the other ranks' parts are stale between checkpoints.  Gathering them is a COLLECTIVE (dp.sync_masters()), and a
         state_dict() call is often rank-local (`if rank == 0: torch.save(engine.state_dict())`, EMA / log_images tooling): an implicit
         collective here would deadlock those.  So this never communicates: it raises unless the masters are whole --
-        call `engine.sync_masters()` on EVERY rank first (trainer.lightning's on_save_checkpoint does)."""
+        call `engine.sync_masters()` on EVERY rank first (trainer.lightning.DiffusionEngineMI355X.state_dict(), which Lightning calls on every
+        rank at checkpoint time, does exactly that and says so)."""
         self.join_optimizer()
         dp = getattr(getattr(self, "store", None), "dp", None)
         if dp is not None and dp.sharded and not dp.masters_whole:

@@ -32,7 +32,7 @@ class TimestepBlock(nn.Module):
     """openaimodel.py:52-62."""
 
     def forward(self, x: Tensor, emb: Tensor):
-        raise NotImplementedError("Abstract base class was called ;_;")
+        raise NotImplementedError("TimestepBlock is an interface: subclasses implement forward(x, emb)")
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
@@ -281,9 +281,9 @@ class UNetModel(nn.Module):
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
         if num_heads == -1:
-            assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+            assert num_head_channels != -1, "UNetModel: num_heads = -1 needs num_head_channels"
         if num_head_channels == -1:
-            assert num_heads != -1, "Either num_heads or num_head_channels has to be set"
+            assert num_heads != -1, "UNetModel: num_head_channels = -1 needs num_heads"
         if resblock_updown:
             raise NotImplementedError("resblock_updown=True is not used by the SD/SDXL configs")
         self.in_channels = in_channels
@@ -296,12 +296,12 @@ class UNetModel(nn.Module):
             self.num_res_blocks = len(channel_mult) * [num_res_blocks]
         else:
             if len(num_res_blocks) != len(channel_mult):
-                raise ValueError("provide num_res_blocks either as an int (globally constant) or as a list/tuple (per-level) with the same length as channel_mult")
+                raise ValueError(f"UNetModel: num_res_blocks is an int or one entry per level ({len(channel_mult)}), got {num_res_blocks!r}")
             self.num_res_blocks = num_res_blocks
         if disable_self_attentions is not None and len(disable_self_attentions) != len(channel_mult):
-            raise ValueError("disable_self_attentions should be a list/tuple with the same length as channel_mult")
+            raise ValueError(f"UNetModel: disable_self_attentions needs one entry per level ({len(channel_mult)})")
         if num_attention_blocks is not None and len(num_attention_blocks) != len(self.num_res_blocks):
-            raise ValueError("provide num_attention_blocks as a list/tuple (per-level) with the same length as num_res_blocks")
+            raise ValueError("UNetModel: num_attention_blocks needs one entry per level, like num_res_blocks")
 
         self.attention_resolutions = attention_resolutions
         self.dropout = dropout
@@ -319,7 +319,7 @@ class UNetModel(nn.Module):
         if self.num_classes is not None:
             if self.num_classes == "sequential":
                 if adm_in_channels is None:
-                    raise ValueError("adm_in_channels should be provided when num_classes is set to 'sequential'")
+                    raise ValueError("UNetModel: num_classes='sequential' needs adm_in_channels (the width of the vector conditioning)")
                 self.label_emb = nn.Sequential(nn.Sequential(nn.Linear(adm_in_channels, time_embed_dim), nn.SiLU(), nn.Linear(time_embed_dim, time_embed_dim)))
             else:
                 raise NotImplementedError(f"num_classes={self.num_classes!r}: only 'sequential' (SDXL) and None (SD1.5) are on the path")
@@ -336,7 +336,6 @@ class UNetModel(nn.Module):
             return ResBlock(cin, time_embed_dim, dropout, out_channels=cout, dims=dims, use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm)
 
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))])
-        self._feature_size = model_channels
         input_block_chans = [model_channels]
         ch = model_channels
         ds = 1
@@ -349,7 +348,6 @@ class UNetModel(nn.Module):
                     if num_attention_blocks is None or nr < num_attention_blocks[level]:
                         layers.append(make_st(ch, transformer_depth[level], disabled_sa))
                 self.input_blocks.append(TimestepEmbedSequential(*layers))
-                self._feature_size += ch
                 input_block_chans.append(ch)
             if level != len(channel_mult) - 1:
                 out_ch = ch
@@ -357,14 +355,12 @@ class UNetModel(nn.Module):
                 ch = out_ch
                 input_block_chans.append(ch)
                 ds *= 2
-                self._feature_size += ch
 
         self.middle_block = TimestepEmbedSequential(
             res(ch, ch),
             make_st(ch, transformer_depth_middle, disable_middle_self_attn) if not disable_middle_transformer else nn.Identity(),
             res(ch, ch),
         )
-        self._feature_size += ch
 
         self.output_blocks = nn.ModuleList([])
         for level, mult in list(enumerate(channel_mult))[::-1]:
@@ -381,7 +377,6 @@ class UNetModel(nn.Module):
                     layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=out_ch))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
-                self._feature_size += ch
 
         self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
         self.input_blocks[0]._nk_input_block = True
@@ -539,7 +534,7 @@ class UNetModel(nn.Module):
     def forward(self, x: Tensor, timesteps: Optional[Tensor] = None, context: Optional[Tensor] = None, y: Optional[Tensor] = None, **kwargs) -> Tensor:
         """openaimodel.py:803-840: x [N, C, H, W], timesteps [N], context [N, L, context_dim], y [N, adm_in_channels]."""
         if (y is not None) != (self.num_classes is not None):
-            raise ValueError(f"y must be None for non-class-conditional models, got {y=}")
+            raise ValueError(f"UNetModel.forward: this network has no label embedding (num_classes=None) but was given y of shape {tuple(y.shape)}")
         if y is not None:
             assert y.shape[0] == x.shape[0]
         N, Cin, H, W = x.shape

@@ -985,6 +985,12 @@ def attention512_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
     if mode == "1" or (mode == "auto" and L <= ATTN512_FLASH_MAX_L):
         out, b_att = attention_fwd(q, k, v, B, 1, D, need_lse=True)
         return out, (lambda do: b_att(do))
+    # (nk_softmax_rows takes rows of whole 16-byte chunks only -- say so HERE, not in a backward that follows a forward which
+    # accepted the shape.  The recompute form rebuilds P from bf16-ROUNDED scores (gemm_nt writes bf16), not from the flash forward's fp32
+    # scores: at logits of 30-50 the two differ by several per cent per element -- INTEGRATION.md section 6, NK_ATTN512_BWD.)
+    if L % 8:
+        raise ValueError(f"attention512_fwd: the chunked recompute backward (L = {L} > {ATTN512_FLASH_MAX_L} tokens per sample, or NK_ATTN512_BWD=0) "
+                         f"needs L % 8 == 0; NK_ATTN512_BWD=1 selects the flash backward, which takes any length")
     out = attention_fwd(q, k, v, B, 1, D, need_lse=False)[0]
 
     def bwd(do: Tensor):

@@ -130,11 +130,18 @@ class DiffusionEngineMI355X(_Base):
         return None
 
     # -- checkpoints: the reference's state_dict keys live under `engine.`; optimizer state rides along ------------------
+    collective_state_dict = True      # False: state_dict() never communicates; under rs_ag it raises while the masters are sharded (as the engine's)
+
     def state_dict(self, *args, **kwargs):
-        """Lightning's dump_checkpoint calls this on EVERY rank (only rank 0 writes the file), which is what makes the collective safe here
-        and nowhere deeper: under rs_ag the sharded masters / optimizer statistics are made whole first (engine.state_dict() itself never
-        communicates)."""
-        self.engine.sync_masters()
+        """COLLECTIVE under the sharded exchange (dp mode rs_ag): every rank must call it.  Lightning's dump_checkpoint does -- it builds the
+        module's state_dict on EVERY rank and only rank 0 writes the file -- and Lightning offers no earlier all-rank hook (on_save_checkpoint
+        runs after the state_dict is built), so the sharded fp32 masters / optimizer statistics are made whole HERE (engine.sync_masters();
+        engine.state_dict() itself never communicates, and raises while they are not whole).  A rank-LOCAL call -- a rank-zero callback, an export
+        script, an EMA dump -- would therefore hang in the collective: such code either calls `engine.sync_masters()` on every rank first, or sets
+        `collective_state_dict = False`, which turns the hidden collective into the engine's explicit error.  All-reduce mode (the default)
+        never communicates here."""
+        if self.collective_state_dict:
+            self.engine.sync_masters()
         return super().state_dict(*args, **kwargs)
 
     def on_save_checkpoint(self, checkpoint: dict) -> None:
