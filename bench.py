@@ -403,6 +403,7 @@ def parse_args(argv=None):
                     help="N > 1: allreduce = flat all-reduce of every gradient slice, the whole optimizer on every rank (default, what Lightning DDP does); "
                          "rs_ag = every slice reduce-scattered into tensor-aligned parts, optimizer on the owned parts, bf16 shadows all-gathered (neurosis_amd/dp.py)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--alt-timeout", type=float, default=180.0, help="seconds one alternative exchange configuration may take before the line is printed without it")
     ap.add_argument("--alt-steps", type=int, default=5,
                     help="N > 1: behind the timed steps, run this many steps in each of the OTHER exchange configurations (dp-mode x wire dtype) in the "
                          "same process and report them as comm.alt (0 = off)")
@@ -644,46 +645,13 @@ def main(argv=None):
         dist.barrier()
 
     steady_peak = torch.cuda.max_memory_allocated()
-    if comm is not None and args.alt_steps > 0:
-        # VERDICT round 5, item 5: an 8-GPU node is scarce, so the run that measures the default exchange also prices the other ones -- a few
-        # steps each of {allreduce fp32, allreduce bf16 wire, rs_ag}, minus the configuration already timed.  rs_ag goes last (it leaves the
-        # foreign parts' fp32 masters stale); a default of rs_ag makes its masters and statistics whole first.
-        alts = [(m, w) for m, w in (("allreduce", "fp32"), ("allreduce", "bf16"), ("rs_ag", "fp32")) if (m, w) != (dp.mode, args.wire_dtype)]
-        if args.optimizer != "adafactor":
-            alts = [a for a in alts if a[0] != "rs_ag"]
-        comm["alt"] = []
-        for mode_, wire_ in alts:
-            if dp.sharded:
-                dp.sync_masters()
-                eng.adafactor.owned = None          # every rank runs the whole update again (chunks stay cut: no arithmetic changes)
-            dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if wire_ == "bf16" else None, mode=mode_, broadcast_params=False)
-            if dp.sharded:
-                dp.attach_optimizer(eng.adafactor)
-            step()                                  # one untimed step: staging buffers, communicator warm-up of this collective
-            dp.reducer.record_timing = True
-            dp.reducer.take_counts()
-            del comm_marks[:]
-            barrier()
-            ta = time.perf_counter()
-            for _ in range(args.alt_steps):
-                step(mark=True)
-            barrier()
-            dta = time.perf_counter() - ta
-            dp.reducer.record_timing = False
-            tm = torch.tensor([dta], device=device, dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            entry = comm_summary(dp, comm_marks, wire_)
-            entry.update({"steps": args.alt_steps, "ms_per_step": round(float(tm.item()) / args.alt_steps * 1e3, 2)})
-            comm["alt"].append(entry)
-        if world > 1:
-            dist.barrier()
-    if world > 1 or forced:
-        # every collective is behind us: the group is taken down BEFORE rank 0 spends ~10 s on the CPU baseline, so that no rank sits in a
-        # collective (or its watchdog) while another one is busy on the host
-        dist.destroy_process_group()
-    if rank == 0:
-        cpu = None if args.no_cpu_baseline else cpu_baseline()
+    emitted = []
+
+    def emit(cpu):
+        """rank 0's ONE JSON line (idempotent: the watchdog of the alternative-exchange phases may get here first)"""
+        if emitted:
+            return
+        emitted.append(True)
         out = {
             "metric": "train images/sec (node) SDXL 1024^2", "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -698,6 +666,74 @@ def main(argv=None):
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+
+    alt_failed = False
+    if comm is not None and args.alt_steps > 0:
+        # VERDICT round 5, item 5: an 8-GPU node is scarce, so the run that measures the default exchange also prices the other ones -- a few
+        # steps each of {allreduce fp32, allreduce bf16 wire, rs_ag}, minus the configuration already timed.  rs_ag goes last (it leaves the
+        # foreign parts' fp32 masters stale); a default of rs_ag makes its masters and statistics whole first.
+        # These phases run collectives no multi-GPU box has executed yet (rs_ag on RCCL at world > 1), and the timed result above must survive
+        # them: an exception is recorded in comm.alt and ends the phases (no further collective is attempted); a phase that does not finish
+        # within --alt-timeout seconds makes EVERY rank's watchdog print (rank 0) and leave with exit code 0.
+        import threading
+
+        def bail():
+            comm["alt_error"] = f"an alternative exchange configuration did not finish within {args.alt_timeout} s; the line was printed without it"
+            if rank == 0:
+                emit(None)
+            sys.stdout.flush()
+            os._exit(0)
+
+        alts = [(m, w) for m, w in (("allreduce", "fp32"), ("allreduce", "bf16"), ("rs_ag", "fp32")) if (m, w) != (dp.mode, args.wire_dtype)]
+        if args.optimizer != "adafactor":
+            alts = [a for a in alts if a[0] != "rs_ag"]
+        comm["alt"] = []
+        for mode_, wire_ in alts:
+            timer = threading.Timer(args.alt_timeout, bail)
+            timer.daemon = True
+            timer.start()
+            try:
+                if dp.sharded:
+                    dp.sync_masters()
+                    eng.adafactor.owned = None          # every rank runs the whole update again (chunks stay cut: no arithmetic changes)
+                dp = FlatDataParallel(unet, eng.store, wire_dtype=torch.bfloat16 if wire_ == "bf16" else None, mode=mode_, broadcast_params=False)
+                if dp.sharded:
+                    dp.attach_optimizer(eng.adafactor)
+                step()                                  # one untimed step: staging buffers, communicator warm-up of this collective
+                dp.reducer.record_timing = True
+                dp.reducer.take_counts()
+                del comm_marks[:]
+                barrier()
+                ta = time.perf_counter()
+                for _ in range(args.alt_steps):
+                    step(mark=True)
+                barrier()
+                dta = time.perf_counter() - ta
+                dp.reducer.record_timing = False
+                tm = torch.tensor([dta], device=device, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                entry = comm_summary(dp, comm_marks, wire_)
+                entry.update({"steps": args.alt_steps, "ms_per_step": round(float(tm.item()) / args.alt_steps * 1e3, 2)})
+                comm["alt"].append(entry)
+            except Exception as e:  # noqa: BLE001 - the measured result must be reported whatever an untested collective path does
+                comm["alt"].append({"mode": mode_, "wire_dtype": wire_, "error": f"{type(e).__name__}: {e}"[:400]})
+                alt_failed = True
+            finally:
+                timer.cancel()
+            if alt_failed:
+                break
+        if world > 1 and not alt_failed:
+            dist.barrier()
+    if (world > 1 or forced) and not alt_failed:
+        # every collective is behind us: the group is taken down BEFORE rank 0 spends ~10 s on the CPU baseline, so that no rank sits in a
+        # collective (or its watchdog) while another one is busy on the host
+        dist.destroy_process_group()
+    if rank == 0:
+        emit(None if args.no_cpu_baseline or alt_failed else cpu_baseline())
+    if alt_failed:      # other ranks may be parked in a collective this rank never joined: no orderly shutdown is possible
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -387,7 +387,7 @@ def test_bench_two_ranks_from_a_bare_shell():
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "0",
-                        "--res", "512", "--batch", "1", "--precomputed-te", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+                        "--res", "512", "--batch", "1", "--precomputed-te", "--no-roofline", "--alt-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -395,3 +395,9 @@ def test_bench_two_ranks_from_a_bare_shell():
     assert out["n_gpus"] == 2 and out["comm"]["world_size"] == 2 and out["config"]["global_batch"] == 2
     assert out["cpu_baseline"] is not None and out["cpu_baseline"]["value"], out["cpu_baseline"]
     assert out["value"] > 0 and out["scaling"] == "weak"
+    # round 6: the same run prices the OTHER exchange configurations behind the timed steps
+    alt = out["comm"]["alt"]
+    assert [(a["mode"], a["wire_dtype"]) for a in alt] == [("allreduce", "bf16"), ("rs_ag", "fp32")], alt
+    assert all(a["ms_per_step"] > 0 and a["collectives_per_step"] > 0 and a["bytes_sent_per_rank_per_step"] > 0 for a in alt), alt
+    assert alt[0]["bytes_sent_per_rank_per_step"] * 2 == out["comm"]["bytes_sent_per_rank_per_step"]          # bf16 wire: half the bytes
+    assert out["comm"]["expected_ms"]["direct_rs_ag_fp32"] > 0

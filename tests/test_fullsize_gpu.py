@@ -327,4 +327,4 @@ def test_full_depth_sdxl_unet_at_config2_sequence_lengths_vs_cpu_oracle():
     """The same step at BASELINE config 2's OWN latent size, 128 x 128 (a 1024^2 image): self-attention over 4096 tokens at the 640-wide level
     and 1024 at the 1280-wide one, the lengths `bench.py` runs (until round 6 L = 4096 was value-checked per op and per
     block only).  Batch 1; the oracle's forward + backward take ~2 minutes on the box's host cores.  Same tolerances as the 64 x 64 case."""
-    _full_depth_sdxl_unet_vs_cpu_oracle(128, floor_matrix=0.99, floor_vector=0.99)
+    _full_depth_sdxl_unet_vs_cpu_oracle(128, floor_matrix=0.993, floor_vector=0.997)     # measured: 0.99471 / 0.99842
