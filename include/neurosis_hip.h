@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 const char* nk_last_error(void);
-int nk_abi_version(void);     /* 4 (round 6; bumped whenever entry points are added or change: round 5 added three without a bump) */
+int nk_abi_version(void);     /* 5 (round 6: + the four *_geglu*_s entry points; bumped whenever entry points are added or change) */
 
 /* ------------------------------------------------------------------------------------------------
  * nn.Linear  (modules/attention.py:53,65,70,204-209,283-290,618,639; modules/diffusion/openaimodel.py:273-279,
@@ -48,6 +48,16 @@ int nk_linear_fwd_geglu(const void* x, const void* w, const float* bias, void* u
                         long ldh, void* stream);
 int nk_linear_dgrad_geglu(const void* dy, const void* w, const void* u, void* du, int M, int N, int I, long lddy, long ldw, long ldu,
                           long lddu, void* stream);
+/* The same pair on the SAVED-DERIVATIVE form of the projection output (round 6).  torch autograd, which is what backs FeedForward in the
+ * reference (modules/attention.py:50-74; no backward source), saves a and g and evaluates gelu'(g) in the backward; here the forward -- which
+ * has the normal cdf and its exponential in registers already -- writes s[M, 2I] = [gelu(g) | a * gelu'(g)] INSTEAD of u = [a | g] (u itself is
+ * never written), and the input gradient of net[2] becomes du[M, 2I] = [d * s[:, :I] | d * s[:, I:]]: two products per element where the
+ * erf-GELU derivative took ~22 vector instructions beside an idle matrix pipe.  s is rounded to bf16 like every stored activation.
+ * nk_linear_fwd_geglu_s takes the shapes nk_linear_fwd_geglu_ok() accepts; elsewhere: nk_linear_fwd then nk_geglu_fwd_s. */
+int nk_linear_fwd_geglu_s(const void* x, const void* w, const float* bias, void* s, void* h, int M, int I, int K, long ldx, long ldw, long lds,
+                          long ldh, void* stream);
+int nk_linear_dgrad_geglu_s(const void* dy, const void* w, const void* s, void* du, int M, int N, int I, long lddy, long ldw, long lds,
+                            long lddu, void* stream);
 int nk_linear_wgrad(const void* dy, const void* x, float* dw, int M, int N, int K, long lddy, long ldx,
                     long lddw, int accumulate, void* stream);
 /* ... with the bias gradient dbias[N] (+)= column sums of dy from the same launch: the weight-gradient kernel already stages the dy panel;
@@ -223,6 +233,9 @@ int nk_layernorm_bwd_params(const void* dy, const void* x, const float* mean, co
 /* GEGLU (attention.py:55-57): y[M][I] = u[:, :I] * gelu_erf(u[:, I:]) */
 int nk_geglu_fwd(const void* u, void* y, long M, int I, void* stream);
 int nk_geglu_bwd(const void* dy, const void* u, void* du, long M, int I, void* stream);
+/* ... and in the saved-derivative form: y = a * gelu(g), s[M][2I] = [gelu(g) | a * gelu'(g)] from u = [a | g] (s may alias u); du = [dy * s1 | dy * s2] */
+int nk_geglu_fwd_s(const void* u, void* y, void* s, long M, int I, void* stream);
+int nk_geglu_bwd_s(const void* dy, const void* s, void* du, long M, int I, void* stream);
 
 /* nn.SiLU on a flat bf16 array (openaimodel.py:274,588,615) */
 int nk_silu_fwd(const void* x, void* y, long n, void* stream);

@@ -48,6 +48,58 @@ __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __
     *(uint4_t*)(du + row * 2 * I + I + ch * 8) = pack8(dg);
   }
 }
+// saved-derivative form (round 6): y = a gelu(g) and s = [gelu(g) | a gelu'(g)] from u = [a | g] (s may BE u: every thread rewrites the two
+// chunks it read); the backward is then two products per element
+__global__ void geglu_fwd_s_kernel(const bf16_t* __restrict__ u, bf16_t* __restrict__ y, bf16_t* s, long M, int I) {
+  const int cpr = I >> 3;
+  const long total = M * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i / cpr;
+    int ch = (int)(i - row * cpr);
+    float a[8], g[8], h[8], s1[8], s2[8];
+    unpack8(*(const uint4_t*)(u + row * 2 * I + ch * 8), a);
+    unpack8(*(const uint4_t*)(u + row * 2 * I + I + ch * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float cdf, pdf;
+      normal_cdf_pdf(g[e], cdf, pdf);
+      s1[e] = g[e] * cdf;
+      h[e] = a[e] * s1[e];
+      s2[e] = a[e] * (cdf + g[e] * pdf);
+    }
+    *(uint4_t*)(y + row * I + ch * 8) = pack8(h);
+    *(uint4_t*)(s + row * 2 * I + ch * 8) = pack8(s1);
+    *(uint4_t*)(s + row * 2 * I + I + ch * 8) = pack8(s2);
+  }
+}
+__global__ void geglu_bwd_s_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s, bf16_t* __restrict__ du, long M, int I) {
+  const int cpr = I >> 3;
+  const long total = M * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long row = i / cpr;
+    int ch = (int)(i - row * cpr);
+    float s1[8], s2[8], d[8];
+    unpack8(*(const uint4_t*)(s + row * 2 * I + ch * 8), s1);
+    unpack8(*(const uint4_t*)(s + row * 2 * I + I + ch * 8), s2);
+    unpack8(*(const uint4_t*)(dy + row * I + ch * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] *= d[e]; s2[e] *= d[e]; }
+    *(uint4_t*)(du + row * 2 * I + ch * 8) = pack8(s1);
+    *(uint4_t*)(du + row * 2 * I + I + ch * 8) = pack8(s2);
+  }
+}
+extern "C" int nk_geglu_fwd_s(const void* u, void* y, void* s, long M, int I, void* stream) {
+  NK_CHECK_ARG(u && y && s && M > 0 && I > 0 && (I & 7) == 0);
+  hipLaunchKernelGGL(geglu_fwd_s_kernel, dim3(ew_blocks(M * (I >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)u, (bf16_t*)y,
+                     (bf16_t*)s, M, I);
+  return nk_check_launch("geglu_fwd_s");
+}
+extern "C" int nk_geglu_bwd_s(const void* dy, const void* s, void* du, long M, int I, void* stream) {
+  NK_CHECK_ARG(dy && s && du && M > 0 && I > 0 && (I & 7) == 0);
+  hipLaunchKernelGGL(geglu_bwd_s_kernel, dim3(ew_blocks(M * (I >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)s, (bf16_t*)du, M, I);
+  return nk_check_launch("geglu_bwd_s");
+}
 extern "C" int nk_geglu_fwd(const void* u, void* y, long M, int I, void* stream) {
   NK_CHECK_ARG(u && y && M > 0 && I > 0 && (I & 7) == 0);
   hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_blocks(M * (I >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream,

@@ -20,7 +20,8 @@ int nk_check_launch(const char* what) {
 
 extern "C" const char* nk_last_error(void) { return g_err; }
 // 4: round 5 added nk_layernorm_bwd_rows / nk_colpart_reduce_batch / nk_layernorm_part_rows without a bump; round 6 adds none
-extern "C" int nk_abi_version(void) { return 4; }
+// 5: round 6 adds the saved-derivative GEGLU entry points (nk_linear_fwd_geglu_s, nk_linear_dgrad_geglu_s, nk_geglu_fwd_s, nk_geglu_bwd_s)
+extern "C" int nk_abi_version(void) { return 5; }
 
 // ---- backward-health word ---------------------------------------------------------------------------------------------
 #include <mutex>

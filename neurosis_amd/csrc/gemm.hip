@@ -128,12 +128,17 @@ __device__ __forceinline__ void nk_gemm_epilogue(const NkGemmParams& p, char* sm
         float a[8], g[8], da[8], dg[8];
         unpack8(gu_a[it], a);
         unpack8(gu_g[it], g);
+        if (p.geglu_save) {      // the forward saved s = [gelu(g) | a gelu'(g)]: two products (wave-uniform branch)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float cdf, pdf;
-          normal_cdf_pdf(g[e], cdf, pdf);
-          da[e] = v[e] * (g[e] * cdf);
-          dg[e] = v[e] * a[e] * (cdf + g[e] * pdf);
+          for (int e = 0; e < 8; ++e) { da[e] = v[e] * a[e]; dg[e] = v[e] * g[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float cdf, pdf;
+            normal_cdf_pdf(g[e], cdf, pdf);
+            da[e] = v[e] * (g[e] * cdf);
+            dg[e] = v[e] * a[e] * (cdf + g[e] * pdf);
+          }
         }
         *(uint4_t*)(C + (long)m * p.ldc + n) = pack8(da);
         *(uint4_t*)(C + (long)m * p.ldc + p.N + n) = pack8(dg);
@@ -1559,6 +1564,8 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
     }
     NkGemmParams ph = p;               // the GEGLU output: [M][I], no bias (it is inside a and g already)
     ph.N = I; ph.ldc = p.ld_h; ph.bias = nullptr;
+    NkGemmParams ps = p;               // the saved-derivative form of u: same place and shape, no bias
+    ps.bias = nullptr;
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
       float4_t pa[4][2], pg[4][2], phh[4][2];
@@ -1572,12 +1579,24 @@ __global__ __launch_bounds__(512, 2) void nk_gemm_xl2g_kernel(const NkGemmParams
           for (int r = 0; r < 4; ++r) {
             // what the consumer of u would read: the bf16-rounded a and g
             const float av = bf2f(f2bf(pa[i][q][r] + ba[q][r])), gv = bf2f(f2bf(pg[i][q][r] + bg[q][r]));
-            phh[i][q][r] = av * gelu_erf(gv);
+            float cdf, pdf;
+            normal_cdf_pdf(gv, cdf, pdf);
+            const float ge = gv * cdf;                               // gelu_erf(gv)
+            phh[i][q][r] = av * ge;
+            if (p.geglu_save) {                                      // (wave-uniform) s = [gelu(g) | a gelu'(g)] leaves instead of u = [a | g]
+              pa[i][q][r] = ge;
+              pg[i][q][r] = av * (cdf + gv * pdf);
+            }
           }
         }
       const int mb = m0 + wm * 128 + ib * 64;
-      reg_epilogue_64x32<0>(p, p.C, pa, mb, abase, lane);           // u[:, a-columns]  (+ bias[abase ..])
-      reg_epilogue_64x32<0>(p, p.C, pg, mb, I + abase, lane);       // u[:, I + a-columns]  (+ bias[I + abase ..])
+      if (p.geglu_save) {
+        reg_epilogue_64x32<0>(ps, p.C, pa, mb, abase, lane);        // s[:, a-columns] = gelu(g)
+        reg_epilogue_64x32<0>(ps, p.C, pg, mb, I + abase, lane);    // s[:, I + a-columns] = a gelu'(g)
+      } else {
+        reg_epilogue_64x32<0>(p, p.C, pa, mb, abase, lane);         // u[:, a-columns]  (+ bias[abase ..])
+        reg_epilogue_64x32<0>(p, p.C, pg, mb, I + abase, lane);     // u[:, I + a-columns]  (+ bias[I + abase ..])
+      }
       reg_epilogue_64x32<0>(ph, p.geglu_h, phh, mb, abase, lane);
     }
     return;

@@ -71,6 +71,10 @@ struct NkGemmParams {
   // weight rows of a column tile as 16 a-rows, 16 gate-rows, 16 a-rows, ...: a lane then holds a and g of the same j.
   bf16_t* geglu_h;
   long ld_h;
+  // round 6: 1 = the saved tensor is s = [gelu(g) | a * gelu'(g)] instead of u = [a | g] -- written by the fused forward INSTEAD of u, read by
+  // the fused input gradient as du = [d * s1 | d * s2]: the erf-GELU derivative is evaluated in the forward's epilogue, which has the cdf and
+  // the exponential already
+  int geglu_save;
   // halo-tile 3 x 3 convolution (conv_halo.h)
   int halo_nb;              // images in the batch (0: not a convolution the halo kernel may take)
   float* stats_part;        // statistics epilogue: [halo_nb][pixel tiles per image][2 * stats_groups] partial sums of the OUTPUT

@@ -86,11 +86,18 @@ extern "C" int nk_linear_fwd_geglu(const void* x, const void* w, const float* bi
   return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_KC, 0, 0, (hipStream_t)stream);
 }
 
-extern "C" int nk_linear_dgrad_geglu(const void* dy, const void* w, const void* u, void* du, int M, int N, int I, long lddy, long ldw,
-                                     long ldu, long lddu, void* stream) {
-  // FeedForward backward through net[2] and the GEGLU in one launch (modules/attention.py:60-74): d = dy[M,N] @ w[N,I] is the gradient of
-  // a * gelu(g); the epilogue turns it into du[M, 2I] = [d * gelu(g) | d * a * gelu'(g)] with u = [a | g] [M, 2I] from the forward --
-  // the stand-alone GEGLU backward kernel and its read of d are gone
+extern "C" int nk_linear_fwd_geglu_s(const void* x, const void* w, const float* bias, void* s, void* h, int M, int I, int K, long ldx, long ldw,
+                                     long lds, long ldh, void* stream) {
+  // nk_linear_fwd_geglu with the SAVED-DERIVATIVE form of the projection output: with u = x w^T + bias = [a | g] (never written),
+  // s[M, 2I] = [gelu(g) | a gelu'(g)] and h = a gelu(g) -- what nk_linear_dgrad_geglu_s needs is then two products per element
+  NK_CHECK_ARG(x && w && s && h && M > 0 && I > 0 && K > 0);
+  NkGemmParams p = geglu_fwd_params(x, w, bias, s, h, M, I, K, ldx, ldw, lds, ldh);
+  p.geglu_save = 1;
+  return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_KC, 0, 0, (hipStream_t)stream);
+}
+
+static int dgrad_geglu(const void* dy, const void* w, const void* u, void* du, int M, int N, int I, long lddy, long ldw, long ldu, long lddu, int save,
+                       void* stream) {
   NK_CHECK_ARG(dy && w && u && du && I > 0 && (I & 7) == 0);
   NkGemmParams p = zero_params();
   p.A = (const bf16_t*)dy; p.lda = lddy;
@@ -98,7 +105,22 @@ extern "C" int nk_linear_dgrad_geglu(const void* dy, const void* w, const void* 
   p.M = M; p.N = I; p.K = N;
   p.C = du; p.ldc = lddu;
   p.geglu_u = (const bf16_t*)u; p.ld_u = ldu;
+  p.geglu_save = save;
   return nk_gemm_dispatch(p, NK_OP_KC, NK_OP_MC, 0, 0, (hipStream_t)stream);
+}
+extern "C" int nk_linear_dgrad_geglu_s(const void* dy, const void* w, const void* s, void* du, int M, int N, int I, long lddy, long ldw,
+                                       long lds, long lddu, void* stream) {
+  // nk_linear_dgrad_geglu on the saved-derivative tensor of nk_linear_fwd_geglu_s / nk_geglu_fwd_s: d = dy[M,N] @ w[N,I],
+  // du[M, 2I] = [d * s[:, :I] | d * s[:, I:]]
+  return dgrad_geglu(dy, w, s, du, M, N, I, lddy, ldw, lds, lddu, 1, stream);
+}
+
+extern "C" int nk_linear_dgrad_geglu(const void* dy, const void* w, const void* u, void* du, int M, int N, int I, long lddy, long ldw,
+                                     long ldu, long lddu, void* stream) {
+  // FeedForward backward through net[2] and the GEGLU in one launch (modules/attention.py:60-74): d = dy[M,N] @ w[N,I] is the gradient of
+  // a * gelu(g); the epilogue turns it into du[M, 2I] = [d * gelu(g) | d * a * gelu'(g)] with u = [a | g] [M, 2I] from the forward --
+  // the stand-alone GEGLU backward kernel and its read of d are gone
+  return dgrad_geglu(dy, w, u, du, M, N, I, lddy, ldw, ldu, lddu, 0, stream);
 }
 
 static int linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, int M, int N, int K, long lddy, long ldx, long lddw,

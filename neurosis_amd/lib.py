@@ -46,6 +46,8 @@ SIGNATURES: dict[str, list] = {
     "nk_linear_dgrad": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "nk_linear_dgrad_geglu": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "nk_linear_fwd_geglu": [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
+    "nk_linear_fwd_geglu_s": [vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
+    "nk_linear_dgrad_geglu_s": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "nk_linear_wgrad": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp],
     "nk_linear_fwd_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, vp],
     "nk_linear_wgrad_batched": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i64, i64, i64, i32, vp],
@@ -75,6 +77,8 @@ SIGNATURES: dict[str, list] = {
     "nk_layernorm_bwd_params": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "nk_geglu_fwd": [vp, vp, i64, i32, vp],
     "nk_geglu_bwd": [vp, vp, vp, i64, i32, vp],
+    "nk_geglu_fwd_s": [vp, vp, vp, i64, i32, vp],
+    "nk_geglu_bwd_s": [vp, vp, vp, i64, i32, vp],
     "nk_silu_fwd": [vp, vp, i64, vp],
     "nk_gelu_fwd": [vp, vp, i64, i32, vp],
     "nk_leaky_relu_fwd": [vp, vp, i64, f32, vp],

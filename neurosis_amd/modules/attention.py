@@ -62,13 +62,16 @@ class FeedForward(nn.Module):
         """x_saved / recompute_h (selective recompute, BasicTransformerBlock.recompute): the projection's input is rebuilt by `x_saved()` and
         the GEGLU product h = a * gelu(g) from the kept projection output u when the weight gradients need them; neither is held."""
         proj = self.net[0].proj
-        u, g, b_proj = ops.linear_geglu_fwd(x, proj.weight, proj.bias, x_saved)       # the GEGLU rides in the projection's epilogue where it can
+        # round 6: unless h must be rebuilt from u in backward (selective recompute), the projection's epilogue keeps the saved-derivative
+        # form s = [gelu(g) | a gelu'(g)] instead of u = [a | g]: the backward's epilogue is then two products per element
+        save_s = not recompute_h and ops.geglu_save_enabled()
+        u, g, b_proj = ops.linear_geglu_fwd(x, proj.weight, proj.bias, x_saved, save_derivative=save_s)     # the GEGLU rides in the projection's epilogue where it can
         y, b_out = linear_module_fwd(self.net[2], g, residual, x_saved=(lambda: ops.geglu_fwd(u)[0]) if recompute_h else None)
         del g
 
         def bwd(dy: Tensor):
             # net[2]'s input gradient with the GEGLU backward in its epilogue: one launch, d(a * gelu(g)) never goes to HBM
-            return b_proj(b_out(dy, geglu_u=u))
+            return b_proj(b_out(dy, geglu_s=u) if save_s else b_out(dy, geglu_u=u))
 
         return y, bwd
 

@@ -522,10 +522,18 @@ def linear_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Opti
     return y, _linear_bwd(x if x_saved is None else x_saved, weight, bias, need_dx)
 
 
-def linear_geglu_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_saved=None):
+def geglu_save_enabled() -> bool:
+    """NK_GEGLU_SAVE: 1 (default) = FeedForward keeps s = [gelu(g) | a gelu'(g)] of its projection instead of u = [a | g] (round 6: the GEGLU
+    derivative is evaluated where the cdf already is -- the forward's epilogue -- and the fused input gradient multiplies); 0 = u (A/B runs)"""
+    return os.environ.get("NK_GEGLU_SAVE", "1") != "0"
+
+
+def linear_geglu_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_saved=None, save_derivative: bool = False):
     """FeedForward.net[0] = GEGLU (modules/attention.py:50-57): u = x @ weight^T + bias [M, 2I] and h = u[:, :I] * gelu(u[:, I:]) [M, I].
     One launch (the GEGLU in the projection's epilogue, nk_linear_fwd_geglu) where the 256 x 256 kernel takes the shape -- the two SDXL
-    FeedForward widths at batch 4 -- else the GEMM followed by the GEGLU kernel.  Returns (u, h, bwd); bwd(du) as linear_fwd's."""
+    FeedForward widths at batch 4 -- else the GEMM followed by the GEGLU kernel.  Returns (u, h, bwd); bwd(du) as linear_fwd's.
+    save_derivative: the first result is s = [gelu(g) | a gelu'(g)] [M, 2I] instead of u (u is never written): hand it to the output
+    projection's backward as `geglu_s` (nk_linear_dgrad_geglu_s)."""
     _check2d(x, "x")
     M, K = x.shape
     I2 = weight.shape[0]
@@ -534,18 +542,28 @@ def linear_geglu_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_saved=
     if I2 % 2 == 0 and x.is_contiguous() and query("nk_linear_fwd_geglu_ok", M, I, K):
         u = torch.empty(M, I2, dtype=BF16, device=x.device)
         h = torch.empty(M, I, dtype=BF16, device=x.device)
-        call("nk_linear_fwd_geglu", x.data_ptr(), wq.data_ptr(), _p(bias), u.data_ptr(), h.data_ptr(), M, I, K, x.stride(0), wq.stride(0), u.stride(0), h.stride(0),
-             _stream())
+        call("nk_linear_fwd_geglu_s" if save_derivative else "nk_linear_fwd_geglu", x.data_ptr(), wq.data_ptr(), _p(bias), u.data_ptr(), h.data_ptr(), M, I, K,
+             x.stride(0), wq.stride(0), u.stride(0), h.stride(0), _stream())
     else:
         u = gemm_nt(x, wq, bias, None)
-        h = geglu_fwd(u)[0]
+        if save_derivative:
+            h = torch.empty(M, I, dtype=BF16, device=x.device)
+            call("nk_geglu_fwd_s", u.data_ptr(), h.data_ptr(), u.data_ptr(), M, I, _stream())       # in place: u becomes s
+        else:
+            h = geglu_fwd(u)[0]
     return u, h, _linear_bwd(x if x_saved is None else x_saved, weight, bias, True)
 
 
 def _linear_bwd(x_in, weight: Tensor, bias: Optional[Tensor], need_dx: bool):
-    def bwd(dy: Tensor, dx_add: Optional[Tensor] = None, geglu_u: Optional[Tensor] = None):
+    def bwd(dy: Tensor, dx_add: Optional[Tensor] = None, geglu_u: Optional[Tensor] = None, geglu_s: Optional[Tensor] = None):
         """geglu_u = the [a | g] matrix whose GEGLU produced x (FeedForward): the returned gradient is then d/du [M, 2K], the GEGLU
-        backward applied in the input-gradient GEMM's epilogue (nk_linear_dgrad_geglu)"""
+        backward applied in the input-gradient GEMM's epilogue (nk_linear_dgrad_geglu).  geglu_s = the saved-derivative form
+        [gelu(g) | a gelu'(g)] of linear_geglu_fwd(save_derivative=True) instead (nk_linear_dgrad_geglu_s)."""
+        entry = "nk_linear_dgrad_geglu"
+        if geglu_s is not None:
+            if geglu_u is not None:
+                raise ValueError("linear bwd: geglu_u and geglu_s are exclusive")
+            geglu_u, entry = geglu_s, "nk_linear_dgrad_geglu_s"
         x = x_in() if callable(x_in) else x_in         # (selective recompute: the layer's input is rebuilt now, on the current stream)
         queued = _wgrad_queue is not None and _wgrad_queue.takes(weight) and dy.is_contiguous() and x.is_contiguous()
         # the bias gradient (column sums of dy) comes out of the weight-gradient launch: every parameter gradient is OVERWRITTEN by its
@@ -567,7 +585,7 @@ def _linear_bwd(x_in, weight: Tensor, bias: Optional[Tensor], need_dx: bool):
                 raise ValueError(f"linear bwd: geglu_u must be [{M}, {2 * K}], got {tuple(geglu_u.shape)}")
             du = torch.empty(M, 2 * K, dtype=BF16, device=dy.device)
             wq = w2d(weight)
-            call("nk_linear_dgrad_geglu", dy.data_ptr(), wq.data_ptr(), geglu_u.data_ptr(), du.data_ptr(), M, N, K, dy.stride(0), wq.stride(0),
+            call(entry, dy.data_ptr(), wq.data_ptr(), geglu_u.data_ptr(), du.data_ptr(), M, N, K, dy.stride(0), wq.stride(0),
                  geglu_u.stride(0), du.stride(0), _stream())
             return du
         return gemm_nn(dy, w2d(weight), dx_add)

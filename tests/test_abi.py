@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(l, s), f"{s} declared in include/neurosis_hip.h but not exported"
-    assert l.nk_abi_version() == 4
+    assert l.nk_abi_version() == 5
 
 
 def test_binding_table_matches_header():

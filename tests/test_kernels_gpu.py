@@ -376,6 +376,49 @@ def test_feedforward_out_dgrad_with_fused_geglu_backward(ops, M, N, I):
     assert_close(fused, separate.float().cpu(), TOL_BF16, "fused vs separate")
 
 
+@pytest.mark.parametrize("M,N,I", [(300, 320, 1280), (4096, 1280, 5120), (1000, 136, 264)])
+def test_feedforward_saved_derivative_form(ops, M, N, I, monkeypatch):
+    """Round 6: FeedForward keeps s = [gelu(g) | a gelu'(g)] instead of u = [a | g].  (1) the fused projection's s and h (nk_linear_fwd_geglu_s,
+    where the 256 x 256 kernel takes the shape) are bit for bit what nk_geglu_fwd_s makes of the plain projection's u (unrotated k order), and
+    equal gelu(g), a gelu'(g) from fp32 autograd at bf16 tolerance; (2) the input gradient of net[2] through s (nk_linear_dgrad_geglu_s) matches
+    autograd of (a * gelu(g)) @ W^T and the stand-alone pair nk_linear_dgrad + nk_geglu_bwd_s."""
+    K = N
+    x, wp_, b = rnd(M, K), rnd(2 * I, K, scale=K ** -0.5), rnd(2 * I, scale=0.1, seed=3)
+    wp = torch.nn.Parameter(wp_.float().cuda())
+    bp = torch.nn.Parameter(b.cuda())
+    monkeypatch.setenv("NK_GEMM_KROT", "0")
+    s, h, _ = ops.linear_geglu_fwd(dev(x), wp, bp, save_derivative=True)
+    u2, _ = ops.linear_fwd(dev(x), wp, bp)
+    h2 = torch.empty_like(h)
+    s2 = torch.empty_like(u2)
+    ops.call("nk_geglu_fwd_s", u2.data_ptr(), h2.data_ptr(), s2.data_ptr(), M, I, ops._stream())
+    assert torch.equal(h, h2) and torch.equal(s, s2)
+    assert torch.equal(h, ops.geglu_fwd(u2)[0])                    # the same h as the u-keeping form
+    monkeypatch.delenv("NK_GEMM_KROT")
+    uq = u2.float().cpu().requires_grad_(True)
+    a, g = uq.chunk(2, dim=-1)
+    gl = F.gelu(g)
+    gl.sum().backward()
+    dgelu = uq.grad[:, I:]
+    assert_close(s[:, :I], gl.detach(), TOL_BF16, "s1 = gelu(g)")
+    assert_close(s[:, I:], (a * dgelu).detach(), TOL_BF16, "s2 = a gelu'(g)")
+    # backward through net[2]
+    w2, dy = rnd(N, I, scale=I ** -0.5), rnd(M, N, seed=11)
+    ur = uq.detach().clone().requires_grad_(True)
+    ar, gr = ur.chunk(2, dim=-1)
+    ((ar * F.gelu(gr)) @ w2.t()).backward(dy)
+    weight2 = torch.nn.Parameter(dev(w2).float())
+    y, bwd2 = ops.linear_fwd(h, weight2, None)
+    du = bwd2(dev(dy), geglu_s=s)
+    ops.join_wgrad_stream()
+    assert du.shape == (M, 2 * I)
+    assert_close(du, ur.grad, TOL_BF16, "du through the saved-derivative form")
+    d = ops.gemm_nn(dev(dy), ops.w2d(weight2))
+    du2 = torch.empty_like(du)
+    ops.call("nk_geglu_bwd_s", d.data_ptr(), s.data_ptr(), du2.data_ptr(), M, I, ops._stream())
+    assert_close(du, du2.float().cpu(), TOL_BF16, "fused vs stand-alone, saved-derivative form")
+
+
 def test_geglu_silu_add_cat(ops):
     M, I = 300, 2560
     u = rnd(M, 2 * I).requires_grad_(True)
