@@ -21,6 +21,14 @@ for M, N, I in [(4096, 1280, 5120), (16384, 640, 2560)]:
     fl = 2.0 * M * N * I
     t = bench(lambda: call("nk_linear_dgrad_geglu", dy.data_ptr(), w.data_ptr(), u.data_ptr(), du.data_ptr(), M, N, I, N, I, 2 * I, 2 * I, ops._stream()))
     print(f"dgrad_geglu (fused)          M={M} N={N} I={I}: {t*1e6:7.1f} us = {fl/t/1e12:5.0f} TFLOP/s")
+    ts = bench(lambda: call("nk_linear_dgrad_geglu_s", dy.data_ptr(), w.data_ptr(), u.data_ptr(), du.data_ptr(), M, N, I, N, I, 2 * I, 2 * I, ops._stream()))
+    print(f"dgrad_geglu_s (saved derivative: two products)         : {ts*1e6:7.1f} us = {fl/ts/1e12:5.0f} TFLOP/s")
+    x = torch.randn(M, N, device="cuda").to(torch.bfloat16); w1 = (torch.randn(2 * I, N, device="cuda") * N ** -0.5).to(torch.bfloat16)
+    hbuf = torch.empty(M, I, device="cuda", dtype=torch.bfloat16)
+    if ops.query("nk_linear_fwd_geglu_ok", M, I, N):
+        tf0 = bench(lambda: call("nk_linear_fwd_geglu", x.data_ptr(), w1.data_ptr(), None, u.data_ptr(), hbuf.data_ptr(), M, I, N, N, N, 2 * I, I, ops._stream()))
+        tf1 = bench(lambda: call("nk_linear_fwd_geglu_s", x.data_ptr(), w1.data_ptr(), None, u.data_ptr(), hbuf.data_ptr(), M, I, N, N, N, 2 * I, I, ops._stream()))
+        print(f"fwd_geglu (keeps u) / fwd_geglu_s (keeps s)             : {tf0*1e6:7.1f} / {tf1*1e6:7.1f} us = {2*fl/tf0/1e12:5.0f} / {2*fl/tf1/1e12:5.0f} TFLOP/s")
     t1 = bench(lambda: ops.gemm_nn(dy, w, out=d))
     print(f"plain dgrad, default kernel                     : {t1*1e6:7.1f} us = {fl/t1/1e12:5.0f} TFLOP/s")
     os.environ["NK_GEMM_G2"] = "0"
