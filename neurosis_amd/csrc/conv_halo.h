@@ -28,10 +28,53 @@
 #pragma once
 #include <type_traits>
 
+// Diagnostic build only (make EXTRA=-DNK_HALO_STAMPS; tools/halo_stamps.py): wave 0 of every workgroup (first 8192) stamps s_memtime at entry,
+// behind the prologue's barrier, behind the k loop and behind the drained epilogue, s_memrealtime around the loop; wave 6 (a halo wave) adds
+// the cycles it spent issuing halo pieces.  None of it exists in the shipped library.
+#ifdef NK_HALO_STAMPS
+__device__ unsigned long long nk_halo_stamp_buf[8 * 8192];
+__device__ unsigned long long nk_halo_kstep_buf[3 * 16 * 20 * 5];      // [wave 0 | 4 | 6][workgroup 2048 + i, i < 16][k-step < 20][phase stamp]
+// phase stamps of a k-step: 0 = behind the R barrier (M begins), 1 = weight DMA issued, 2 = MFMAs issued, 3 = behind the M barrier (R begins),
+// 4 = fragment reads + halo pieces issued and the vmcnt wait done (in front of the R barrier of the NEXT k-step)
+#define CH_KSTAMP(t, ph) do { const int w_ = tid >> 6; if ((tid & 63) == 0 && (w_ == 0 || w_ == 4 || w_ == 6) && blockIdx.x >= 2048 && blockIdx.x < 2048 + 16 && (t) < 20) \
+    nk_halo_kstep_buf[((((w_ == 0 ? 0 : (w_ == 4 ? 1 : 2)) * 16 + (blockIdx.x - 2048)) * 20 + (t)) * 5) + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int nk_debug_halo_ksteps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nk_halo_kstep_buf), sizeof(nk_halo_kstep_buf)) == hipSuccess ? 0 : 1;
+}
+#define CH_STAMP(slot) do { if (tid == 0 && blockIdx.x < 8192) nk_halo_stamp_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CH_STAMP_RT(slot) do { if (tid == 0 && blockIdx.x < 8192) nk_halo_stamp_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int nk_debug_halo_stamps(unsigned long long* host_out, int nwg) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nk_halo_stamp_buf), (size_t)nwg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#else
+#define CH_STAMP(slot)
+#define CH_STAMP_RT(slot)
+#define CH_KSTAMP(t, ph)
+#endif
 #define CH_TW 32
 #define CH_HW (CH_TW + 2)
 #define CH_BSTAGE 20480                         // weights of one k-step: up to 160 rows x 128 B
 #define CH_NS 3
+// Round 6: the 128-column tile stages its weights in the R phase, into a ring of FOUR stages.  Phase stamps (tools/halo_stamps.py, the VAE's
+// 128 -> 128 convolution at 1024^2: a k-step of 1 830 cycles against a 1 024-cycle MFMA floor, every k-step alike) put ~450 cycles of stalled
+// weight-DMA issue IN FRONT of the 32 MFMAs of every M phase -- a wave issues in order -- while the R phase ends in 600-900 cycles of waiting
+// at its barrier: the two groups' M phases alternate, so the stall is paid twice per k-step.  Issued behind the fragment reads of the R
+// phase instead, half a k-step earlier, the DMA of k-step t + 2 would race the other group's last reads of k-step t - 1 in a three-stage
+// ring (issued before the barrier, awaited behind it); with four stages it overwrites k-step t - 2's.  (Three k-steps ahead from the M
+// phase was measured first and changed nothing: the weights were never late.)  The 160-column tile has no room for a fourth stage.
+#define CH_BSTAGE_DEEP 16384
+#define CH_NS_DEEP 4
+template <int BN_> struct HaloRing {
+#ifdef NK_HALO_FIRE_IN_M      // diagnostic build: the round-5 arrangement for every tile (A/B runs)
+  static constexpr bool DEEP = false;
+#else
+  static constexpr bool DEEP = BN_ == 128;
+#endif
+  static constexpr int BST = DEEP ? CH_BSTAGE_DEEP : CH_BSTAGE;
+  static constexpr int NS = DEEP ? CH_NS_DEEP : CH_NS;
+  static constexpr int AHEAD = 2;                                     // k-steps between a stage's DMA and its first read
+  static constexpr bool FIRE_IN_R = DEEP;                             // weights of k-step t + 2 issued in the R phase of k-step t (else: its M phase)
+};
 #define CH_NBW 6                                // weight-staging waves (0..5); waves 6, 7 stage the halo
 
 template <int MI>
@@ -42,7 +85,9 @@ struct HaloGeom {
   static constexpr int HPIECES = ((HPX + 7) / 8 + 1) & ~1;            // 1 KiB pieces (8 pixels each), even: 26 / 44
   static constexpr int HBUF = HPIECES * 1024;
   static constexpr int HPW = HPIECES / 2;                             // pieces per halo wave and slab: 13 / 22
-  static constexpr int SMEM = 2 * HBUF + CH_NS * CH_BSTAGE;           // 114688 / 151552
+  static constexpr int SMEM = 2 * HBUF + CH_NS * CH_BSTAGE;           // 114688 / 151552 (the 160-column tile)
+  static constexpr int SMEM_DEEP = 2 * HBUF + CH_NS_DEEP * CH_BSTAGE_DEEP;   // 118784 / 155648 (the 128-column tile's four-stage ring)
+  template <int BN_> static constexpr int smem() { return HaloRing<BN_>::DEEP ? SMEM_DEEP : SMEM; }
 };
 // halo pieces a halo wave issues at tap t when its NPH pieces are spread over taps 0..LAST
 constexpr int ch_count(int NPH, int LAST, int t) { return t > LAST ? 0 : (NPH + LAST - t) / (LAST + 1); }
@@ -85,6 +130,7 @@ template <int BN_, int MI, int STATS>
 __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G = HaloGeom<MI>;
+  using R = HaloRing<BN_>;
   constexpr int HN = BN_ / 2, NJ = HN / 16;          // columns per group; 16-column blocks per wave: 5 or 4
   constexpr int RPW = G::RPW, HPW = G::HPW, HBUF = G::HBUF;
   constexpr int HLAST = 6;                           // last tap at which halo pieces of the next slab are issued
@@ -92,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wq = wave & 3;
   const bool hwave = wave >= CH_NBW;
+  CH_STAMP(0);
 
   const int H = p.ga.H, W = p.ga.W, Cin = p.ga.C, Cout = p.N;
   const int txn = (W + CH_TW - 1) / CH_TW, tyn = (H + G::TH - 1) / G::TH;
@@ -151,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
     for (int i = 0; i < HPW; ++i) fire_halo(i, s0, smem);
   } else {
     wb.fire_next(true, adv_tap, ring, wave);
-    wb.fire_next(nk > 1, adv_tap, ring + CH_BSTAGE, wave);
+    wb.fire_next(nk > 1, adv_tap, ring + R::BST, wave);
   }
 
   FragG2<OP_KC, BN_, NJ> fb;
@@ -181,9 +228,10 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   }
   CH_BAR();
+  CH_STAMP(1); CH_STAMP_RT(4);
   if (grp == 1) { CH_BAR(); }                              // the second group runs one barrier behind
 
-  unsigned so = 0, sn = 2 * CH_BSTAGE;                     // ring stage of k-step t / of k-step t + 2
+  unsigned so = 0, sn = R::AHEAD * R::BST;                 // ring stage of k-step t / of k-step t + AHEAD
   int t = 0;
   int sl = s0;                                             // the channel slab of loop iteration s
   for (int s = 0; s < nslab; ++s) {
@@ -218,19 +266,30 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
         }
         // the next slab's halo has landed (this wave's share): before the barrier that precedes its first use
         if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if constexpr (R::FIRE_IN_R) {
+        constexpr int tap2 = (tap + 2) % 9;
+        wb.fire_next(t + 2 < nk, tap2 == 8 ? adv_end : adv_tap, ring + sn, wave);
+        // the weights of k-step t + 1 have landed (this wave's share); those of t + 2, just issued, stay in flight
+        if (nbw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the weights of k-step t + 1 have landed (this wave's share)
       }
+      CH_KSTAMP(t, 4);
       CH_BAR();
+      CH_KSTAMP(t, 0);
       // ---- M: the wave's MFMAs; weights of k-step t + 2 staged and the sources after them computed in their shadow ----
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      if (!hwave) {
-        // weights of k-step t + 2; the pointer then moves on to k-step t + 3: the next tap, unless t + 2 is a slab's last tap
-        constexpr int tap2 = (tap + 2) % 9;
-        wb.fire_next(t + 2 < nk, tap2 == 8 ? adv_end : adv_tap, ring + sn, wave);
+      if constexpr (!R::FIRE_IN_R) {
+        if (!hwave) {
+          // weights of k-step t + 2; the pointer then moves on to k-step t + 3: the next tap, unless t + 2 is a slab's last tap
+          constexpr int tap2 = (tap + 2) % 9;
+          wb.fire_next(t + 2 < nk, tap2 == 8 ? adv_end : adv_tap, ring + sn, wave);
+        }
       }
+      CH_KSTAMP(t, 1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -239,9 +298,11 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
           for (int j = 0; j < NJ; ++j)     // operands swapped (D = B.A^T): a lane holds 4 consecutive COLUMNS of one row
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks * NJ + j], af[ks * MI + i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      CH_KSTAMP(t, 2);
       CH_BAR();
-      so += CH_BSTAGE; if (so == CH_NS * CH_BSTAGE) so = 0;
-      sn += CH_BSTAGE; if (sn == CH_NS * CH_BSTAGE) sn = 0;
+      CH_KSTAMP(t, 3);
+      so += R::BST; if (so == R::NS * R::BST) so = 0;
+      sn += R::BST; if (sn == R::NS * R::BST) sn = 0;
       ++t;
     };
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
@@ -251,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   }
   if (grp == 0) { CH_BAR(); }                              // ... and the first group waits for it here
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the past-the-end zero-page pieces must land before the LDS is given up
+  CH_STAMP(2); CH_STAMP_RT(5);
 
   // ---- epilogue ----
   // row block i = (tile row wq * RPW + (i >> 1), pixel columns (i & 1) * 16 + (lane & 15)); acc[i][j][r] = its column grp*HN + j*16 + g4*4 + r
@@ -428,6 +490,10 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
       p.stats_part[((long)img * per_img + trem) * 2 * p.stats_groups + 2 * (n0 / cpg + gi) + k] = a;
     }
   }
+#ifdef NK_HALO_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CH_STAMP(3);
+#endif
 #undef CH_BAR
 }
 
@@ -470,10 +536,10 @@ static int launch_halo_as(const NkGemmParams& p_in, hipStream_t stream) {
   NkGemmParams p = p_in;
   p.k_rotate = k_rotate_on(p.ga.C) ? 1 : 0;          // (channel slabs, not k-steps: 512 input channels and up)
   auto kern = nk_conv3x3_halo_kernel<BN_, MI, STATS>;
-  nk_optin_lds((const void*)kern, HaloGeom<MI>::SMEM);
+  nk_optin_lds((const void*)kern, HaloGeom<MI>::template smem<BN_>());
   const NkGather& g = p.ga;
   const long tiles = (long)p.halo_nb * ((g.W + CH_TW - 1) / CH_TW) * ((g.H + HaloGeom<MI>::TH - 1) / HaloGeom<MI>::TH) * (p.N / BN_);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), HaloGeom<MI>::SMEM, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), HaloGeom<MI>::template smem<BN_>(), stream, p);
   return nk_check_launch("nk_conv3x3_halo_kernel");
 }
 template <int STATS>
