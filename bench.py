@@ -130,12 +130,13 @@ class GemmTimer:
 
     NAMES = ("nk_linear_fwd", "nk_linear_dgrad", "nk_linear_wgrad", "nk_conv2d_fwd", "nk_conv2d_dgrad", "nk_conv2d_wgrad",
              "nk_linear_fwd_batched", "nk_linear_wgrad_batched", "nk_conv2d_fwd_stats", "nk_conv2d_dgrad_flipped", "nk_linear_wgrad_bias",
-             "nk_conv2d_wgrad_bias", "nk_linear_dgrad_geglu", "nk_linear_fwd_geglu")
+             "nk_conv2d_wgrad_bias", "nk_linear_dgrad_geglu", "nk_linear_fwd_geglu", "nk_linear_dgrad_geglu_s", "nk_linear_fwd_geglu_s")
     # the batched entry points (several same-shape GEMMs per launch) are reported with the family they belong to; so are the
     # convolutions with a fused GroupNorm statistics epilogue and the input gradients that run as forward convolutions of dy
     FAMILY = {"nk_linear_fwd_batched": "nk_linear_fwd", "nk_linear_wgrad_batched": "nk_linear_wgrad", "nk_conv2d_fwd_stats": "nk_conv2d_fwd",
               "nk_conv2d_dgrad_flipped": "nk_conv2d_dgrad", "nk_linear_wgrad_bias": "nk_linear_wgrad", "nk_conv2d_wgrad_bias": "nk_conv2d_wgrad",
-              "nk_linear_dgrad_geglu": "nk_linear_dgrad", "nk_linear_fwd_geglu": "nk_linear_fwd"}
+              "nk_linear_dgrad_geglu": "nk_linear_dgrad", "nk_linear_fwd_geglu": "nk_linear_fwd",
+              "nk_linear_dgrad_geglu_s": "nk_linear_dgrad", "nk_linear_fwd_geglu_s": "nk_linear_fwd"}     # (round 6: the saved-derivative forms, same arguments)
 
     def __init__(self):
         self.records = []
@@ -149,9 +150,9 @@ class GemmTimer:
             return 2.0 * args[4] * args[5] * args[6]
         if name == "nk_linear_wgrad":
             return 2.0 * args[3] * args[4] * args[5]
-        if name in ("nk_linear_wgrad_bias", "nk_linear_dgrad_geglu"):        # (dy, x | w, dw | u, dbias | du, M, N, K | I, ...)
+        if name in ("nk_linear_wgrad_bias", "nk_linear_dgrad_geglu", "nk_linear_dgrad_geglu_s"):        # (dy, x | w, dw | u, dbias | du, M, N, K | I, ...)
             return 2.0 * args[4] * args[5] * args[6]
-        if name == "nk_linear_fwd_geglu":       # (x, w, bias, u, h, M, I, K, ...): the GEMM is M x 2I x K
+        if name in ("nk_linear_fwd_geglu", "nk_linear_fwd_geglu_s"):       # (x, w, bias, u | s, h, M, I, K, ...): the GEMM is M x 2I x K
             return 2.0 * args[5] * 2 * args[6] * args[7]
         if name == "nk_linear_fwd_batched":     # (ptrs, ptrs, ptrs, count, M, N, K, ...)
             return 2.0 * args[3] * args[4] * args[5] * args[6]

@@ -22,9 +22,9 @@ def flops(name, args):
         key = (f"{name[:-8]}[x{args[4]}]", args[5], args[6], args[7])
     elif name == "nk_linear_wgrad_bias":     # (dy, x, dw, dbias, M, N, K, ...)
         key = (name, args[4], args[5], args[6])
-    elif name == "nk_linear_fwd_geglu":
+    elif name in ("nk_linear_fwd_geglu", "nk_linear_fwd_geglu_s"):
         key = (name, args[5], 2 * args[6], args[7])
-    elif name == "nk_linear_dgrad_geglu":
+    elif name in ("nk_linear_dgrad_geglu", "nk_linear_dgrad_geglu_s"):
         key = (name, args[4], args[6], args[5])
     elif name.startswith("nk_linear"):
         key = (name, args[5], args[6], args[7]) if name == "nk_linear_fwd" else ((name, args[4], args[5], args[6]) if name == "nk_linear_dgrad" else (name, args[3], args[4], args[5]))
