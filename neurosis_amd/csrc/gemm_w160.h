@@ -323,6 +323,20 @@ __global__ __launch_bounds__(512, 1) void nk_gemm_w160_kernel(const NkGemmParams
     rd(std::integral_constant<int, 16>{}); rd(std::integral_constant<int, 17>{});
     if constexpr (NRD == 20) { rd(std::integral_constant<int, 18>{}); rd(std::integral_constant<int, 19>{}); }
   }
+  // ALL of them back before either k loop is entered.  To the compiler an asm read defines its outputs where it stands; the edge into a loop
+  // that keeps fragments in registers across iterations carries the allocator's phi copies of them, and it placed those (for the bias
+  // variant of the loop) straight behind the reads, in front of the loop's first counted wait: the last-requested fragment (A 4) was copied
+  // before its data had returned, and the first sub-step's row 4 ran on whatever the registers held before -- one 16 x 64 block of one
+  // weight gradient wrong about once per hundred steps, seen only when the leftovers were huge (tools/check_async_reads.py
+  // screens the assembly for this).  Naming every fragment "+v" here pins the copies behind the wait; inside the loop the counted waits name theirs.
+  if constexpr (NJ == 5)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[0][0]), "+v"(bhi[0][0]), "+v"(blo[0][1]), "+v"(bhi[0][1]), "+v"(blo[0][2]), "+v"(bhi[0][2]), "+v"(blo[0][3]),
+                 "+v"(bhi[0][3]), "+v"(blo[0][4]), "+v"(bhi[0][4]), "+v"(alo[0][0]), "+v"(ahi[0][0]), "+v"(alo[0][1]), "+v"(ahi[0][1]), "+v"(alo[0][2]),
+                 "+v"(ahi[0][2]), "+v"(alo[0][3]), "+v"(ahi[0][3]), "+v"(alo[0][4]), "+v"(ahi[0][4]));
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[0][0]), "+v"(bhi[0][0]), "+v"(blo[0][1]), "+v"(bhi[0][1]), "+v"(blo[0][2]), "+v"(bhi[0][2]), "+v"(blo[0][3]),
+                 "+v"(bhi[0][3]), "+v"(alo[0][0]), "+v"(ahi[0][0]), "+v"(alo[0][1]), "+v"(ahi[0][1]), "+v"(alo[0][2]), "+v"(ahi[0][2]), "+v"(alo[0][3]),
+                 "+v"(ahi[0][3]), "+v"(alo[0][4]), "+v"(ahi[0][4]));
   __builtin_amdgcn_sched_barrier(0);
   auto k_loop = [&](auto bias_tag) {
     unsigned so = 0;

@@ -144,7 +144,9 @@ def test_selective_recompute_is_neutral_and_saves_memory():
     held0, y0, dx0 = peak(None)
     held1, y1, dx1 = peak("norms")
     # three LayerNorm outputs (3 x 4096 x 1280 bf16 = 31.5 MB) and the GEGLU product (4096 x 5120 bf16 = 42 MB) are no longer held
-    assert y0 == y1 and dx0 == dx1
+    # (the input gradient agrees to rounding, not bit for bit: without the policy the GEGLU backward multiplies by the bf16 [gelu(g) | a gelu'(g)]
+    # the forward saved (ops.geglu_save_enabled), with it by the factors rebuilt in fp32 from the kept projection)
+    assert y0 == y1 and abs(dx0 - dx1) <= 1e-4 * abs(dx0)
     assert held0 - held1 >= 70e6, (held0, held1)
 
 
