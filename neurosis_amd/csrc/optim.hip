@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
   AF_HEALTH_GATE(a);
   __shared__ float red[4];
   __shared__ float colsh[16][AF_TC + 4];
+  __shared__ float rowsh[AF_TR];
   __shared__ unsigned flag[2];
   const NkAfItem it = a.items[a.item_lo + blockIdx.x];
   const NkAfTensor t = a.tensors[it.tensor];
@@ -253,12 +254,18 @@ __global__ __launch_bounds__(256) void af_stats_kernel(const NkAfArgs a) {
         }
         // sum over the 16 column lanes of this row (lanes cx = 0..15 are adjacent within the wave)
         rs += __shfl_xor(rs, 8); rs += __shfl_xor(rs, 4); rs += __shfl_xor(rs, 2); rs += __shfl_xor(rs, 1);
-        if (cx == 0 && r < t.d0) AF_PUBLISH(rowpart + r, rs);
+        // (through LDS, published in one piece below: one coalesced 1 KiB store per block instead of 64 masked 16-byte write-through stores
+        // on the same vmcnt as the next batch of loads; 51.9 -> 50.3 us per 128 MB chunk.  What holds this pass at 2.4 TB/s against the
+        // 4.5 of af_u2_kernel's identical reads is its tail -- two counter round trips and the finishing blocks' reductions, with one
+        // generation of blocks per chunk and nothing to overlap them; bigger chunks run the update faster alone (13.6 -> 11.1 ms) and the
+        // step slower beside the frozen VAE encoder (146.2 -> 147.2 ms): profiles/r06_adafactor_chunks.txt)
+        if (cx == 0) rowsh[ry + 16 * (i0 + u)] = rs;
       }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) colsh[ry][cx * 4 + e] = cs[e];
     __syncthreads();
+    if (it.tr * AF_TR + tid < t.d0) AF_PUBLISH(rowpart + it.tr * AF_TR + tid, rowsh[tid]);      // 256 consecutive floats
     if (tid < AF_TC) {
       const int c = it.tc * AF_TC + tid;
       if (c < t.d1) {
