@@ -45,6 +45,7 @@ def screen_kernel(name, lines):
     seen = set()
     work = [(0, ())]            # (pc, in-flight reads oldest first: (line number, from asm))
     dsts = {}                   # line number of a read -> its destination registers
+    smem = set()                # line numbers of scalar memory reads (out-of-order returns on lgkmcnt)
     budget = 400 * len(lines) + 10000
     while work and budget > 0:
         pc, state = work.pop()
@@ -73,6 +74,10 @@ def screen_kernel(name, lines):
                     n = int(m.group(1))
                 elif "cnt" not in ins.split(None, 1)[1]:                      # raw immediate: lgkmcnt is bits 11:8
                     n = (int(ins.split()[1], 0) >> 8) & 15
+                if n is not None and n > 0 and in_asm and any(r in smem for r, _ in inflight) and any(a for _, a in inflight):
+                    # scalar memory reads share lgkmcnt with LDS and return OUT OF ORDER: with one in flight, a hand-counted lgkmcnt(N > 0) no
+                    # longer says which LDS read is back (the compiler never counts across them; a hand-written wait can)
+                    findings.setdefault((no, -1), (no, ins + "      [counted wait with a scalar memory read in flight]", next(r for r, _ in inflight if r in smem), [0]))
                 if n is not None and n < len(inflight):
                     inflight = inflight[len(inflight) - n:] if n else []
                 continue
@@ -85,9 +90,11 @@ def screen_kernel(name, lines):
             if op.startswith("ds_read") or op.startswith("ds_load"):
                 dsts[no] = regs_of(rest.split(",")[0])
                 inflight.append((no, in_asm))
-            elif op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_memtime") or op.startswith("s_buffer_load"):
+            elif op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_mem") or op.startswith("s_buffer_load"):
                 dsts[no] = set()
                 inflight.append((no, False))                   # counts on lgkmcnt without a vector destination to protect
+                if op.startswith("s_"):
+                    smem.add(no)
             if len(inflight) > 40:
                 inflight = inflight[-40:]
             m = BRANCH.match(text)
