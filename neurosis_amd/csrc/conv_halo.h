@@ -73,8 +73,22 @@ template <int BN_> struct HaloRing {
   static constexpr int BST = DEEP ? CH_BSTAGE_DEEP : CH_BSTAGE;
   static constexpr int NS = DEEP ? CH_NS_DEEP : CH_NS;
   static constexpr int AHEAD = 2;                                     // k-steps between a stage's DMA and its first read
-  static constexpr bool FIRE_IN_R = DEEP;                             // weights of k-step t + 2 issued in the R phase of k-step t (else: its M phase)
+  // Round 6 (late): the 128-column tile hands ALL of its DMA to four PRODUCER WAVES (waves 8-11, one per SIMD beside one wave of each compute
+  // group; the two-group GEMM's arrangement, gemm_g2.h nk_gemm_g2p_kernel).  A group's R phase is bound below by its LDS reads (4 waves x
+  // 16 KiB = 512 cycles at 128 B/clk, as long as the other group's 512-cycle M phase): whatever the same waves spend issuing DMA -- an LDS-DMA
+  // instruction holds the wave's issue until the fill path takes it -- lands on top, in BOTH groups' R phases, twice per k-step.  Waves 8-10
+  // stage the weights (pieces pw + 3 i: 6 / 5 / 5 per k-step), wave 11 the halo (44 / 26 pieces per slab over taps 0-6).  Needs three waves
+  // per SIMD, i.e. <= 168 VGPRs: the 160-column tile (233) keeps the eight-wave form.  -DNK_HALO_NO_PROD: the eight-wave form everywhere (A/B).
+#ifdef NK_HALO_NO_PROD
+  static constexpr bool PROD = false;
+#else
+  static constexpr bool PROD = DEEP;
+#endif
+  static constexpr bool FIRE_IN_R = DEEP && !PROD;                    // weights of k-step t + 2 issued in the R phase of k-step t (else: its M phase)
+  static constexpr int THREADS = PROD ? 768 : 512;
+  static constexpr int WAVES_PER_SIMD = PROD ? 3 : 2;
 };
+#define CH_NPROD_W 3                            // producer waves that stage weights (waves 8, 9, 10); wave 11 stages the halo
 #define CH_NBW 6                                // weight-staging waves (0..5); waves 6, 7 stage the halo
 
 template <int MI>
@@ -94,20 +108,21 @@ constexpr int ch_count(int NPH, int LAST, int t) { return t > LAST ? 0 : (NPH + 
 constexpr int ch_start(int NPH, int LAST, int t) { int s = 0; for (int u = 0; u < t; ++u) s += ch_count(NPH, LAST, u); return s; }
 
 // weights of one k-step: rows = output channels, 64 k of (tap, slab); the KC image of the g2 kernel, staged by waves 0-5
-template <int BN_>
+template <int BN_, int NBW = CH_NBW>
 struct HaloWeights {
   static constexpr int NPC = BN_ / 8;                               // 1 KiB pieces per k-step: 20 or 16
-  static constexpr int NPW = (NPC + CH_NBW - 1) / CH_NBW;           // 4 or 3
+  static constexpr int NPW = (NPC + NBW - 1) / NBW;                 // 4 or 3 (six staging waves); 6 (three producer waves)
   const bf16_t* rp[NPW];
   bool ok[NPW];
-  __device__ __forceinline__ static int pieces(int wave) { return wave >= CH_NBW ? 0 : (wave + CH_NBW * (NPW - 1) < NPC ? NPW : NPW - 1); }
+  // `wave`: index among the staging waves (0 .. NBW-1; anything else stages nothing)
+  __device__ __forceinline__ static int pieces(int wave) { return wave >= NBW ? 0 : (wave + NBW * (NPW - 1) < NPC ? NPW : NPW - 1); }
   __device__ __forceinline__ void init(const bf16_t* Wt, long ld, int Cout, int n0, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-      const int pc = wave + CH_NBW * i;
+      const int pc = wave + NBW * i;
       const int row = pc * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ (lane >> 3);                   // slot (lane & 7) of row (lane >> 3) holds source chunk slot ^ (row & 7)
-      ok[i] = wave < CH_NBW && pc < NPC && n0 + row < Cout;
+      ok[i] = wave < NBW && pc < NPC && n0 + row < Cout;
       rp[i] = Wt + (long)(n0 + (ok[i] ? row : 0)) * ld + chunk * 8;
     }
   }
@@ -117,8 +132,8 @@ struct HaloWeights {
     const bf16_t* zp = (const bf16_t*)nk_zero_page;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-      if (wave + CH_NBW * i < NPC)      // (wave-uniform)
-        __builtin_amdgcn_global_load_lds((nk_gptr)((live && ok[i]) ? rp[i] : zp), (nk_lptr)(img + (wave + CH_NBW * i) * 1024), 16, 0, 0);
+      if (wave + NBW * i < NPC)      // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((nk_gptr)((live && ok[i]) ? rp[i] : zp), (nk_lptr)(img + (wave + NBW * i) * 1024), 16, 0, 0);
       rp[i] += adv;
     }
   }
@@ -127,7 +142,7 @@ struct HaloWeights {
 // MI: 16-pixel row blocks per wave (2: 4 x 32 tiles, 4: 8 x 32 tiles)
 // STATS: 1 = per-tile GroupNorm partial sums of the output written to p.stats_part
 template <int BN_, int MI, int STATS>
-__global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmParams p) {
+__global__ __launch_bounds__(HaloRing<BN_>::THREADS, HaloRing<BN_>::WAVES_PER_SIMD) void nk_conv3x3_halo_kernel(const NkGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G = HaloGeom<MI>;
   using R = HaloRing<BN_>;
@@ -137,7 +152,8 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wq = wave & 3;
-  const bool hwave = wave >= CH_NBW;
+  constexpr bool PROD = HaloRing<BN_>::PROD;           // waves 8-11 own the DMA; the eight compute waves stage nothing
+  const bool hwave = !PROD && wave >= CH_NBW;
   CH_STAMP(0);
 
   const int H = p.ga.H, W = p.ga.W, Cin = p.ga.C, Cout = p.N;
@@ -168,9 +184,12 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
   const unsigned lds0 = (unsigned)(size_t)(lds_c)smem;
   char* const ring = smem + 2 * HBUF;
 
-  // ---- halo staging (waves 6, 7): piece i of a halo wave covers halo pixels hp0 + 8 i (one per 8 lanes), slot lane & 7 of each;
-  // the source of a lane's 16 bytes is recomputed per piece (a dozen scalar-ish VALU instructions) instead of kept in 13 / 22 registers ----
-  const int hp0 = (wave - CH_NBW) * HPW * 8 + (lane >> 3);
+  // ---- halo staging (waves 6, 7; the producer form: wave 11 alone): piece i of a halo wave covers halo pixels hp0 + 8 i (one per 8 lanes),
+  // slot lane & 7 of each; the source of a lane's 16 bytes is recomputed per piece (a dozen scalar-ish VALU instructions) instead of kept in
+  // 13 / 22 registers ----
+  constexpr int HPP = PROD ? G::HPIECES : HPW;            // pieces per halo-staging wave and slab
+  const int hw = PROD ? 0 : wave - CH_NBW;                // index among the halo-staging waves
+  const int hp0 = hw * HPP * 8 + (lane >> 3);
   auto fire_halo = [&](int i, int slab, char* hbuf) {     // piece i of this halo wave, channel slab `slab`
     const int hp = hp0 + 8 * i;
     const int py = hp / CH_HW, px = hp - py * CH_HW;
@@ -178,27 +197,94 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
     const bool v = hp < G::HPX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;      // else padding: the zero page
     const int chunk = (lane & 7) ^ (hp & 7);
     const bf16_t* src = v ? p.A + ((long)((img * H + y) * W + x) * Cin + chunk * 8 + slab * 64) : (const bf16_t*)nk_zero_page;
-    __builtin_amdgcn_global_load_lds((nk_gptr)src, (nk_lptr)(hbuf + ((wave - CH_NBW) * HPW + i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((nk_gptr)src, (nk_lptr)(hbuf + (hw * HPP + i) * 1024), 16, 0, 0);
   };
 
   // ---- weights ----
-  HaloWeights<BN_> wb;
-  wb.init(p.B, p.ldb, Cout, n0, wave, lane);
+  using WB = HaloWeights<BN_, PROD ? CH_NPROD_W : CH_NBW>;
+  const int sw = PROD ? wave - 8 : wave;                  // index among the weight-staging waves (the compute waves of the producer form: none)
+  WB wb;
+  if (!PROD || wave >= 8) wb.init(p.B, p.ldb, Cout, n0, sw, lane);
   const long adv_tap = Cin, adv_slab = 64 - 8l * Cin;
   // rotated slab order (OpG2::rotate in gemm_g2.h has the why: every XCD reads the whole weight tensor -- 29.5 MB for 1280 -> 1280): XCD x walks
   // the channel slabs s0, ..., nslab - 1, 0, ..., s0 - 1, s0 = x nslab / 8; the taps of a slab keep their order
   const int s0 = p.k_rotate ? (xcd * nslab) >> 3 : 0;
   const long adv_wrap = 64 - 9l * Cin;               // from (last slab, tap 8) back to (slab 0, tap 0)
+#define CH_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
+  if constexpr (PROD) {
+    if (wave >= 8) {
+      // ================= producers =================
+      // Barrier b (b = 0: the prologue's) is the boundary the compute groups see: group 0 reads k-step t between barriers 2t and 2t + 1 and
+      // multiplies between 2t + 1 and 2t + 2, group 1 one barrier later; a read issued in an R phase has returned behind the `lgkmcnt(0)` that
+      // opens the M phase, i.e. before the barrier that closes it.  So stage (t + 2) % 4 -- last read as k-step t - 2, by group 1, done
+      // before barrier 2t - 1 -- may be written behind barrier 2t, and must have landed before barrier 2t + 4 (group 0's R of t + 2): the
+      // weight producers fire k-step t + 2 between barriers 2t and 2t + 1 and wait for k-step t + 1 (counted vmcnt: one k-step stays in
+      // flight) between 2t + 1 and 2t + 2.  The halo of slab s + 1 goes into the buffer slab s - 1 was read from, last by group 1 in its R of
+      // k-step 9s - 1, done before barrier 18s + 1: the halo producer fires in the SECOND half of k-steps 9s .. 9s + 6 (behind barrier
+      // 18s + 1 at the earliest) and drains in the second half of k-step 9s + 8, in front of barrier 18s + 18 = group 0's first read of it.
+      const int pw = wave - 8;
+      const bool halo_wave = pw == CH_NPROD_W;
+      const int npw = WB::pieces(pw);                      // 6 / 5 / 5; 0 for the halo producer
+      if (halo_wave) {
 #pragma unroll
-  for (int i = 0; i < HaloWeights<BN_>::NPW; ++i) wb.rp[i] += s0 * 64;
-
-  // ---- prologue loads go out first: halo of slab 0, weights of k-steps 0 and 1 ----
-  if (hwave) {
+        for (int i = 0; i < HPP; ++i) fire_halo(i, s0, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) fire_halo(i, s0, smem);
+        for (int i = 0; i < WB::NPW; ++i) wb.rp[i] += s0 * 64;
+        wb.fire_next(true, adv_tap, ring, pw);
+        wb.fire_next(nk > 1, adv_tap, ring + R::BST, pw);
+        if (npw == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // k-step 0 landed (this wave's pieces)
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      }
+      CH_BAR();                                            // barrier 0
+      unsigned sn = R::AHEAD * R::BST;
+      int t = 0, sl = s0;
+      for (int s = 0; s < nslab; ++s) {
+        char* const hnext = smem + ((s + 1) & 1) * HBUF;
+        const bool more = s + 1 < nslab;
+        const int sln = sl + 1 == nslab ? 0 : sl + 1;
+        const long adv_end = sl + 1 == nslab ? adv_wrap : adv_slab;
+        auto pstep = [&](auto tapc) {
+          constexpr int tap = decltype(tapc)::value;
+          constexpr int tap2 = (tap + 2) % 9;
+          if (!halo_wave) wb.fire_next(t + 2 < nk, tap2 == 8 ? adv_end : adv_tap, ring + sn, pw);
+          CH_BAR();                                        // barrier 2t + 1
+          if (halo_wave) {
+            if (more) {
+              constexpr int cnt = ch_count(HPP, HLAST, tap), st = ch_start(HPP, HLAST, tap);
+#pragma unroll
+              for (int i = 0; i < cnt; ++i) fire_halo(st + i, sln, hnext);
+            }
+            if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          } else {
+            if (npw == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // k-step t + 1 landed; t + 2, just issued, stays in flight
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          }
+          CH_BAR();                                        // barrier 2t + 2
+          sn += R::BST; if (sn == R::NS * R::BST) sn = 0;
+          ++t;
+        };
+        pstep(std::integral_constant<int, 0>{}); pstep(std::integral_constant<int, 1>{}); pstep(std::integral_constant<int, 2>{});
+        pstep(std::integral_constant<int, 3>{}); pstep(std::integral_constant<int, 4>{}); pstep(std::integral_constant<int, 5>{});
+        pstep(std::integral_constant<int, 6>{}); pstep(std::integral_constant<int, 7>{}); pstep(std::integral_constant<int, 8>{});
+        sl = sln;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the past-the-end zero-page pieces must land before the LDS is given up
+      CH_BAR();                                            // barrier 2 nk + 1 (group 1's last)
+      return;
+    }
   } else {
-    wb.fire_next(true, adv_tap, ring, wave);
-    wb.fire_next(nk > 1, adv_tap, ring + R::BST, wave);
+#pragma unroll
+    for (int i = 0; i < WB::NPW; ++i) wb.rp[i] += s0 * 64;
+    // ---- prologue loads go out first: halo of slab 0, weights of k-steps 0 and 1 ----
+    if (hwave) {
+#pragma unroll
+      for (int i = 0; i < HPW; ++i) fire_halo(i, s0, smem);
+    } else {
+      wb.fire_next(true, adv_tap, ring, wave);
+      wb.fire_next(nk > 1, adv_tap, ring + R::BST, wave);
+    }
   }
 
   FragG2<OP_KC, BN_, NJ> fb;
@@ -216,16 +302,17 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
   bf16x8_t af[2 * MI], bfr[2 * NJ];
 
-#define CH_BAR() __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0)
-  const int nbw = HaloWeights<BN_>::pieces(wave);         // weight pieces this wave stages per k-step (0 for the halo waves)
+  const int nbw = PROD ? 0 : WB::pieces(wave);            // weight pieces this wave stages per k-step (0 for the halo waves)
 
   // ---- prologue waits: halo 0 and weights 0 landed for everyone (weights 1 stay in flight) ----
-  if (hwave) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    if (nbw == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (nbw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (!PROD) {
+    if (hwave) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (nbw == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (nbw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
   }
   CH_BAR();
   CH_STAMP(1); CH_STAMP_RT(4);
@@ -245,9 +332,9 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
       constexpr int dy = tap / 3, dx = tap % 3;
       // ---- R: fragment reads of k-step t; halo pieces of slab s + 1; wait for the weights of k-step t + 1 ----
       __builtin_amdgcn_sched_barrier(0);
-      g2_read<OP_KC, BN_, NJ>(bfr, fb, so);
       int hpv = hpl;
       asm volatile("" : "+v"(hpv));          // (opaque: keeps the 9 x RPW tap addresses from being hoisted out of the slab loop into 18-36 registers)
+      g2_read<OP_KC, BN_, NJ>(bfr, fb, so);
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const int hp = hpv + (r + dy) * CH_HW + dx;
@@ -258,7 +345,9 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
         G2_RD128(af[MI + 2 * r], a1, 0);
         G2_RD128(af[MI + 2 * r + 1], a1, 2048);
       }
-      if (hwave) {
+      if constexpr (PROD) {
+        // (nothing to stage, nothing to wait for: the producers publish k-step t + 1 and the next halo behind the barriers)
+      } else if (hwave) {
         if (more) {
           constexpr int cnt = ch_count(HPW, HLAST, tap), st = ch_start(HPW, HLAST, tap);
 #pragma unroll
@@ -282,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void nk_conv3x3_halo_kernel(const NkGemmPar
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      if constexpr (!R::FIRE_IN_R) {
+      if constexpr (!R::FIRE_IN_R && !PROD) {
         if (!hwave) {
           // weights of k-step t + 2; the pointer then moves on to k-step t + 3: the next tap, unless t + 2 is a slab's last tap
           constexpr int tap2 = (tap + 2) % 9;
@@ -539,7 +628,7 @@ static int launch_halo_as(const NkGemmParams& p_in, hipStream_t stream) {
   nk_optin_lds((const void*)kern, HaloGeom<MI>::template smem<BN_>());
   const NkGather& g = p.ga;
   const long tiles = (long)p.halo_nb * ((g.W + CH_TW - 1) / CH_TW) * ((g.H + HaloGeom<MI>::TH - 1) / HaloGeom<MI>::TH) * (p.N / BN_);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), HaloGeom<MI>::template smem<BN_>(), stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(HaloRing<BN_>::THREADS), HaloGeom<MI>::template smem<BN_>(), stream, p);
   return nk_check_launch("nk_conv3x3_halo_kernel");
 }
 template <int STATS>

@@ -74,10 +74,17 @@ def screen_kernel(name, lines):
                     n = int(m.group(1))
                 elif "cnt" not in ins.split(None, 1)[1]:                      # raw immediate: lgkmcnt is bits 11:8
                     n = (int(ins.split()[1], 0) >> 8) & 15
-                if n is not None and n > 0 and in_asm and any(r in smem for r, _ in inflight) and any(a for _, a in inflight):
-                    # scalar memory reads share lgkmcnt with LDS and return OUT OF ORDER: with one in flight, a hand-counted lgkmcnt(N > 0) no
-                    # longer says which LDS read is back (the compiler never counts across them; a hand-written wait can)
-                    findings.setdefault((no, -1), (no, ins + "      [counted wait with a scalar memory read in flight]", next(r for r, _ in inflight if r in smem), [0]))
+                if n is not None and n > 0 and in_asm:
+                    # scalar memory reads share lgkmcnt with LDS and return OUT OF ORDER: one that is YOUNGER than an asm LDS read and returns
+                    # before it lets a hand-counted lgkmcnt(N > 0) pass with that read still outstanding.  (An OLDER one only makes the wait
+                    # longer: the compiler's hoisted kernel-argument loads in front of a loop are fine.)
+                    seen_asm = False
+                    for r, a in inflight:
+                        if a:
+                            seen_asm = True
+                        elif r in smem and seen_asm:
+                            findings.setdefault((no, -1), (no, ins + "      [counted wait with a younger scalar memory read in flight]", r, [0]))
+                            break
                 if n is not None and n < len(inflight):
                     inflight = inflight[len(inflight) - n:] if n else []
                 continue
