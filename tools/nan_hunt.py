@@ -1,7 +1,8 @@
 """Hunt for a rare non-finite value in the metric's step: bench.py's own step (graph replay, both backward streams, the optimizer stream) run for
 many steps; after every backward the loss and the flat gradient buffer are checked, and at the first non-finite one the parameters whose
 gradients hold it are listed in module order (the LAST module in forward order with a bad gradient is where the backward went wrong).
-    python tools/nan_hunt.py [steps] [sync|nosync]
+    python tools/nan_hunt.py [steps] [sync|nosync] [mixed]
+mixed: every step draws one of BASELINE config 4's aspect buckets (bench.MIXED_BUCKETS) instead of 1024 x 1024.
 sync (default): the check is read every step (the host waits for the GPU once per step); nosync: flags stay on the device until the end.
 """
 import os
@@ -14,6 +15,8 @@ import bench  # noqa: E402
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 SYNC = (sys.argv[2] if len(sys.argv) > 2 else "sync") == "sync"
+MIXED = len(sys.argv) > 3 and sys.argv[3] == "mixed"
+gen_cpu = torch.Generator().manual_seed(7)
 args = bench.parse_args([])
 device = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -41,7 +44,8 @@ def report(step):
 
 
 for s in range(STEPS):
-    batch = bench.synthetic_batch(device, args.batch, (args.res, args.res), gen, False)
+    hw = bench.MIXED_BUCKETS[int(torch.randint(len(bench.MIXED_BUCKETS), (1,), generator=gen_cpu))] if MIXED else (args.res, args.res)
+    batch = bench.synthetic_batch(device, args.batch, hw, gen, False)
     sig = bench.draw_sigmas(args.batch, gen, device)
     eng.accumulate(0, None, last=True)
     loss = eng.training_step(batch, 0, sigmas=sig)
