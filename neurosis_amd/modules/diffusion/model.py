@@ -168,8 +168,8 @@ class AttnBlock(nn.Module):
             o, b_att = ops.attention_fwd(q.t, k.t, v.t, x.N, 1, self.in_channels)
         elif self.in_channels == 512:
             o, b_att = ops.attention512_fwd(q.t, k.t, v.t, x.N)       # flash forward; backward recomputes the probabilities chunk by chunk
-        else:
-            raise NotImplementedError(f"AttnBlock backward: {self.in_channels} channels (the SD / SDXL autoencoders use 512; <= 160 also has kernels)")
+        else:       # any other width (a VAE whose last level has 256 or 384 channels): two-GEMM forward, chunked recompute backward
+            o, b_att = ops.attention_anydim_fwd(q.t, k.t, v.t, x.N)
         y, b_p = self.proj_out.fwd(Img(o, x.N, x.H, x.W), residual=x.t)
 
         def bwd(dy: Tensor) -> Tensor:

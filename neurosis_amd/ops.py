@@ -1010,6 +1010,24 @@ def attention512_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
         raise ValueError(f"attention512_fwd: the chunked recompute backward (L = {L} > {ATTN512_FLASH_MAX_L} tokens per sample, or NK_ATTN512_BWD=0) "
                          f"needs L % 8 == 0; NK_ATTN512_BWD=1 selects the flash backward, which takes any length")
     out = attention_fwd(q, k, v, B, 1, D, need_lse=False)[0]
+    return out, _attention_recompute_bwd(q, k, v, B)
+
+
+def attention_anydim_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
+    """Single-head attention of ANY head dim (a multiple of 8) WITH a backward: the reference's AttnBlock trains at whatever channel count the
+    autoencoder's last level has (modules/diffusion/model.py:224-243); head dims <= 160 and 512 have flash kernels (attention_fwd, attention512_fwd),
+    everything else -- a VAE with ch * ch_mult[-1] of 256 or 384 -- takes this form: the two-GEMM forward of attention_unfused and
+    the chunked recompute backward shared with attention512_fwd.  Working set [L, L] bf16 forward, [chunk, L] backward.  q / k / v dense [B*L, D]."""
+    L, D = q.shape[0] // B, q.shape[1]
+    if D % 8 or L % 8:
+        raise ValueError(f"attention_anydim_fwd: head dim and tokens per sample must be multiples of 8, got D = {D}, L = {L}")
+    return attention_unfused(q, k, v, B), _attention_recompute_bwd(q, k, v, B)
+
+
+def _attention_recompute_bwd(q: Tensor, k: Tensor, v: Tensor, B: int):
+    """bwd(do) -> (dq, dk, dv) of single-head attention by recomputing the probabilities chunk by chunk (attention512_fwd has the formulae)."""
+    L, D = q.shape[0] // B, q.shape[1]
+    scale = float(D) ** -0.5
 
     def bwd(do: Tensor):
         _check2d(do, "do")
@@ -1032,7 +1050,7 @@ def attention512_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
             dk[b * L:(b + 1) * L].copy_(cast_bf16(dk32))
         return dq, dk, dv
 
-    return out, bwd
+    return bwd
 
 
 # ------------------------------------------------------------------------------------------------

@@ -75,6 +75,54 @@ def test_attention512_backward_vs_autograd(impl, chunk, B, L, monkeypatch):
         assert e <= 3e-2 and cs >= 0.999, (name, e, cs)
 
 
+@pytest.mark.parametrize("D,B,L,chunk", [(256, 2, 256, 2048), (384, 1, 1024, 2048), (200, 2, 64, 2048), (256, 1, 200, 96)])
+def test_attention_of_any_head_dim_backward_vs_autograd(D, B, L, chunk, monkeypatch):
+    """ops.attention_anydim_fwd: the mid-block attention of an autoencoder whose last level is neither <= 160 nor 512 channels wide
+    (the reference's AttnBlock trains at any width, modules/diffusion/model.py:224-243): two-GEMM forward, chunked recompute backward (one chunk; three
+    ragged chunks), against fp32 autograd; a K-tail width (200) included.  And through the module: AttnBlock(256).fwdb no longer refuses."""
+    from neurosis_amd import ops
+
+    monkeypatch.setattr(ops, "ATTN512_BWD_CHUNK", chunk)
+    g = torch.Generator().manual_seed(2)
+    q, k, v, do = (torch.randn(B * L, D, generator=g).to(torch.bfloat16) for _ in range(4))
+    qr, kr, vr = (t.float().reshape(B, L, D).requires_grad_(True) for t in (q, k, v))
+    ref = ((qr @ kr.transpose(1, 2)) * D ** -0.5).softmax(-1) @ vr
+    ref.backward(do.float().reshape(B, L, D))
+    o, bwd = ops.attention_anydim_fwd(q.cuda(), k.cuda(), v.cuda(), B)
+    assert rel_err(o, ref.reshape(B * L, D)) <= 2e-2
+    for name, got, want in zip("qkv", bwd(do.cuda()), (qr.grad, kr.grad, vr.grad)):
+        e, cs = rel_err(got, want.reshape(B * L, D)), cosine(got, want.reshape(B * L, D))
+        assert e <= 3e-2 and cs >= 0.999, (name, e, cs)
+    with pytest.raises(ValueError):
+        ops.attention_anydim_fwd(q.cuda()[: B * (L - 4)], k.cuda()[: B * (L - 4)], v.cuda()[: B * (L - 4)], B)      # tokens per sample not a multiple of 8
+
+
+def test_attnblock_of_256_channels_trains():
+    from neurosis_amd import ops
+    from neurosis_amd.modules.diffusion.model import AttnBlock
+
+    torch.manual_seed(0)
+    C, N, H, W = 256, 2, 16, 16
+    blk = AttnBlock(C).cuda()
+    for p_ in blk.parameters():
+        p_.data = (p_.data.float() + 0.02 * torch.randn_like(p_.data.float())).to(p_.dtype)
+    x = (torch.randn(N * H * W, C, device="cuda") * 0.5).to(torch.bfloat16)
+    y, bwd = blk.fwdb(ops.Img(x, N, H, W))
+    dy = (torch.randn(N * H * W, C, device="cuda") * 0.1).to(torch.bfloat16)
+    dx = bwd(dy)
+    # fp32 autograd of the same block (GroupNorm 32 groups, 1 x 1 convolutions as linears, softmax attention, residual)
+    xr = x.float().requires_grad_(True)
+    w = {n: p_.detach().float() for n, p_ in blk.named_parameters()}
+    xn = torch.nn.functional.group_norm(xr.reshape(N, H * W, C).transpose(1, 2), blk.norm.num_groups, w["norm.weight"], w["norm.bias"], blk.norm.eps).transpose(1, 2)
+    lin = lambda t, n: t @ w[n + ".weight"].reshape(C, C).t() + w[n + ".bias"]
+    qf, kf, vf = lin(xn, "q"), lin(xn, "k"), lin(xn, "v")
+    of = ((qf @ kf.transpose(1, 2)) * C ** -0.5).softmax(-1) @ vf
+    yr = lin(of, "proj_out").reshape(N * H * W, C) + xr
+    yr.backward(dy.float())
+    assert rel_err(y.t, yr) <= 3e-2 and cosine(y.t, yr) >= 0.999
+    assert rel_err(dx, xr.grad) <= 4e-2 and cosine(dx, xr.grad) >= 0.998
+
+
 @pytest.mark.parametrize("tag", ["rec_only", "rec_kl"])
 def test_reconstruction_step_against_reference(tag):
     fx0 = load_fixture("vae_train_tiny")
