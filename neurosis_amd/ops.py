@@ -923,7 +923,8 @@ def cat_fwd(a: Img, b: Img):
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
-def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head: int, causal: bool = False, need_lse: bool = True):
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head: int, causal: bool = False, need_lse: bool = True,
+                  return_lse: bool = False):
     """softmax(q k^T / sqrt(d)) v.  q [B*Lq, H*D], k/v [B*Lk, H*D] token matrices (column slices allowed).
     bwd(do) -> (dq, dk, dv) dense token matrices.  causal=True (frozen text transformers) is forward only.
     dim_head = 512 (the VAE mid block): csrc/attn512.h forward (need_lse=False skips the log-sum-exp output: inference), csrc/attn512_bwd.h backward."""
@@ -958,6 +959,8 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, heads: int, dim_head:
              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), _stream())
         return dq, dk, dv
 
+    if return_lse:              # [B, heads, Lq] fp32, natural log of the row sums of exp(scale q k^T) (the chunked recompute backward rebuilds P from it)
+        return o, bwd, lse
     return o, bwd
 
 
@@ -1009,8 +1012,8 @@ def attention512_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
     if L % 8:
         raise ValueError(f"attention512_fwd: the chunked recompute backward (L = {L} > {ATTN512_FLASH_MAX_L} tokens per sample, or NK_ATTN512_BWD=0) "
                          f"needs L % 8 == 0; NK_ATTN512_BWD=1 selects the flash backward, which takes any length")
-    out = attention_fwd(q, k, v, B, 1, D, need_lse=False)[0]
-    return out, _attention_recompute_bwd(q, k, v, B)
+    out, _, lse = attention_fwd(q, k, v, B, 1, D, need_lse=True, return_lse=True)
+    return out, _attention_recompute_bwd(q, k, v, B, lse=lse.reshape(B * L))
 
 
 def attention_anydim_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
@@ -1024,10 +1027,29 @@ def attention_anydim_fwd(q: Tensor, k: Tensor, v: Tensor, B: int):
     return attention_unfused(q, k, v, B), _attention_recompute_bwd(q, k, v, B)
 
 
-def _attention_recompute_bwd(q: Tensor, k: Tensor, v: Tensor, B: int):
-    """bwd(do) -> (dq, dk, dv) of single-head attention by recomputing the probabilities chunk by chunk (attention512_fwd has the formulae)."""
+def _attention_recompute_bwd(q: Tensor, k: Tensor, v: Tensor, B: int, lse: Optional[Tensor] = None):
+    """bwd(do) -> (dq, dk, dv) of single-head attention by recomputing the probabilities chunk by chunk (attention512_fwd has the formulae).
+
+    lse ([B*L] fp32: the flash forward's log-sum-exp per query row) makes the rebuilt probabilities follow the forward's.  The scores
+    GEMM writes bf16; a score of 40 has a bf16 spacing of 0.25, so exp() of the ROUNDED score is off by up to 13 % -- while the forward exponentiated
+    fp32 scores.  With lse the row's log-sum-exp is subtracted INSIDE the GEMM, before the rounding: q gets eight more columns holding -lse / scale as
+    three bf16 pieces (exact to 2^-24 relative) and k eight more of ones, so the accumulator holds scale q.k - lse in fp32 and what is rounded to bf16
+    is log p: <= 0, with |log p| <= 4 for every entry that carries weight -- spacing <= 2^-6, 1.6 % at worst, typically 0.4 %.  nk_softmax_rows then
+    renormalises the row (its sum is 1 up to those roundings)."""
     L, D = q.shape[0] // B, q.shape[1]
     scale = float(D) ** -0.5
+    if lse is not None:
+        neg = -lse.to(torch.float32) / scale
+        p1 = neg.to(BF16)
+        r1 = neg - p1.float()
+        p2 = r1.to(BF16)
+        p3 = (r1 - p2.float()).to(BF16)
+        q_aug = torch.cat([q, torch.stack([p1, p2, p3], dim=1), torch.zeros(q.shape[0], 5, dtype=BF16, device=q.device)], dim=1)
+        ones = torch.zeros(k.shape[0], 8, dtype=BF16, device=k.device)
+        ones[:, :3] = 1.0
+        k_aug = torch.cat([k, ones], dim=1)
+    else:
+        q_aug, k_aug = q, k
 
     def bwd(do: Tensor):
         _check2d(do, "do")
@@ -1039,7 +1061,7 @@ def _attention_recompute_bwd(q: Tensor, k: Tensor, v: Tensor, B: int):
                 rows = slice(b * L + c0, b * L + min(c0 + ATTN512_BWD_CHUNK, L))
                 keys = slice(b * L, (b + 1) * L)
                 n = rows.stop - rows.start
-                p = gemm_nt(q[rows], k[keys], alpha=scale)                         # scores [n, L] ...
+                p = gemm_nt(q_aug[rows], k_aug[keys], alpha=scale)                 # scores [n, L] (minus the row's log-sum-exp where known) ...
                 call("nk_softmax_rows", p.data_ptr(), n, L, _stream())             # ... -> probabilities, as the forward's
                 dp = gemm_nt(do[rows], v[keys])                                     # dP = dO V^T
                 gemm_tn_f32(p, do[rows], dv32, c0 > 0)                              # dV (+)= P^T dO

@@ -75,6 +75,34 @@ def test_attention512_backward_vs_autograd(impl, chunk, B, L, monkeypatch):
         assert e <= 3e-2 and cs >= 0.999, (name, e, cs)
 
 
+def test_attention512_recompute_backward_follows_the_forward_at_large_logits(monkeypatch):
+    """the chunked recompute backward (what L > 2 048 tokens per sample selects) rebuilt the probabilities from bf16-ROUNDED scores
+    while the flash forward exponentiates fp32 scores; at logits of 30-50 (spacing 0.25) that put errors of 10 % and more into P and dS.  Now the row's
+    log-sum-exp from the forward is subtracted inside the scores GEMM, before the rounding.  Scores here reach ~45."""
+    from neurosis_amd import ops
+
+    monkeypatch.setenv("NK_ATTN512_BWD", "0")
+    g = torch.Generator().manual_seed(5)
+    B, L, D = 1, 512, 512
+    q = (torch.randn(B * L, D, generator=g) * 3.3).to(torch.bfloat16)
+    k = (torch.randn(B * L, D, generator=g) * 3.0).to(torch.bfloat16)
+    v, do = (torch.randn(B * L, D, generator=g).to(torch.bfloat16) for _ in range(2))
+    qr, kr, vr = (t.float().reshape(B, L, D).requires_grad_(True) for t in (q, k, v))
+    sc = (qr @ kr.transpose(1, 2)) * D ** -0.5
+    assert float(sc.detach().max()) > 35.0
+    ref = sc.softmax(-1) @ vr
+    ref.backward(do.float().reshape(B, L, D))
+    o, bwd = ops.attention512_fwd(q.cuda(), k.cuda(), v.cuda(), B)
+    errs = {}
+    for name, got, want in zip("qkv", bwd(do.cuda()), (qr.grad, kr.grad, vr.grad)):
+        errs[name] = (rel_err(got, want.reshape(B * L, D)), cosine(got, want.reshape(B * L, D)))
+    # the same backward WITHOUT the forward's log-sum-exp (the round-5 form), for the record in the failure message
+    old = ops._attention_recompute_bwd(q.cuda(), k.cuda(), v.cuda(), B)(do.cuda())
+    errs_old = {n: (rel_err(g_, w.reshape(B * L, D)), cosine(g_, w.reshape(B * L, D))) for n, g_, w in zip("qkv", old, (qr.grad, kr.grad, vr.grad))}
+    for name, (e, cs) in errs.items():      # measured 3.4e-3 .. 4.7e-3 with the log-sum-exp, 1.8e-2 .. 3.9e-2 without
+        assert e <= 1e-2 and cs >= 0.9999 and e < 0.5 * errs_old[name][0], (name, e, cs, errs_old[name])
+
+
 @pytest.mark.parametrize("D,B,L,chunk", [(256, 2, 256, 2048), (384, 1, 1024, 2048), (200, 2, 64, 2048), (256, 1, 200, 96)])
 def test_attention_of_any_head_dim_backward_vs_autograd(D, B, L, chunk, monkeypatch):
     """ops.attention_anydim_fwd: the mid-block attention of an autoencoder whose last level is neither <= 160 nor 512 channels wide
