@@ -146,7 +146,15 @@ class FlatAdafactor:
         self.counters = torch.zeros(n_counters, dtype=torch.int32, device=dev)
         self.nitems, self.ntensors = len(items), len(store.params)
         self.state = torch.zeros(max(state_off, 1), dtype=torch.float32, device=dev)
-        self.ws = torch.empty(max(ws_max, 1), dtype=torch.float32, device=dev)
+        # NK_AF_STREAMS (default 1; 2 = A/B): consecutive chunks alternate between two streams forked from the caller's, so that one chunk's
+        # tail (counter round trips, finishing blocks) runs beside the next chunk's loads.  Chunks share nothing but the
+        # partial-sum workspace, which then exists once per stream.
+        import os as _os
+
+        self.nstreams = 2 if _os.environ.get("NK_AF_STREAMS", "1") == "2" else 1
+        self._side = None
+        self.ws = torch.empty(max(ws_max, 1) * self.nstreams, dtype=torch.float32, device=dev)
+        self._ws_stride = max(ws_max, 1)
         self.u2_part = torch.zeros(self.nitems, dtype=torch.float32, device=dev)
         self.p2_part = torch.zeros(self.nitems, dtype=torch.float32, device=dev)
         self.mean_row = torch.zeros(max(mr_slots, 1), dtype=torch.float32, device=dev)
@@ -191,11 +199,11 @@ class FlatAdafactor:
         self._p2_valid = False
 
     # -- the update -------------------------------------------------------------------------------
-    def _args(self, chunk, beta2t: float, rel_step: float, grad_scale: float) -> _Args:
+    def _args(self, chunk, beta2t: float, rel_step: float, grad_scale: float, ws_slot: int = 0) -> _Args:
         t0, t1, i0, i1 = chunk
         s = self.store
         has_matrix = int((self._tens_np["kind"][t0:t1] == 1).any())
-        return _Args(s.master.data_ptr(), s.grad.data_ptr(), s.shadow.data_ptr(), self.state.data_ptr(), self.ws.data_ptr(),
+        return _Args(s.master.data_ptr(), s.grad.data_ptr(), s.shadow.data_ptr(), self.state.data_ptr(), self.ws.data_ptr() + 4 * self._ws_stride * ws_slot,
                      self.tensors.data_ptr(), self.items.data_ptr(), self.u2_part.data_ptr(), self.p2_part.data_ptr(),
                      self.mean_row.data_ptr(), self.scale.data_ptr(), self.lr_t.data_ptr(), i0, i1, t0, t1,
                      beta2t, self.eps[0], self.eps[1], self.clip_threshold, rel_step, self.weight_decay, grad_scale,
@@ -217,8 +225,20 @@ class FlatAdafactor:
     def step(self, grad_scale: float = 1.0) -> None:
         """One Adafactor update of every parameter (adafactor.py:162-255); also rewrites the bf16 shadows."""
         self.begin_step()
-        for ci in range(len(self.chunks)):
-            self.step_chunk(ci, grad_scale)
+        if self.nstreams == 2 and self.store.master.is_cuda:
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = [torch.cuda.Stream(device=self.store.master.device) for _ in range(2)]
+            for st in self._side:
+                st.wait_stream(cur)
+            for ci in range(len(self.chunks)):
+                with torch.cuda.stream(self._side[ci & 1]):
+                    self.step_chunk(ci, grad_scale, ws_slot=ci & 1)
+            for st in self._side:
+                cur.wait_stream(st)
+        else:
+            for ci in range(len(self.chunks)):
+                self.step_chunk(ci, grad_scale)
         self.end_step()
 
     # -- the same update, chunk by chunk: a chunk may be issued as soon as ITS gradients are final (DiffusionEngine streams the
@@ -233,13 +253,13 @@ class FlatAdafactor:
         self._rel = self.rel_step(self.step_count)
         self._done = [False] * len(self.chunks)
 
-    def step_chunk(self, ci: int, grad_scale: float = 1.0) -> None:
+    def step_chunk(self, ci: int, grad_scale: float = 1.0, ws_slot: int = 0) -> None:
         if self._done[ci]:
             return
         if not self._mine(ci):          # another rank's shard
             self._done[ci] = True
             return
-        a = self._args(self.chunks[ci], self._beta2t, self._rel, grad_scale)
+        a = self._args(self.chunks[ci], self._beta2t, self._rel, grad_scale, ws_slot)
         call("nk_adafactor_chunk", C.byref(a), ops._stream())
         self._done[ci] = True
 

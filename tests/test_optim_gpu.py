@@ -26,10 +26,13 @@ def set_grads(params, grads, scale=1.0):
         p.grad.copy_(g.cuda() * scale)
 
 
+@pytest.mark.parametrize("streams", ["1", "2"])
 @pytest.mark.parametrize("tag", ["relative", "manual"])
-def test_flat_adafactor_matches_reference_steps(tag):
+def test_flat_adafactor_matches_reference_steps(tag, streams, monkeypatch):
+    """(streams = 2: NK_AF_STREAMS=2, consecutive chunks alternating between two streams with a workspace each)"""
     from neurosis_amd.optim import FlatAdafactor
 
+    monkeypatch.setenv("NK_AF_STREAMS", streams)
     c = load_fixture("adafactor_steps")[tag]
     store, params = make_store(c["init"])
     opt = FlatAdafactor(store, chunk_bytes=8 << 10, **c["kwargs"])   # tiny chunks: several chunks even for this small set
